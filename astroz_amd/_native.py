@@ -1,0 +1,278 @@
+"""ctypes binding of libastroz_hip.so (include/astroz_hip.h).
+
+This is the ONLY compute path of the package: there is no NumPy / CPU fallback.  If the shared
+library is missing, or no MI355X is visible, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libastroz_hip.so")
+
+WGS84, WGS72 = 0, 1
+OUT_TEME, OUT_ECEF, OUT_GEODETIC = 0, 1, 2
+SAT_MAJOR, TIME_MAJOR = 0, 1
+OUTPUT_MODES = {"teme": OUT_TEME, "ecef": OUT_ECEF, "geodetic": OUT_GEODETIC}
+
+AZ_ERR_HIP = -200
+
+# every symbol include/astroz_hip.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "astroz_version", "astroz_init", "astroz_deinit", "tle_parse", "tle_free",
+    "tle_get_satellite_number", "tle_get_epoch", "tle_get_inclination", "tle_get_eccentricity",
+    "tle_get_mean_motion", "sgp4_init", "sgp4_free", "sgp4_propagate", "sgp4_propagate_batch",
+    "azh_device_count", "azh_last_error", "azh_parse_tle_lines", "azh_constellation_from_tle_text",
+    "azh_constellation_from_tle_lines", "azh_constellation_from_elements", "azh_constellation_free",
+    "azh_num_satellites", "azh_num_sgp4", "azh_num_sdp4", "azh_get_epochs", "azh_get_status",
+    "azh_get_field", "azh_propagate_host", "azh_propagate_device", "azh_propagate_device_cached",
+    "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile",
+    "azh_last_kernel_ms",
+]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, what):
+        self.code = code
+        super().__init__("%s failed with code %d%s" % (what, code, _detail(code)))
+
+
+_lib = None
+
+
+def _detail(code):
+    if _lib is not None and code == AZ_ERR_HIP:
+        msg = _lib.azh_last_error().decode(errors="replace")
+        return " (%s)" % msg if msg else " (HIP runtime error: is an MI355X visible?)"
+    return ""
+
+
+def lib():
+    """Load libastroz_hip.so.  Fails loudly if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "astroz_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, dbl, i32, u32 = C.c_void_p, C.c_size_t, C.c_double, C.c_int32, C.c_uint32
+    L.astroz_version.restype = u32
+    L.tle_parse.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.tle_parse.restype = i32
+    L.tle_free.argtypes = [vp]
+    L.tle_get_satellite_number.argtypes = [vp]
+    L.tle_get_satellite_number.restype = u32
+    for f in ("tle_get_epoch", "tle_get_inclination", "tle_get_eccentricity", "tle_get_mean_motion"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = dbl
+    L.sgp4_init.argtypes = [vp, i32, C.POINTER(vp)]
+    L.sgp4_init.restype = i32
+    L.sgp4_free.argtypes = [vp]
+    L.sgp4_propagate.argtypes = [vp, dbl, vp, vp]
+    L.sgp4_propagate.restype = i32
+    L.sgp4_propagate_batch.argtypes = [vp, vp, vp, u32]
+    L.sgp4_propagate_batch.restype = i32
+    L.azh_device_count.restype = C.c_int
+    L.azh_last_error.restype = C.c_char_p
+    L.azh_parse_tle_lines.argtypes = [C.c_char_p, C.c_char_p, vp]
+    L.azh_parse_tle_lines.restype = i32
+    L.azh_constellation_from_tle_text.argtypes = [C.c_char_p, sz, i32, i32, C.POINTER(vp)]
+    L.azh_constellation_from_tle_text.restype = i32
+    L.azh_constellation_from_tle_lines.argtypes = [vp, vp, sz, i32, i32, C.POINTER(vp)]
+    L.azh_constellation_from_tle_lines.restype = i32
+    L.azh_constellation_from_elements.argtypes = [sz] + [vp] * 8 + [i32, i32, C.POINTER(vp)]
+    L.azh_constellation_from_elements.restype = i32
+    L.azh_constellation_free.argtypes = [vp]
+    for f in ("azh_num_satellites", "azh_num_sgp4", "azh_num_sdp4"):
+        getattr(L, f).argtypes = [vp]
+        getattr(L, f).restype = sz
+    L.azh_get_epochs.argtypes = [vp, vp]
+    L.azh_get_epochs.restype = i32
+    L.azh_get_status.argtypes = [vp, vp, vp, vp]
+    L.azh_get_status.restype = i32
+    L.azh_get_field.argtypes = [vp, C.c_char_p, vp]
+    L.azh_get_field.restype = i32
+    L.azh_propagate_host.argtypes = [vp, vp, sz, vp, vp, vp, i32, dbl, vp, i32, sz, vp]
+    L.azh_propagate_host.restype = i32
+    L.azh_propagate_device.argtypes = [vp, vp, sz, vp, vp, vp, i32, dbl, vp, i32, sz, vp, vp]
+    L.azh_propagate_device.restype = i32
+    L.azh_propagate_device_cached.argtypes = [vp, vp, vp, i32, sz, vp, vp]
+    L.azh_propagate_device_cached.restype = i32
+    L.azh_propagate_jd_host.argtypes = [vp, vp, vp, sz, vp, vp, i32, i32, vp]
+    L.azh_propagate_jd_host.restype = i32
+    L.azh_synchronize.argtypes = [vp]
+    L.azh_synchronize.restype = i32
+    L.azh_propagate_one_host.argtypes = [vp, sz, vp, sz, vp, vp, vp]
+    L.azh_propagate_one_host.restype = i32
+    L.azh_set_time_tile.argtypes = [vp, u32, u32]
+    L.azh_set_time_tile.restype = i32
+    L.azh_last_kernel_ms.argtypes = [vp]
+    L.azh_last_kernel_ms.restype = dbl
+    _lib = L
+    return L
+
+
+def check(code, what):
+    if code != 0:
+        raise NativeError(code, what)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class DeviceConstellation:
+    """Owner of one azh_constellation handle (device-resident element table)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        L = lib()
+        self.n = L.azh_num_satellites(handle)
+        self.n_sgp4 = L.azh_num_sgp4(handle)
+        self.n_sdp4 = L.azh_num_sdp4(handle)
+        self._epochs = None
+        self._status = None
+
+    # -- constructors ------------------------------------------------------------------
+    @classmethod
+    def from_tle_text(cls, text, grav=WGS72, device=0):
+        b = text.encode() if isinstance(text, str) else bytes(text)
+        h = C.c_void_p()
+        check(lib().azh_constellation_from_tle_text(b, len(b), grav, device, C.byref(h)),
+              "azh_constellation_from_tle_text")
+        return cls(h)
+
+    @classmethod
+    def from_tle_lines(cls, pairs, grav=WGS72, device=0):
+        n = len(pairs)
+        a1 = (C.c_char_p * n)(*[p[0].encode() for p in pairs])
+        a2 = (C.c_char_p * n)(*[p[1].encode() for p in pairs])
+        h = C.c_void_p()
+        check(lib().azh_constellation_from_tle_lines(a1, a2, n, grav, device, C.byref(h)),
+              "azh_constellation_from_tle_lines")
+        return cls(h)
+
+    @classmethod
+    def from_elements(cls, epoch_jd, mm_revday, ecc, incl_deg, raan_deg, argp_deg, ma_deg, bstar,
+                      grav=WGS72, device=0):
+        cols = [_f64(x) for x in (epoch_jd, mm_revday, ecc, incl_deg, raan_deg, argp_deg, ma_deg, bstar)]
+        n = len(cols[0])
+        assert all(len(c) == n for c in cols)
+        h = C.c_void_p()
+        check(lib().azh_constellation_from_elements(n, *[c.ctypes.data for c in cols], grav, device,
+                                                    C.byref(h)), "azh_constellation_from_elements")
+        return cls(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().azh_constellation_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- queries -----------------------------------------------------------------------
+    @property
+    def epochs(self):
+        if self._epochs is None:
+            e = np.empty(self.n, dtype=np.float64)
+            check(lib().azh_get_epochs(self._h, e.ctypes.data), "azh_get_epochs")
+            self._epochs = e
+        return self._epochs
+
+    @property
+    def status(self):
+        """(init error code, is_deep, irez) per satellite."""
+        if self._status is None:
+            e = np.empty(self.n, dtype=np.uint8)
+            d = np.empty(self.n, dtype=np.uint8)
+            r = np.empty(self.n, dtype=np.uint8)
+            check(lib().azh_get_status(self._h, e.ctypes.data, d.ctypes.data, r.ctypes.data), "azh_get_status")
+            self._status = (e, d.astype(bool), r)
+        return self._status
+
+    def field(self, name):
+        out = np.empty(self.n, dtype=np.float64)
+        check(lib().azh_get_field(self._h, name.encode(), out.ctypes.data), "azh_get_field(%s)" % name)
+        return out
+
+    def set_time_tile(self, sgp4_tile=0, sdp4_tile=0):
+        check(lib().azh_set_time_tile(self._h, sgp4_tile, sdp4_tile), "azh_set_time_tile")
+
+    # -- propagation -------------------------------------------------------------------
+    def propagate_host(self, times_min, offsets_min=None, *, pos, vel=None, mode=OUT_TEME, reference_jd=0.0,
+                       mask=None, layout=TIME_MAJOR, stride=0, err=None):
+        times = _f64(times_min)
+        off = None if offsets_min is None else _f64(offsets_min)
+        if off is not None and len(off) < self.n:
+            raise ValueError("epoch_offsets must have at least num_satellites elements")
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        if m is not None and len(m) < self.n:
+            raise ValueError("satellite_mask must have at least num_satellites elements")
+        rows = (stride or self.n) if layout == TIME_MAJOR else self.n
+        need = rows * len(times) * 3 * 8
+        for name, arr in (("positions", pos), ("velocities", vel)):
+            if arr is None:
+                continue
+            if arr.dtype != np.float64 or not arr.flags.c_contiguous or not arr.flags.writeable:
+                raise ValueError("%s must be a writable C-contiguous float64 array" % name)
+            if arr.nbytes < need:
+                raise ValueError("%s array too small" % name)
+        if err is not None and (err.dtype != np.uint8 or err.nbytes < self.n * len(times)):
+            raise ValueError("err array too small")
+        check(lib().azh_propagate_host(self._h, times.ctypes.data, len(times), _ptr(off), pos.ctypes.data,
+                                       _ptr(vel), mode, float(reference_jd), _ptr(m), layout, stride,
+                                       _ptr(err)), "azh_propagate_host")
+
+    def propagate_device(self, times_min, offsets_min, d_pos, d_vel=None, *, mode=OUT_TEME, reference_jd=0.0,
+                         mask=None, layout=TIME_MAJOR, stride=0, d_err=None, stream=None):
+        """d_pos/d_vel/d_err are raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous."""
+        times = _f64(times_min)
+        off = None if offsets_min is None else _f64(offsets_min)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        check(lib().azh_propagate_device(self._h, times.ctypes.data, len(times), _ptr(off), d_pos, d_vel, mode,
+                                         float(reference_jd), _ptr(m), layout, stride, d_err, stream),
+              "azh_propagate_device")
+
+    def propagate_device_cached(self, d_pos, d_vel=None, *, layout=TIME_MAJOR, stride=0, d_err=None, stream=None):
+        check(lib().azh_propagate_device_cached(self._h, d_pos, d_vel, layout, stride, d_err, stream),
+              "azh_propagate_device_cached")
+
+    def propagate_one(self, sat_index, tsince_min):
+        t = _f64(np.atleast_1d(tsince_min))
+        n = len(t)
+        pos = np.empty((n, 3))
+        vel = np.empty((n, 3))
+        err = np.empty(n, dtype=np.uint8)
+        check(lib().azh_propagate_one_host(self._h, sat_index, t.ctypes.data, n, pos.ctypes.data, vel.ctypes.data,
+                                           err.ctypes.data), "azh_propagate_one_host")
+        return err, pos, vel
+
+    def synchronize(self):
+        check(lib().azh_synchronize(self._h), "azh_synchronize")
+
+    def last_kernel_ms(self):
+        return lib().azh_last_kernel_ms(self._h)
+
+
+def parse_tle_lines(line1, line2):
+    """All numeric fields of one TLE (host-side text parsing only; no GPU needed)."""
+    out = np.zeros(16, dtype=np.float64)
+    rc = lib().azh_parse_tle_lines(line1.encode(), line2.encode(), out.ctypes.data)
+    if rc != 0:
+        raise ValueError("Failed to parse TLE lines")
+    return out
+
+
+def device_count():
+    return lib().azh_device_count()

@@ -1,0 +1,233 @@
+"""python-sgp4 compatible API, GPU-backed -- mirror of the reference's ``astroz.api``.
+
+Same names and call signatures as bindings/python/astroz/api.py (L86-359): ``Satrec``,
+``SatrecArray``, ``jday``, ``days2mdhms``, ``WGS72``, ``WGS84``, ``WGS72OLD``, ``accelerated``::
+
+    from astroz_amd.api import Satrec, SatrecArray, jday, WGS72
+
+Every propagation runs in HIP kernels on an MI355X through libastroz_hip.so; there is no CPU
+path.  Differences from the reference that are deliberate (SURVEY.md 8a17 "quirks not to copy"):
+
+* error codes are real: ``e`` holds python-sgp4 codes per (satellite, time) and only the failing
+  satellite's row is zero-filled (the reference returns all-zero ``e`` and zero-fills 8 lanes);
+* the deep-space rows of ``SatrecArray.sgp4`` come back satellite-major as documented (the
+  reference's ``sdp4_batch_propagate_into`` writes them time-major into a satellite-major array);
+* ``jday`` is python-sgp4's exact formula (the reference's passes seconds through an f16).
+"""
+import math
+
+import numpy as np
+
+from . import _native
+from ._native import WGS72, WGS84
+
+WGS72OLD = WGS72
+accelerated = True
+
+_TWOPI = 2.0 * math.pi
+_DEG2RAD = math.pi / 180.0
+
+
+def jday(year, mon, day, hr, minute, sec):
+    """Calendar date -> (jd, fr): Julian date at the preceding midnight and the day fraction.
+    python-sgp4's formula; reference Datetime.jday, src/Datetime.zig L235-240."""
+    jd = (367.0 * year - 7 * (year + ((mon + 9) // 12.0)) * 0.25 // 1.0
+          + 275 * mon / 9.0 // 1.0 + day + 1721013.5)
+    fr = (sec + minute * 60.0 + hr * 3600.0) / 86400.0
+    return jd, fr
+
+
+_CUM_DAYS = (0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334, 365)
+
+
+def days2mdhms(year, days):
+    """Fractional day of year -> (month, day, hour, minute, second).
+    reference Datetime.days2mdhms, src/Datetime.zig L244-253."""
+    whole = int(math.floor(days))
+    leap = (year % 4 == 0 and year % 100 != 0) or year % 400 == 0
+    month = 1
+    while month < 12:
+        end = _CUM_DAYS[month] + (1 if leap and month >= 2 else 0)
+        if whole <= end:
+            break
+        month += 1
+    start = _CUM_DAYS[month - 1] + (1 if leap and month > 2 else 0)
+    day = whole - start
+    rem = (days - whole) * 24.0
+    hour = int(math.floor(rem))
+    rem = (rem - hour) * 60.0
+    minute = int(math.floor(rem))
+    second = (rem - minute) * 60.0
+    return month, day, hour, minute, second
+
+
+class Satrec:
+    """One satellite record.  Use :meth:`twoline2rv`.
+
+    TLE text is parsed on the host at construction; the element initialisation (and every
+    propagation) runs on the GPU and is performed lazily -- or in one batch when the record is
+    placed in a :class:`SatrecArray`."""
+
+    def __init__(self, line1, line2, whichconst, fields):
+        self._line1 = line1
+        self._line2 = line2
+        self.whichconst = int(whichconst)
+        self._f = fields
+        epoch_jd = float(fields[3])
+        # python-sgp4 style split (bindings/python/src/satrec.zig L129-131)
+        self.jdsatepoch = math.floor(epoch_jd - 0.5) + 0.5
+        self.jdsatepochF = epoch_jd - self.jdsatepoch
+        self.error = 0
+        self.t = 0.0
+        self._dev = None      # 1-satellite device constellation (lazy)
+        self._status = None   # (err, is_deep, irez), filled by _ensure or by a SatrecArray
+        self._a = None
+
+    @classmethod
+    def twoline2rv(cls, line1, line2, whichconst=WGS72):
+        """Create a Satrec from TLE lines (bindings/python/src/satrec.zig L83-166)."""
+        fields = _native.parse_tle_lines(line1, line2)
+        return cls(line1, line2, whichconst, fields)
+
+    # -- TLE-derived attributes (satrec.zig L390-430) -----------------------------------
+    satnum = property(lambda self: int(self._f[0]))
+    epochyr = property(lambda self: int(self._f[1]))
+    epochdays = property(lambda self: float(self._f[2]))
+    ecco = property(lambda self: float(self._f[8]))
+    inclo = property(lambda self: float(self._f[6]) * _DEG2RAD)
+    nodeo = property(lambda self: float(self._f[7]) * _DEG2RAD)
+    argpo = property(lambda self: float(self._f[9]) * _DEG2RAD)
+    mo = property(lambda self: float(self._f[10]) * _DEG2RAD)
+    no_kozai = property(lambda self: float(self._f[11]) * _TWOPI / 1440.0)
+    bstar = property(lambda self: float(self._f[5]))
+    ndot = property(lambda self: float(self._f[4]) * _TWOPI / (1440.0 * 1440.0))
+
+    # -- device-derived attributes (satrec.zig L432-474) ---------------------------------
+    def _ensure(self):
+        if self._dev is None:
+            self._dev = _native.DeviceConstellation.from_tle_lines(
+                [(self._line1, self._line2)], self.whichconst)
+            e, d, r = self._dev.status
+            self._status = (int(e[0]), bool(d[0]), int(r[0]))
+            if self._status[0]:
+                self.error = self._status[0]
+        return self._dev
+
+    @property
+    def is_deep_space(self):
+        if self._status is None:
+            self._ensure()
+        return self._status[1]
+
+    @property
+    def a(self):
+        if self._a is None:
+            self._a = float(self._ensure().field("a")[0])
+        return self._a
+
+    @property
+    def alta(self):
+        return self.a * (1.0 + self.ecco) - 1.0
+
+    @property
+    def altp(self):
+        return self.a * (1.0 - self.ecco) - 1.0
+
+    # -- propagation ---------------------------------------------------------------------
+    def sgp4(self, jd, fr):
+        """-> (error, (x, y, z) km, (vx, vy, vz) km/s), TEME.  satrec.zig L169-201."""
+        tsince = ((jd + fr) - (self.jdsatepoch + self.jdsatepochF)) * 1440.0
+        self.t = tsince
+        e, r, v = self._ensure().propagate_one(0, tsince)
+        self.error = int(e[0])
+        return self.error, tuple(float(x) for x in r[0]), tuple(float(x) for x in v[0])
+
+    def sgp4_array(self, jd, fr):
+        """Many times, one satellite (lane = time on the GPU).  -> e (n,), r (n,3), v (n,3)."""
+        jd = np.atleast_1d(np.asarray(jd, dtype=np.float64))
+        fr = np.atleast_1d(np.asarray(fr, dtype=np.float64))
+        tsince = ((jd + fr) - (self.jdsatepoch + self.jdsatepochF)) * 1440.0
+        e, r, v = self._ensure().propagate_one(0, tsince)
+        return e, r, v
+
+
+class SatrecArray:
+    """Batch propagator: all satellites x all times in one GPU call.
+
+    Near-earth and deep-space members are handled transparently (two kernels on two streams);
+    the gravity model is the first satellite's, as in the reference (satrec.zig L879-880)."""
+
+    def __init__(self, satrecs, device=0):
+        satrecs = list(satrecs)
+        if not satrecs:
+            raise ValueError("Must provide at least one Satrec object")
+        for s in satrecs:
+            if not isinstance(s, Satrec):
+                raise TypeError("All items must be Satrec objects")
+        self._num_sats = len(satrecs)
+        grav = satrecs[0].whichconst
+        self._dev = _native.DeviceConstellation.from_tle_lines(
+            [(s._line1, s._line2) for s in satrecs], grav, device)
+        err, deep, irez = self._dev.status
+        if err.any():
+            # shared.buildBatches raises on any init failure (shared.zig L78-82)
+            bad = int(np.flatnonzero(err)[0])
+            raise ValueError("%s (satellite index %d)" % (
+                "Invalid eccentricity" if err[bad] == 1 else "Satellite decayed", bad))
+        for s, e, d, r in zip(satrecs, err, deep, irez):
+            if s._status is None and s.whichconst == grav:
+                s._status = (int(e), bool(d), int(r))
+        self._sgp4_indices = np.flatnonzero(~deep)
+        self._sdp4_indices = np.flatnonzero(deep)
+        self._epochs = self._dev.epochs
+
+    @property
+    def num_satellites(self):
+        return self._num_sats
+
+    def _grid(self, jd, fr):
+        jd = np.atleast_1d(np.asarray(jd, dtype=np.float64))
+        fr = np.atleast_1d(np.asarray(fr, dtype=np.float64))
+        # api.py L300-302
+        reference_jd = jd[0] + fr[0]
+        epoch_offsets = (reference_jd - self._epochs) * 1440.0
+        times = ((jd + fr) - reference_jd) * 1440.0
+        return times, epoch_offsets
+
+    def sgp4(self, jd, fr, *, velocities=True):
+        """-> e (n_sats, n_times) uint8, r, v (n_sats, n_times, 3) float64 [km, km/s, TEME].
+
+        Like the reference the arrays are physically time-major and returned as transposed
+        views (api.py L307-320)."""
+        times, offsets = self._grid(jd, fr)
+        n_times, n_sats = len(times), self._num_sats
+        r_tm = np.empty((n_times, n_sats, 3), dtype=np.float64)
+        v_tm = np.empty((n_times, n_sats, 3), dtype=np.float64) if velocities else None
+        e = np.zeros((n_sats, n_times), dtype=np.uint8)
+        self._dev.propagate_host(times, offsets, pos=r_tm, vel=v_tm, layout=_native.TIME_MAJOR, err=e)
+        r = r_tm.transpose(1, 0, 2)
+        v = v_tm.transpose(1, 0, 2) if velocities else np.zeros((n_sats, n_times, 3), dtype=np.float64)
+        return e, r, v
+
+    def sgp4_device(self, jd, fr, *, velocities=True, stream=None):
+        """Same computation, results left resident in HBM: returns torch tensors on the GPU
+        (e (n_sats,n_times) uint8, r_tm, v_tm (n_times, n_sats, 3) float64).  Asynchronous with
+        respect to the host; ordered on the constellation's stream (or `stream`)."""
+        import torch
+
+        times, offsets = self._grid(jd, fr)
+        n_times, n_sats = len(times), self._num_sats
+        dev = torch.device("cuda", torch.cuda.current_device())
+        r_tm = torch.empty((n_times, n_sats, 3), dtype=torch.float64, device=dev)
+        v_tm = torch.empty((n_times, n_sats, 3), dtype=torch.float64, device=dev) if velocities else None
+        e = torch.empty((n_sats, n_times), dtype=torch.uint8, device=dev)
+        torch.cuda.current_stream().synchronize()  # allocations visible before a foreign stream writes
+        self._dev.propagate_device(times, offsets, r_tm.data_ptr(), None if v_tm is None else v_tm.data_ptr(),
+                                   layout=_native.TIME_MAJOR, d_err=e.data_ptr(), stream=stream)
+        return e, r_tm, v_tm
+
+    def synchronize(self):
+        self._dev.synchronize()
+
+
+__all__ = ["Satrec", "SatrecArray", "jday", "days2mdhms", "WGS72", "WGS84", "WGS72OLD", "accelerated"]

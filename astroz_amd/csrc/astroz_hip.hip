@@ -1,0 +1,697 @@
+// astroz_hip.hip -- libastroz_hip.so: C ABI (include/astroz_hip.h) over the gfx950 kernels.
+// gfx950 only; compiled with  hipcc --offload-arch=gfx950.
+#include "../../include/astroz_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "tle_host.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+bool hip_ok(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return false;
+}
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        if (!hip_ok((expr), #expr)) return AZ_ERR_HIP;                                                      \
+    } while (0)
+
+AzGrav make_grav(int which)
+{
+    // src/constants.zig L41-64
+    AzGrav g;
+    if (which == AZ_WGS72) {
+        g.radius_km = 6378.135;
+        g.j2 = 0.001082616;
+        g.j4 = -0.00000165597;
+        g.xke = 0.0743669161331734132;
+        g.j3oj2 = -0.00234506972242078;
+    } else {
+        g.radius_km = 6378.137;
+        g.j2 = 0.00108262998905;
+        g.j4 = -0.00000161098761;
+        g.xke = 0.07436685316871385;
+        g.j3oj2 = -0.00233899967218727;
+    }
+    g.vkmpersec = g.xke * g.radius_km / 60.0; // src/Sgp4.zig L177
+    return g;
+}
+
+const char *const kFieldNames[] = {
+#define X(n) #n,
+    AZ_SGP4_FIELDS(X) AZ_DEEP_FIELDS(X)
+#undef X
+};
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap) return AZ_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max<size_t>(n, 64);
+        if (!hip_ok(hipMalloc((void **)&p, want * sizeof(T)), "hipMalloc")) return AZ_ERR_HIP;
+        cap = want;
+        return AZ_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+} // namespace
+
+struct azh_constellation {
+    int device = 0;
+    size_t n = 0, n_pad = 0;
+    AzGrav g{};
+    double *d_el = nullptr;
+    unsigned *d_flags = nullptr;
+    std::vector<unsigned> h_flags;
+    std::vector<double> h_epoch;
+    // launch lists (table indices)
+    DevBuf<unsigned> d_list; // [sgp4 | sdp4 (ordered by irez) | bad]
+    unsigned n_sgp4 = 0, n_sdp4 = 0, n_bad = 0;
+    // per-call scratch
+    DevBuf<double> d_times, d_offsets, d_sin, d_cos;
+    DevBuf<unsigned char> d_mask;
+    bool have_offsets = false, have_mask = false;
+    unsigned cached_n_times = 0;
+    int cached_mode = 0;
+    hipStream_t s_main = nullptr, s_deep = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    bool timed = false;
+    unsigned tile_sgp4 = 0, tile_sdp4 = 0;
+};
+
+namespace {
+
+int set_device(const azh_constellation *c) { return hip_ok(hipSetDevice(c->device), "hipSetDevice") ? AZ_OK : AZ_ERR_HIP; }
+
+void destroy(azh_constellation *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_el) (void)hipFree(c->d_el);
+    if (c->d_flags) (void)hipFree(c->d_flags);
+    c->d_list.release();
+    c->d_times.release();
+    c->d_offsets.release();
+    c->d_sin.release();
+    c->d_cos.release();
+    c->d_mask.release();
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
+    if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
+    if (c->s_main) (void)hipStreamDestroy(c->s_main);
+    if (c->s_deep) (void)hipStreamDestroy(c->s_deep);
+    delete c;
+}
+
+// raw columns (AzRawField order, each of length n) -> device table via the init kernel
+int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav, int device, azh_constellation **out)
+{
+    if (!out) return AZ_ERR_NULL_POINTER;
+    *out = nullptr;
+    if (n == 0) return AZ_ERR_VALUE;
+    if (n > 0x7fffffffu) return AZ_ERR_VALUE;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        g_last_error = "no such HIP device";
+        return AZ_ERR_HIP;
+    }
+    azh_constellation *c = new (std::nothrow) azh_constellation();
+    if (!c) return AZ_ERR_ALLOC_FAILED;
+    c->device = device;
+    c->n = n;
+    c->n_pad = (n + 63) / 64 * 64;
+    c->g = make_grav(grav);
+    int32_t rc = AZ_OK;
+    double *d_raw = nullptr;
+    do {
+        if (set_device(c) != AZ_OK) { rc = AZ_ERR_HIP; break; }
+        if (!hip_ok(hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking), "hipStreamCreate") ||
+            !hip_ok(hipStreamCreateWithFlags(&c->s_deep, hipStreamNonBlocking), "hipStreamCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreate(&c->ev_t0), "hipEventCreate") || !hip_ok(hipEventCreate(&c->ev_t1), "hipEventCreate")) {
+            rc = AZ_ERR_HIP;
+            break;
+        }
+        const size_t np = c->n_pad;
+        if (!hip_ok(hipMalloc((void **)&c->d_el, sizeof(double) * AZ_NUM_FIELDS * np), "hipMalloc(el)") ||
+            !hip_ok(hipMalloc((void **)&c->d_flags, sizeof(unsigned) * np), "hipMalloc(flags)") ||
+            !hip_ok(hipMalloc((void **)&d_raw, sizeof(double) * AZ_NUM_RAW * np), "hipMalloc(raw)")) {
+            rc = AZ_ERR_HIP;
+            break;
+        }
+        std::vector<double> staging((size_t)AZ_NUM_RAW * np, 0.0);
+        for (int k = 0; k < AZ_NUM_RAW; ++k) memcpy(&staging[(size_t)k * np], cols[k].data(), sizeof(double) * n);
+        if (!hip_ok(hipMemcpyAsync(d_raw, staging.data(), sizeof(double) * staging.size(), hipMemcpyHostToDevice, c->s_main), "H2D raw") ||
+            !hip_ok(hipMemsetAsync(c->d_el, 0, sizeof(double) * AZ_NUM_FIELDS * np, c->s_main), "memset el") ||
+            !hip_ok(hipMemsetAsync(c->d_flags, 0, sizeof(unsigned) * np, c->s_main), "memset flags")) {
+            rc = AZ_ERR_HIP;
+            break;
+        }
+        hipLaunchKernelGGL(k_init, dim3((unsigned)(np / AZ_BLOCK)), dim3(AZ_BLOCK), 0, c->s_main, d_raw, n, np, c->g, c->d_el, c->d_flags);
+        if (!hip_ok(hipGetLastError(), "k_init launch")) { rc = AZ_ERR_HIP; break; }
+        c->h_flags.resize(n);
+        if (!hip_ok(hipMemcpyAsync(c->h_flags.data(), c->d_flags, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->s_main), "D2H flags") ||
+            !hip_ok(hipStreamSynchronize(c->s_main), "sync(init)")) {
+            rc = AZ_ERR_HIP;
+            break;
+        }
+        c->h_epoch = cols[R_epoch_jd];
+        // launch lists: near-earth in catalog order; deep-space grouped by resonance class so that
+        // waves are uniform in the integrator branch; failed inits last
+        std::vector<unsigned> list;
+        list.reserve(n);
+        for (size_t s = 0; s < n; ++s)
+            if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && !(c->h_flags[s] & AZ_FLAG_DEEP)) list.push_back((unsigned)s);
+        c->n_sgp4 = (unsigned)list.size();
+        for (unsigned cls = 0; cls < 3; ++cls)
+            for (size_t s = 0; s < n; ++s)
+                if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && (c->h_flags[s] & AZ_FLAG_DEEP) && AZ_FLAG_IREZ(c->h_flags[s]) == cls)
+                    list.push_back((unsigned)s);
+        c->n_sdp4 = (unsigned)list.size() - c->n_sgp4;
+        for (size_t s = 0; s < n; ++s)
+            if (AZ_FLAG_ERR(c->h_flags[s]) != 0) list.push_back((unsigned)s);
+        c->n_bad = (unsigned)list.size() - c->n_sgp4 - c->n_sdp4;
+        if (c->d_list.ensure(list.size()) != AZ_OK ||
+            !hip_ok(hipMemcpy(c->d_list.p, list.data(), sizeof(unsigned) * list.size(), hipMemcpyHostToDevice), "H2D list")) {
+            rc = AZ_ERR_HIP;
+            break;
+        }
+    } while (0);
+    if (d_raw) (void)hipFree(d_raw);
+    if (rc != AZ_OK) {
+        destroy(c);
+        return rc;
+    }
+    *out = c;
+    return AZ_OK;
+}
+
+int32_t build_from_records(const std::vector<azh::TleRecord> &recs, int grav, int device, azh_constellation **out)
+{
+    std::vector<double> cols[AZ_NUM_RAW];
+    for (auto &v : cols) v.resize(recs.size());
+    for (size_t i = 0; i < recs.size(); ++i) {
+        const azh::TleRecord &r = recs[i];
+        cols[R_epoch_jd][i] = r.epoch_jd;
+        cols[R_mm_revday][i] = r.mm_revday;
+        cols[R_ecc][i] = r.ecc;
+        cols[R_incl_deg][i] = r.incl_deg;
+        cols[R_raan_deg][i] = r.raan_deg;
+        cols[R_argp_deg][i] = r.argp_deg;
+        cols[R_ma_deg][i] = r.ma_deg;
+        cols[R_bstar][i] = r.bstar;
+    }
+    return build(cols, recs.size(), grav, device, out);
+}
+
+unsigned auto_tile(unsigned n_list, unsigned n_times, unsigned forced, unsigned min_tile)
+{
+    if (forced) return std::min(std::max(forced, 1u), std::max(n_times, 1u));
+    // aim for ~16k waves (4 per SIMD x 4 rounds over 1,024 SIMDs) without making tiles so short
+    // that the per-tile element loads and full-sincos seeding dominate
+    const unsigned waves_x = (n_list + AZ_BLOCK - 1) / AZ_BLOCK;
+    unsigned n_tiles = (16384 + waves_x - 1) / std::max(waves_x, 1u);
+    n_tiles = std::max(1u, std::min(n_tiles, n_times));
+    unsigned tile = (n_times + n_tiles - 1) / n_tiles;
+    tile = std::max(tile, std::min(min_tile, n_times));
+    return std::max(tile, 1u);
+}
+
+template <bool DEEP>
+void launch_propagate(const PropArgs &a, int layout, bool vel, hipStream_t st)
+{
+    dim3 grid((a.n_list + AZ_BLOCK - 1) / AZ_BLOCK, (a.n_times + a.tile - 1) / a.tile);
+    dim3 block(AZ_BLOCK);
+    if (layout == AZ_LAYOUT_TIME_MAJOR) {
+        if (vel)
+            hipLaunchKernelGGL((k_propagate<1, true, DEEP>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((k_propagate<1, false, DEEP>), grid, block, 0, st, a);
+    } else {
+        if (vel)
+            hipLaunchKernelGGL((k_propagate<0, true, DEEP>), grid, block, 0, st, a);
+        else
+            hipLaunchKernelGGL((k_propagate<0, false, DEEP>), grid, block, 0, st, a);
+    }
+}
+
+// upload times / offsets / mask and (if needed) build the GMST table
+int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+                     const uint8_t *mask, int mode, double reference_jd, hipStream_t st)
+{
+    if (n_times > 0xffffffffu) return AZ_ERR_VALUE;
+    if (c->d_times.ensure(n_times) != AZ_OK) return AZ_ERR_HIP;
+    HIP_TRY(hipMemcpyAsync(c->d_times.p, times, sizeof(double) * n_times, hipMemcpyHostToDevice, st));
+    c->have_offsets = offsets != nullptr;
+    if (offsets) {
+        if (c->d_offsets.ensure(c->n) != AZ_OK) return AZ_ERR_HIP;
+        HIP_TRY(hipMemcpyAsync(c->d_offsets.p, offsets, sizeof(double) * c->n, hipMemcpyHostToDevice, st));
+    }
+    c->have_mask = mask != nullptr;
+    if (mask) {
+        if (c->d_mask.ensure(c->n) != AZ_OK) return AZ_ERR_HIP;
+        HIP_TRY(hipMemcpyAsync(c->d_mask.p, mask, c->n, hipMemcpyHostToDevice, st));
+    }
+    if (mode != AZ_OUT_TEME) {
+        if (c->d_sin.ensure(n_times) != AZ_OK || c->d_cos.ensure(n_times) != AZ_OK) return AZ_ERR_HIP;
+        hipLaunchKernelGGL(k_gmst, dim3((unsigned)((n_times + 255) / 256)), dim3(256), 0, st, c->d_times.p,
+                           (unsigned)n_times, reference_jd, c->d_sin.p, c->d_cos.p);
+        HIP_TRY(hipGetLastError());
+    }
+    c->cached_n_times = (unsigned)n_times;
+    c->cached_mode = mode;
+    return AZ_OK;
+}
+
+// the launches proper; inputs already staged on the device
+int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layout, size_t stride, uint8_t *d_err,
+                   hipStream_t st)
+{
+    const unsigned n_times = c->cached_n_times;
+    if (n_times == 0) return AZ_OK;
+    if (stride == 0) stride = c->n;
+    if (layout == AZ_LAYOUT_TIME_MAJOR && stride < c->n) return AZ_ERR_VALUE;
+
+    PropArgs a{};
+    a.el = c->d_el;
+    a.flags = c->d_flags;
+    a.n_pad = c->n_pad;
+    a.times = c->d_times.p;
+    a.n_times = n_times;
+    a.offsets = c->have_offsets ? c->d_offsets.p : nullptr;
+    a.pos = d_pos;
+    a.vel = d_vel;
+    a.sin_g = c->d_sin.p;
+    a.cos_g = c->d_cos.p;
+    a.mask = c->have_mask ? c->d_mask.p : nullptr;
+    a.err = d_err;
+    a.stride_sats = stride;
+    a.mode = c->cached_mode;
+    a.g = c->g;
+
+    HIP_TRY(hipEventRecord(c->ev_t0, st));
+    if (d_err) HIP_TRY(hipMemsetAsync(d_err, 0, c->n * (size_t)n_times, st));
+    const bool fork = c->n_sdp4 > 0;
+    if (fork) {
+        // deep-space rows on their own stream, concurrent with the near-earth launch
+        HIP_TRY(hipEventRecord(c->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(c->s_deep, c->ev_fork, 0));
+        PropArgs d = a;
+        d.list = c->d_list.p + c->n_sgp4;
+        d.n_list = c->n_sdp4;
+        d.tile = auto_tile(c->n_sdp4, n_times, c->tile_sdp4, 8);
+        launch_propagate<true>(d, layout, d_vel != nullptr, c->s_deep);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev_join, c->s_deep));
+    }
+    if (c->n_sgp4 > 0) {
+        a.list = c->d_list.p;
+        a.n_list = c->n_sgp4;
+        a.tile = auto_tile(c->n_sgp4, n_times, c->tile_sgp4, 8);
+        launch_propagate<false>(a, layout, d_vel != nullptr, st);
+        HIP_TRY(hipGetLastError());
+    }
+    if (c->n_bad > 0) {
+        hipLaunchKernelGGL(k_fill_bad, dim3((n_times + 255) / 256, c->n_bad), dim3(256), 0, st,
+                           c->d_list.p + c->n_sgp4 + c->n_sdp4, c->n_bad, c->d_flags, n_times, d_pos, d_vel, d_err,
+                           c->have_mask ? c->d_mask.p : nullptr, layout, stride);
+        HIP_TRY(hipGetLastError());
+    }
+    if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
+    HIP_TRY(hipEventRecord(c->ev_t1, st));
+    c->timed = true;
+    return AZ_OK;
+}
+
+} // namespace
+
+// ======================================================================================= (B)
+extern "C" {
+
+int azh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+const char *azh_last_error(void) { return g_last_error.c_str(); }
+
+int32_t azh_parse_tle_lines(const char *line1, const char *line2, double *o)
+{
+    if (!line1 || !line2 || !o) return AZ_ERR_NULL_POINTER;
+    azh::TleRecord r;
+    int rc = azh::parse_lines(line1, line2, r);
+    if (rc == -1) return AZ_ERR_BAD_TLE_LENGTH;
+    if (rc != 0) return AZ_ERR_UNKNOWN;
+    o[0] = r.satnum; o[1] = r.epoch_year; o[2] = r.epoch_day; o[3] = r.epoch_jd; o[4] = r.ndot; o[5] = r.bstar;
+    o[6] = r.incl_deg; o[7] = r.raan_deg; o[8] = r.ecc; o[9] = r.argp_deg; o[10] = r.ma_deg; o[11] = r.mm_revday;
+    o[12] = r.elnum; o[13] = r.revnum; o[14] = (double)(unsigned char)r.classification; o[15] = 0.0;
+    return AZ_OK;
+}
+
+int32_t azh_constellation_from_tle_text(const char *text, size_t len, int32_t grav, int32_t device,
+                                        azh_constellation **out)
+{
+    if (!text || !out) return AZ_ERR_NULL_POINTER;
+    std::vector<azh::TleRecord> recs;
+    azh::parse_all(std::string_view(text, len), recs);
+    if (recs.empty()) return AZ_ERR_BAD_TLE_LENGTH;
+    return build_from_records(recs, grav, device, out);
+}
+
+int32_t azh_constellation_from_tle_lines(const char *const *line1, const char *const *line2, size_t n,
+                                         int32_t grav, int32_t device, azh_constellation **out)
+{
+    if (!line1 || !line2 || !out) return AZ_ERR_NULL_POINTER;
+    std::vector<azh::TleRecord> recs(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (!line1[i] || !line2[i]) return AZ_ERR_NULL_POINTER;
+        int rc = azh::parse_lines(line1[i], line2[i], recs[i]);
+        if (rc == -1) return AZ_ERR_BAD_TLE_LENGTH;
+        if (rc != 0) return AZ_ERR_UNKNOWN;
+    }
+    return build_from_records(recs, grav, device, out);
+}
+
+int32_t azh_constellation_from_elements(size_t n, const double *epoch_jd, const double *mm, const double *ecc,
+                                        const double *incl, const double *raan, const double *argp,
+                                        const double *ma, const double *bstar, int32_t grav, int32_t device,
+                                        azh_constellation **out)
+{
+    if (!epoch_jd || !mm || !ecc || !incl || !raan || !argp || !ma || !bstar || !out) return AZ_ERR_NULL_POINTER;
+    std::vector<double> cols[AZ_NUM_RAW];
+    const double *src[AZ_NUM_RAW] = {epoch_jd, mm, ecc, incl, raan, argp, ma, bstar};
+    for (int k = 0; k < AZ_NUM_RAW; ++k) cols[k].assign(src[k], src[k] + n);
+    return build(cols, n, grav, device, out);
+}
+
+void azh_constellation_free(azh_constellation *c) { destroy(c); }
+
+size_t azh_num_satellites(const azh_constellation *c) { return c ? c->n : 0; }
+size_t azh_num_sgp4(const azh_constellation *c) { return c ? c->n_sgp4 : 0; }
+size_t azh_num_sdp4(const azh_constellation *c) { return c ? c->n_sdp4 : 0; }
+
+int32_t azh_get_epochs(const azh_constellation *c, double *out)
+{
+    if (!c || !out) return AZ_ERR_NULL_POINTER;
+    memcpy(out, c->h_epoch.data(), sizeof(double) * c->n);
+    return AZ_OK;
+}
+
+int32_t azh_get_status(const azh_constellation *c, uint8_t *err, uint8_t *deep, uint8_t *irez)
+{
+    if (!c) return AZ_ERR_NULL_POINTER;
+    for (size_t s = 0; s < c->n; ++s) {
+        const unsigned f = c->h_flags[s];
+        if (err) err[s] = (uint8_t)AZ_FLAG_ERR(f);
+        if (deep) deep[s] = (f & AZ_FLAG_DEEP) ? 1 : 0;
+        if (irez) irez[s] = (uint8_t)AZ_FLAG_IREZ(f);
+    }
+    return AZ_OK;
+}
+
+int32_t azh_get_field(const azh_constellation *c, const char *name, double *out)
+{
+    if (!c || !name || !out) return AZ_ERR_NULL_POINTER;
+    for (int k = 0; k < AZ_NUM_FIELDS; ++k) {
+        if (strcmp(kFieldNames[k], name) == 0) {
+            if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+            HIP_TRY(hipMemcpy(out, c->d_el + (size_t)k * c->n_pad, sizeof(double) * c->n, hipMemcpyDeviceToHost));
+            return AZ_OK;
+        }
+    }
+    return AZ_ERR_VALUE;
+}
+
+int32_t azh_set_time_tile(azh_constellation *c, uint32_t sgp4_tile, uint32_t sdp4_tile)
+{
+    if (!c) return AZ_ERR_NULL_POINTER;
+    c->tile_sgp4 = sgp4_tile;
+    c->tile_sdp4 = sdp4_tile;
+    return AZ_OK;
+}
+
+int32_t azh_propagate_device(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+                             double *d_pos, double *d_vel, int32_t mode, double reference_jd, const uint8_t *mask,
+                             int32_t layout, size_t stride, uint8_t *d_err, void *stream)
+{
+    if (!c || !d_pos || (n_times && !times)) return AZ_ERR_NULL_POINTER;
+    if (mode < 0 || mode > 2 || layout < 0 || layout > 1) return AZ_ERR_VALUE;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    hipStream_t st = stream ? (hipStream_t)stream : c->s_main;
+    int32_t rc = stage_inputs(c, times, n_times, offsets, mask, mode, reference_jd, st);
+    if (rc != AZ_OK) return rc;
+    return launch_all(c, d_pos, d_vel, layout, stride, d_err, st);
+}
+
+int32_t azh_propagate_device_cached(azh_constellation *c, double *d_pos, double *d_vel, int32_t layout,
+                                    size_t stride, uint8_t *d_err, void *stream)
+{
+    if (!c || !d_pos) return AZ_ERR_NULL_POINTER;
+    if (layout < 0 || layout > 1) return AZ_ERR_VALUE;
+    if (c->cached_n_times == 0) return AZ_ERR_NOT_INITIALIZED;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    return launch_all(c, d_pos, d_vel, layout, stride, d_err, stream ? (hipStream_t)stream : c->s_main);
+}
+
+int32_t azh_propagate_host(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+                           double *pos, double *vel, int32_t mode, double reference_jd, const uint8_t *mask,
+                           int32_t layout, size_t stride, uint8_t *err)
+{
+    if (!c || !pos || (n_times && !times)) return AZ_ERR_NULL_POINTER;
+    if (n_times == 0) return AZ_OK;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    if (stride == 0) stride = c->n;
+    const size_t rows = (layout == AZ_LAYOUT_TIME_MAJOR) ? stride : c->n;
+    const size_t bytes = rows * n_times * 3 * sizeof(double);
+    double *d_pos = nullptr, *d_vel = nullptr;
+    uint8_t *d_err = nullptr;
+    int32_t rc = AZ_OK;
+    do {
+        if (!hip_ok(hipMalloc((void **)&d_pos, bytes), "hipMalloc(pos)")) { rc = AZ_ERR_HIP; break; }
+        if (vel && !hip_ok(hipMalloc((void **)&d_vel, bytes), "hipMalloc(vel)")) { rc = AZ_ERR_HIP; break; }
+        if (err && !hip_ok(hipMalloc((void **)&d_err, c->n * n_times), "hipMalloc(err)")) { rc = AZ_ERR_HIP; break; }
+        // rows the kernels do not touch (masked satellites, stride padding) must come back unchanged
+        const bool partial = mask != nullptr || (layout == AZ_LAYOUT_TIME_MAJOR && stride > c->n);
+        if (partial) {
+            if (!hip_ok(hipMemcpyAsync(d_pos, pos, bytes, hipMemcpyHostToDevice, c->s_main), "H2D pos")) { rc = AZ_ERR_HIP; break; }
+            if (vel && !hip_ok(hipMemcpyAsync(d_vel, vel, bytes, hipMemcpyHostToDevice, c->s_main), "H2D vel")) { rc = AZ_ERR_HIP; break; }
+        }
+        rc = azh_propagate_device(c, times, n_times, offsets, d_pos, d_vel, mode, reference_jd, mask, layout, stride, d_err, nullptr);
+        if (rc != AZ_OK) break;
+        if (!hip_ok(hipMemcpyAsync(pos, d_pos, bytes, hipMemcpyDeviceToHost, c->s_main), "D2H pos")) { rc = AZ_ERR_HIP; break; }
+        if (vel && !hip_ok(hipMemcpyAsync(vel, d_vel, bytes, hipMemcpyDeviceToHost, c->s_main), "D2H vel")) { rc = AZ_ERR_HIP; break; }
+        if (err && !hip_ok(hipMemcpyAsync(err, d_err, c->n * n_times, hipMemcpyDeviceToHost, c->s_main), "D2H err")) { rc = AZ_ERR_HIP; break; }
+        if (!hip_ok(hipStreamSynchronize(c->s_main), "sync")) { rc = AZ_ERR_HIP; break; }
+    } while (0);
+    if (rc != AZ_OK) (void)hipStreamSynchronize(c->s_main);
+    if (d_pos) (void)hipFree(d_pos);
+    if (d_vel) (void)hipFree(d_vel);
+    if (d_err) (void)hipFree(d_err);
+    return rc;
+}
+
+int32_t azh_propagate_jd_host(azh_constellation *c, const double *jd, const double *fr, size_t n_times, double *pos,
+                              double *vel, int32_t mode, int32_t layout, uint8_t *err)
+{
+    if (!c || !jd || !fr || !pos) return AZ_ERR_NULL_POINTER;
+    // Constellation.propagate (src/Constellation.zig L266-269): tsinceBase = (jd+fr - refEpoch)*1440,
+    // offsets = (refEpoch - epoch)*1440 (L153); GMST at jd+fr
+    const double ref = c->h_epoch.empty() ? 0.0 : c->h_epoch[0];
+    std::vector<double> times(n_times), offs(c->n);
+    for (size_t t = 0; t < n_times; ++t) times[t] = ((jd[t] + fr[t]) - ref) * 1440.0;
+    for (size_t s = 0; s < c->n; ++s) offs[s] = (ref - c->h_epoch[s]) * 1440.0;
+    return azh_propagate_host(c, times.data(), n_times, offs.data(), pos, vel, mode, ref, nullptr, layout, 0, err);
+}
+
+int32_t azh_synchronize(azh_constellation *c)
+{
+    if (!c) return AZ_ERR_NULL_POINTER;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(c->s_deep));
+    HIP_TRY(hipStreamSynchronize(c->s_main));
+    return AZ_OK;
+}
+
+double azh_last_kernel_ms(azh_constellation *c)
+{
+    if (!c || !c->timed) return -1.0;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1.0;
+    }
+    return (double)ms;
+}
+
+int32_t azh_propagate_one_host(azh_constellation *c, size_t sat, const double *tsince, size_t n, double *pos,
+                               double *vel, uint8_t *err)
+{
+    if (!c || !tsince || !pos) return AZ_ERR_NULL_POINTER;
+    if (sat >= c->n) return AZ_ERR_VALUE;
+    if (n == 0) return AZ_OK;
+    if (n > 0xffffffffu) return AZ_ERR_VALUE;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    double *d_t = nullptr, *d_p = nullptr, *d_v = nullptr;
+    uint8_t *d_e = nullptr;
+    int32_t rc = AZ_OK;
+    hipStream_t st = c->s_main;
+    do {
+        if (!hip_ok(hipMalloc((void **)&d_t, sizeof(double) * n), "hipMalloc") ||
+            !hip_ok(hipMalloc((void **)&d_p, sizeof(double) * 3 * n), "hipMalloc") ||
+            !hip_ok(hipMalloc((void **)&d_v, sizeof(double) * 3 * n), "hipMalloc") ||
+            !hip_ok(hipMalloc((void **)&d_e, n), "hipMalloc")) { rc = AZ_ERR_HIP; break; }
+        if (!hip_ok(hipMemcpyAsync(d_t, tsince, sizeof(double) * n, hipMemcpyHostToDevice, st), "H2D")) { rc = AZ_ERR_HIP; break; }
+        hipLaunchKernelGGL(k_one_satellite, dim3((unsigned)((n + AZ_BLOCK - 1) / AZ_BLOCK)), dim3(AZ_BLOCK), 0, st, c->d_el,
+                           c->d_flags, c->n_pad, (unsigned)sat, d_t, (unsigned)n, d_p, d_v, d_e, 0, c->g);
+        if (!hip_ok(hipGetLastError(), "k_one_satellite")) { rc = AZ_ERR_HIP; break; }
+        if (!hip_ok(hipMemcpyAsync(pos, d_p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st), "D2H")) { rc = AZ_ERR_HIP; break; }
+        if (vel && !hip_ok(hipMemcpyAsync(vel, d_v, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st), "D2H")) { rc = AZ_ERR_HIP; break; }
+        if (err && !hip_ok(hipMemcpyAsync(err, d_e, n, hipMemcpyDeviceToHost, st), "D2H")) { rc = AZ_ERR_HIP; break; }
+        if (!hip_ok(hipStreamSynchronize(st), "sync")) { rc = AZ_ERR_HIP; break; }
+    } while (0);
+    if (rc != AZ_OK) (void)hipStreamSynchronize(st);
+    if (d_t) (void)hipFree(d_t);
+    if (d_p) (void)hipFree(d_p);
+    if (d_v) (void)hipFree(d_v);
+    if (d_e) (void)hipFree(d_e);
+    return rc;
+}
+
+// ======================================================================================= (A)
+// The reference's c_api surface (src/c_api/root.zig).
+
+uint32_t astroz_version(void) { return (0u << 16) | (3u << 8) | 0u; }
+void astroz_init(void) {}
+void astroz_deinit(void) {}
+
+struct TleHandle {
+    azh::TleRecord rec;
+};
+
+int32_t tle_parse(const char *str, void **out)
+{
+    if (!str || !out) return AZ_ERR_NULL_POINTER;
+    TleHandle *h = new (std::nothrow) TleHandle();
+    if (!h) return AZ_ERR_ALLOC_FAILED;
+    int rc = azh::parse_first(std::string_view(str, strlen(str)), h->rec);
+    if (rc != 0) {
+        delete h;
+        return rc == -1 ? AZ_ERR_BAD_TLE_LENGTH : AZ_ERR_UNKNOWN;
+    }
+    *out = h;
+    return AZ_OK;
+}
+void tle_free(void *h) { delete static_cast<TleHandle *>(h); }
+uint32_t tle_get_satellite_number(void *h) { return static_cast<TleHandle *>(h)->rec.satnum; }
+double tle_get_epoch(void *h) { return (static_cast<TleHandle *>(h)->rec.epoch_jd - 2451545.0) * 86400.0; }
+double tle_get_inclination(void *h) { return static_cast<TleHandle *>(h)->rec.incl_deg; }
+double tle_get_eccentricity(void *h) { return static_cast<TleHandle *>(h)->rec.ecc; }
+double tle_get_mean_motion(void *h) { return static_cast<TleHandle *>(h)->rec.mm_revday; }
+
+struct Sgp4Handle {
+    azh_constellation *c;
+};
+
+int32_t sgp4_init(void *tle, int32_t grav, void **out)
+{
+    if (!tle || !out) return AZ_ERR_NULL_POINTER;
+    std::vector<azh::TleRecord> recs(1, static_cast<TleHandle *>(tle)->rec);
+    azh_constellation *c = nullptr;
+    int32_t rc = build_from_records(recs, grav == 1 ? AZ_WGS72 : AZ_WGS84, 0, &c);
+    if (rc != AZ_OK) return rc;
+    const unsigned f = c->h_flags[0];
+    int32_t e = AZ_OK;
+    // same precedence as Sgp4.initElements (src/Sgp4.zig L111-123)
+    if (AZ_FLAG_ERR(f) == 1)
+        e = AZ_ERR_INVALID_ECCENTRICITY;
+    else if (AZ_FLAG_ERR(f) == 6)
+        e = AZ_ERR_SATELLITE_DECAYED;
+    else if (f & AZ_FLAG_DEEP)
+        e = AZ_ERR_DEEP_SPACE_NOT_SUPPORTED;
+    if (e != AZ_OK) {
+        destroy(c);
+        return e;
+    }
+    Sgp4Handle *h = new (std::nothrow) Sgp4Handle{c};
+    if (!h) {
+        destroy(c);
+        return AZ_ERR_ALLOC_FAILED;
+    }
+    *out = h;
+    return AZ_OK;
+}
+
+void sgp4_free(void *h)
+{
+    if (!h) return;
+    destroy(static_cast<Sgp4Handle *>(h)->c);
+    delete static_cast<Sgp4Handle *>(h);
+}
+
+int32_t sgp4_propagate(void *h, double tsince, double pos[3], double vel[3])
+{
+    if (!h || !pos || !vel) return AZ_ERR_NULL_POINTER;
+    return azh_propagate_one_host(static_cast<Sgp4Handle *>(h)->c, 0, &tsince, 1, pos, vel, nullptr);
+}
+
+int32_t sgp4_propagate_batch(void *h, const double *times, double *results, uint32_t count)
+{
+    if (!h || !times || !results) return AZ_ERR_NULL_POINTER;
+    if (count == 0) return AZ_OK;
+    azh_constellation *c = static_cast<Sgp4Handle *>(h)->c;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    double *d_t = nullptr, *d_o = nullptr;
+    int32_t rc = AZ_OK;
+    hipStream_t st = c->s_main;
+    do {
+        if (!hip_ok(hipMalloc((void **)&d_t, sizeof(double) * count), "hipMalloc") ||
+            !hip_ok(hipMalloc((void **)&d_o, sizeof(double) * 6 * count), "hipMalloc")) { rc = AZ_ERR_HIP; break; }
+        if (!hip_ok(hipMemcpyAsync(d_t, times, sizeof(double) * count, hipMemcpyHostToDevice, st), "H2D")) { rc = AZ_ERR_HIP; break; }
+        hipLaunchKernelGGL(k_one_satellite, dim3((count + AZ_BLOCK - 1) / AZ_BLOCK), dim3(AZ_BLOCK), 0, st, c->d_el, c->d_flags,
+                           c->n_pad, 0u, d_t, count, d_o, (double *)nullptr, (unsigned char *)nullptr, 1, c->g);
+        if (!hip_ok(hipGetLastError(), "k_one_satellite")) { rc = AZ_ERR_HIP; break; }
+        if (!hip_ok(hipMemcpyAsync(results, d_o, sizeof(double) * 6 * count, hipMemcpyDeviceToHost, st), "D2H")) { rc = AZ_ERR_HIP; break; }
+        if (!hip_ok(hipStreamSynchronize(st), "sync")) { rc = AZ_ERR_HIP; break; }
+    } while (0);
+    if (rc != AZ_OK) (void)hipStreamSynchronize(st);
+    if (d_t) (void)hipFree(d_t);
+    if (d_o) (void)hipFree(d_o);
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,155 @@
+// devmath.h -- fp64 elementwise math for the CDNA4 SGP4/SDP4 kernels.
+//
+// Replaces the reference's simdMath (src/simdMath.zig L29-212: sincosN / atan2N / modTwoPiN /
+// pow15N / pow23N) with a design that fits a lane that OWNS one satellite and walks time:
+//   * az_sincos      full-range sincos (2-term Cody-Waite + degree-13/12 minimax), ~1 ulp
+//   * az_rotate*     (sin,cos) of angle+d from (sin,cos) of angle for small d by a short Taylor
+//                    rotation -- the work-horse: slowly drifting angles (arg of perigee, node,
+//                    Kepler corrections, J2 short-period corrections) never need a fresh sincos
+//   * az_rcp/az_rsqrt hardware v_rcp_f64 / v_rsq_f64 seeds (~2^-23) + Newton refinement;
+//                    the reference's 11+K divides and 4 square roots become 3 rcp + 2 rsqrt
+//   * no atan2 and no mod-2pi at all on the near-earth path: u is only ever used through
+//                    sin/cos, and (sin u, cos u) are already known exactly
+//
+// The header is plain C++ so that the SAME source can also be compiled for the host by the
+// test-only emulation harness (tests/host_emul); the product only ever compiles it with hipcc.
+#pragma once
+#include <math.h>
+
+#ifndef AZ_DEVICE
+#define AZ_DEVICE __device__ __forceinline__
+#endif
+
+#ifdef AZ_HOST_EMUL
+// test-only stand-ins for the gfx950 intrinsics (seed precision mimics v_rcp_f64/v_rsq_f64)
+static inline double az_hw_rcp(double x) { return (double)(1.0f / (float)x); }
+static inline double az_hw_rsq(double x) { return (double)(1.0f / sqrtf((float)x)); }
+static inline bool az_any(bool p) { return p; }
+static inline double az_rint(double x) { return nearbyint(x); }
+#else
+AZ_DEVICE double az_hw_rcp(double x) { return __builtin_amdgcn_rcp(x); }
+AZ_DEVICE double az_hw_rsq(double x) { return __builtin_amdgcn_rsq(x); }
+// wave64 vote: true if the predicate holds on any active lane (s_cmp on the exec-masked ballot)
+AZ_DEVICE bool az_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+AZ_DEVICE double az_rint(double x) { return __builtin_rint(x); }
+#endif
+
+#define AZ_PI 3.14159265358979323846
+#define AZ_TWOPI 6.28318530717958647692
+
+// ---------------------------------------------------------------- reciprocal / rsqrt
+// 1/x to ~1 ulp: seed 2^-23 -> 2^-46 -> 2^-92 (rounded).  x > 0, normal.
+AZ_DEVICE double az_rcp(double x)
+{
+    double r = az_hw_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+// 1/x to ~2^-46: enough for a Newton *step* (the step is re-evaluated next trip)
+AZ_DEVICE double az_rcp1(double x)
+{
+    double r = az_hw_rcp(x);
+    double e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+// 1/sqrt(x) to ~1 ulp
+AZ_DEVICE double az_rsqrt(double x)
+{
+    double y = az_hw_rsq(x);
+    double h = 0.5 * y;
+    double e = fma(-x * y, h, 0.5); // 0.5 - 0.5*x*y^2
+    y = fma(y, e, y);
+    h = 0.5 * y;
+    e = fma(-x * y, h, 0.5);
+    return fma(y, e, y);
+}
+
+// ---------------------------------------------------------------- full-range sincos
+// |x| up to ~1e6 rad with < 2e-16 absolute error (2-term Cody-Waite: k*pio2_lo residual 1e-33*k).
+AZ_DEVICE void az_sincos(double x, double &s, double &c)
+{
+    const double kf = az_rint(x * 0.63661977236758134308);
+    double r = fma(-kf, 1.57079632679489655800e+00, x);
+    r = fma(-kf, 6.12323399573676603587e-17, r);
+    const int k = (int)kf;
+    const double z = r * r;
+    // minimax on [-pi/4, pi/4] (the classic fdlibm kernel coefficients)
+    double ps = fma(1.58969099521155010221e-10, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double sr = fma(ps, z * r, r);
+    double pc = fma(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double cr = fma(z, fma(pc, z, -0.5), 1.0);
+    const bool swap = (k & 1) != 0;
+    double ss = swap ? cr : sr;
+    double cc = swap ? sr : cr;
+    s = (k & 2) ? -ss : ss;
+    c = ((k + 1) & 2) ? -cc : cc;
+}
+
+// ---------------------------------------------------------------- small rotations
+// (s,c) <- (sin,cos)(angle + d).  Written as s += (s*q + c*p), q = cos d - 1, p = sin d, so the
+// rounding error is that of one addition to s (c), not of a product.
+#define AZ_ROT_SMALL 0.0078125 /* 2^-7: truncation  d^7/5040 < 4e-19, d^8/40320 < 4e-22 */
+#define AZ_ROT_TINY 1.0e-4     /* d^3 term kept: d^5/120 < 1e-22, d^4/24 < 5e-18        */
+
+AZ_DEVICE void az_rot_apply(double &s, double &c, double p, double q)
+{
+    const double ns = s + fma(s, q, c * p);
+    const double nc = c + fma(c, q, -(s * p));
+    s = ns;
+    c = nc;
+}
+// |d| <= 2^-7
+AZ_DEVICE void az_rotate_small(double &s, double &c, double d)
+{
+    const double d2 = d * d;
+    const double q = d2 * fma(d2, fma(d2, -1.0 / 720.0, 1.0 / 24.0), -0.5);
+    const double p = d * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+    az_rot_apply(s, c, p, q);
+}
+// |d| <= 1e-4
+AZ_DEVICE void az_rotate_tiny(double &s, double &c, double d)
+{
+    const double d2 = d * d;
+    const double q = d2 * fma(d2, 1.0 / 24.0, -0.5);
+    const double p = d * fma(d2, -1.0 / 6.0, 1.0);
+    az_rot_apply(s, c, p, q);
+}
+// any d: wave-uniform choice between the Taylor rotation and sincos(d) + angle addition
+AZ_DEVICE void az_rotate(double &s, double &c, double d)
+{
+    if (az_any(fabs(d) > AZ_ROT_SMALL)) {
+        double sd, cd;
+        az_sincos(d, sd, cd);
+        const double ns = fma(s, cd, c * sd);
+        const double nc = fma(c, cd, -(s * sd));
+        s = ns;
+        c = nc;
+    } else {
+        az_rotate_small(s, c, d);
+    }
+}
+// (s,c) of a+b from (sa,ca),(sb,cb)
+AZ_DEVICE void az_angle_add(double sa, double ca, double sb, double cb, double &s, double &c)
+{
+    s = fma(sa, cb, ca * sb);
+    c = fma(ca, cb, -(sa * sb));
+}
+
+// positive modulus (only the deep-space path and GMST need an explicit reduced angle)
+AZ_DEVICE double az_mod2pi(double x)
+{
+    double r = fma(-floor(x * (1.0 / AZ_TWOPI)), AZ_TWOPI, x);
+    if (r < 0.0) r += AZ_TWOPI;
+    if (r >= AZ_TWOPI) r -= AZ_TWOPI;
+    return r;
+}

@@ -1,0 +1,257 @@
+// kernels.h -- the gfx950 kernels.  Included only by astroz_hip.hip (compiled with hipcc).
+//
+// Work decomposition (the reverse of the reference's): the reference vectorises 8 satellites per
+// AVX-512 register and calls a kernel 1,685 x 1,440 times through a function pointer
+// (src/Constellation.zig L387-434, src/dispatch.zig L18-23).  Here one wave64 lane owns one
+// satellite for a whole tile of time steps: the ~32 per-satellite constants are loaded once per
+// tile with coalesced 512-B wave loads from the SoA table and stay in VGPRs; slowly drifting
+// angles are carried as (sin,cos) pairs between steps; a 2-D grid (satellite blocks x time tiles)
+// supplies the tens of thousands of waves needed to fill 256 CUs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "init_device.h"
+#include "propagate_device.h"
+
+#define AZ_BLOCK 64 /* one wave per workgroup: no cross-wave barriers anywhere */
+#define AZ_RESEED 256 /* re-seed carried (sin,cos) pairs with a full sincos every 256 steps */
+#define AZ_SM_CHUNK 4 /* time steps staged in LDS per flush in the satellite-major store path */
+
+struct PropArgs {
+    const double *el;
+    const unsigned *flags;
+    size_t n_pad;
+    const unsigned *list; // table indices of the satellites this launch handles
+    unsigned n_list;
+    const double *times; // minutes from the reference instant
+    unsigned n_times;
+    const double *offsets; // per-satellite minutes (table index), may be null
+    double *pos, *vel;
+    const double *sin_g, *cos_g; // GMST per time (ECEF / geodetic)
+    const unsigned char *mask;   // per satellite, may be null
+    unsigned char *err;          // n_sats x n_times, may be null (pre-zeroed)
+    size_t stride_sats;          // time-major row length
+    unsigned tile;               // time steps per workgroup
+    int mode;
+    AzGrav g;
+};
+
+__device__ __forceinline__ void az_epilogue(double r[3], double v[3], int mode, bool vel, const double *sin_g,
+                                            const double *cos_g, unsigned i)
+{
+    if (mode != 0) {
+        const double sg = sin_g[i], cg = cos_g[i];
+        az_to_ecef(r, sg, cg);
+        if (vel) az_to_ecef(v, sg, cg);
+        if (mode == 2) az_ecef_to_geodetic(r);
+    }
+}
+
+// Stores of one time step.
+//  time-major  (t, s, 3): lane = satellite -> a wave writes 64 x 24 B = 1,536 contiguous bytes
+//  sat-major   (s, t, 3): rows are n_times*24 B apart, so AZ_SM_CHUNK steps are staged in LDS and
+//                         flushed as 8-byte words that are contiguous along each satellite's row
+template <int LAYOUT, bool VEL>
+struct Stager {
+    // [pos|vel][lane][AZ_SM_CHUNK*3 + 1]: the +1 double of padding makes the per-lane row stride
+    // 13 doubles = 26 banks, so the 16-lane groups of ds_write_b64 hit distinct bank pairs
+    static constexpr int ROW = AZ_SM_CHUNK * 3 + 1;
+};
+
+template <int LAYOUT, bool VEL, bool DEEP>
+__global__ void __launch_bounds__(AZ_BLOCK) k_propagate(PropArgs p)
+{
+    __shared__ double lds[(LAYOUT == 0) ? (VEL ? 2 : 1) * AZ_BLOCK * Stager<LAYOUT, VEL>::ROW : 1];
+    constexpr int ROW = Stager<LAYOUT, VEL>::ROW;
+
+    const unsigned lane = threadIdx.x;
+    const unsigned li = blockIdx.x * AZ_BLOCK + lane;
+    const bool in_range = li < p.n_list;
+    // out-of-range lanes shadow the last satellite (the reference pads its last batch the same way,
+    // Constellation.zig L145-147) so the wave stays convergent; they never store
+    const unsigned s = p.list[in_range ? li : p.n_list - 1];
+    const unsigned fl = p.flags[s];
+    const bool wr = in_range && (p.mask == nullptr || p.mask[s] != 0);
+    const double off = p.offsets ? p.offsets[s] : 0.0;
+    const unsigned t0 = blockIdx.y * p.tile;
+    const unsigned t1 = min(t0 + p.tile, p.n_times);
+
+    Sgp4Lane e4;
+    Sgp4Carry c4;
+    Sdp4Lane e8;
+    Sdp4Res q8;
+    Sdp4Carry c8;
+    if (DEEP) {
+        az_load_sdp4(p.el, p.n_pad, s, fl, e8, q8);
+        c8.atime = 0.0;
+        c8.xli = e8.xlamo;
+        c8.xni = e8.no_unkozai;
+    } else {
+        az_load_sgp4(p.el, p.n_pad, s, fl, e4);
+        c4.t_prev = 0.0;
+        c4.sW = c4.sO = 0.0;
+        c4.cW = c4.cO = 1.0;
+    }
+
+    // block of satellite rows this wave flushes in the sat-major path
+    const unsigned li0 = blockIdx.x * AZ_BLOCK;
+
+#pragma unroll 1
+    for (unsigned i = t0; i < t1; ++i) {
+        const double t = p.times[i] + off;
+        double r[3], v[3];
+        int rc = 0;
+        if (DEEP) {
+            rc = az_sdp4_step<VEL>(e8, q8, p.g, t, c8, r, v);
+        } else {
+            const bool first = ((i - t0) % AZ_RESEED) == 0;
+            az_sgp4_step<VEL>(e4, p.g, t, first, c4, r, v);
+        }
+        az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, i);
+        if (DEEP) {
+            if (rc != 0) {
+                r[0] = r[1] = r[2] = 0.0;
+                v[0] = v[1] = v[2] = 0.0;
+                if (p.err && wr) p.err[(size_t)s * p.n_times + i] = (unsigned char)rc;
+            }
+        }
+
+        if (LAYOUT == 1) {
+            if (wr) {
+                const size_t ob = ((size_t)i * p.stride_sats + s) * 3;
+                p.pos[ob] = r[0];
+                p.pos[ob + 1] = r[1];
+                p.pos[ob + 2] = r[2];
+                if (VEL) {
+                    p.vel[ob] = v[0];
+                    p.vel[ob + 1] = v[1];
+                    p.vel[ob + 2] = v[2];
+                }
+            }
+        } else {
+            const unsigned k = (i - t0) % AZ_SM_CHUNK;
+            double *row = lds + lane * ROW + k * 3;
+            row[0] = r[0];
+            row[1] = r[1];
+            row[2] = r[2];
+            if (VEL) {
+                double *vrow = row + AZ_BLOCK * ROW;
+                vrow[0] = v[0];
+                vrow[1] = v[1];
+                vrow[2] = v[2];
+            }
+            const bool flush = (k == AZ_SM_CHUNK - 1) || (i + 1 == t1);
+            if (flush) {
+                __syncthreads(); // single wave: orders the LDS writes before the transposed reads
+                const unsigned nsteps = k + 1;
+                const unsigned tb = i - k; // first time index of this chunk
+                const unsigned words = nsteps * 3;
+                const unsigned total = AZ_BLOCK * words;
+                for (unsigned w = lane; w < total; w += AZ_BLOCK) {
+                    const unsigned rl = w / words, cw = w - rl * words;
+                    const unsigned lj = li0 + rl;
+                    if (lj < p.n_list) {
+                        const unsigned sj = p.list[lj];
+                        if (p.mask == nullptr || p.mask[sj] != 0) {
+                            const size_t ob = ((size_t)sj * p.n_times + tb) * 3 + cw;
+                            p.pos[ob] = lds[rl * ROW + cw];
+                            if (VEL) p.vel[ob] = lds[AZ_BLOCK * ROW + rl * ROW + cw];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// one satellite x many times: lane = time, the satellite's constants are wave-uniform.  Every
+// evaluation is a 'first' step (full sincos seeds); deep-space lanes integrate the resonance from
+// epoch themselves, like the reference's sdp4Times8 (src/Sdp4.zig L1105-1128).
+__global__ void __launch_bounds__(AZ_BLOCK) k_one_satellite(const double *el, const unsigned *flags,
+                                                            size_t n_pad, unsigned sat, const double *tsince,
+                                                            unsigned n, double *pos, double *vel,
+                                                            unsigned char *err, int interleaved, AzGrav g)
+{
+    const unsigned i = blockIdx.x * AZ_BLOCK + threadIdx.x;
+    const double t = tsince[i < n ? i : n - 1];
+    const unsigned fl = flags[sat];
+    double r[3], v[3];
+    int rc = AZ_FLAG_ERR(fl);
+    if (rc == 0) {
+        if (fl & AZ_FLAG_DEEP) {
+            Sdp4Lane e;
+            Sdp4Res q;
+            Sdp4Carry c;
+            az_load_sdp4(el, n_pad, sat, fl, e, q);
+            c.atime = 0.0;
+            c.xli = e.xlamo;
+            c.xni = e.no_unkozai;
+            rc = az_sdp4_step<true>(e, q, g, t, c, r, v);
+        } else {
+            Sgp4Lane e;
+            Sgp4Carry c;
+            az_load_sgp4(el, n_pad, sat, fl, e);
+            c.t_prev = 0.0;
+            az_sgp4_step<true>(e, g, t, true, c, r, v);
+        }
+    }
+    if (rc != 0) {
+        r[0] = r[1] = r[2] = 0.0;
+        v[0] = v[1] = v[2] = 0.0;
+    }
+    if (i < n) {
+        if (interleaved) {
+            double *o = pos + (size_t)i * 6;
+            o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = v[0]; o[4] = v[1]; o[5] = v[2];
+        } else {
+            pos[(size_t)i * 3] = r[0]; pos[(size_t)i * 3 + 1] = r[1]; pos[(size_t)i * 3 + 2] = r[2];
+            if (vel) { vel[(size_t)i * 3] = v[0]; vel[(size_t)i * 3 + 1] = v[1]; vel[(size_t)i * 3 + 2] = v[2]; }
+        }
+        if (err) err[i] = (unsigned char)rc;
+    }
+}
+
+// rows of satellites whose init failed: zero state + the init error code at every time
+__global__ void k_fill_bad(const unsigned *list, unsigned n_list, const unsigned *flags, unsigned n_times,
+                           double *pos, double *vel, unsigned char *err, const unsigned char *mask, int layout,
+                           size_t stride_sats)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x; // time
+    const unsigned li = blockIdx.y;
+    if (i >= n_times || li >= n_list) return;
+    const unsigned s = list[li];
+    if (mask && !mask[s]) return;
+    const size_t ob = (layout == 0) ? ((size_t)s * n_times + i) * 3 : ((size_t)i * stride_sats + s) * 3;
+    pos[ob] = pos[ob + 1] = pos[ob + 2] = 0.0;
+    if (vel) vel[ob] = vel[ob + 1] = vel[ob + 2] = 0.0;
+    if (err) err[(size_t)s * n_times + i] = (unsigned char)AZ_FLAG_ERR(flags[s]);
+}
+
+// GMST table (WorldCoordinateSystem.julianToGmst, src/WorldCoordinateSystem.zig L146-154;
+// Constellation.zig L573-581)
+__global__ void k_gmst(const double *times, unsigned n, double reference_jd, double *sin_g, double *cos_g)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double d = (reference_jd + times[i] / 1440.0) - 2451545.0;
+    const double tc = d / 36525.0;
+    double gm = 280.46061837 + 360.98564736629 * d + 0.000387933 * tc * tc - tc * tc * tc / 38710000.0;
+    gm = fmod(gm, 360.0);
+    if (gm < 0) gm += 360.0;
+    gm *= AZ_PI / 180.0;
+    sin_g[i] = sin(gm);
+    cos_g[i] = cos(gm);
+}
+
+// element initialisation: raw[k*n_pad + s] -> el rows + flags
+__global__ void __launch_bounds__(AZ_BLOCK) k_init(const double *raw, size_t n, size_t n_pad, AzGrav g, double *el,
+                                                   unsigned *flags)
+{
+    const size_t s = (size_t)blockIdx.x * AZ_BLOCK + threadIdx.x;
+    if (s >= n) return;
+    double in[AZ_NUM_RAW];
+#pragma unroll
+    for (int k = 0; k < AZ_NUM_RAW; ++k) in[k] = raw[(size_t)k * n_pad + s];
+    flags[s] = az_init_satellite(in, g, el, n_pad, s);
+}

@@ -1,0 +1,490 @@
+// propagate_device.h -- per-lane SGP4 / SDP4 step.  One lane owns one satellite and walks time.
+//
+// What it computes is what the reference computes per (satellite, time):
+//   near-earth : Sgp4Batch.propagateBatchDirect (src/Sgp4Batch.zig L113-157) +
+//                Sgp4.keplerAndPosVel (src/Sgp4.zig L646-750)
+//   deep-space : Sdp4Batch.propagateBatchDirect (src/Sdp4Batch.zig L199-343) with the *scalar*
+//                error semantics of Sdp4.propagateElementsCarry (src/Sdp4.zig L881-970)
+// How it computes it is different (see devmath.h): angles that drift slowly in time are carried as
+// (sin,cos) pairs in registers and advanced by small rotations; the Kepler iteration rotates
+// (sin E, cos E) by each Newton correction instead of re-evaluating sincos; u = atan2(sinu,cosu)
+// is never formed because only sin/cos of u + small corrections are needed.
+#pragma once
+#include "devmath.h"
+#include "fields.h"
+
+// ------------------------------------------------------------------------------------------
+// near-earth constants of one satellite, register resident for the whole time tile
+struct Sgp4Lane {
+    double mo, mdot, argpo, argpdot, nodeo, nodedot, xnodcf;
+    double cc1, bc4, t2cof, ecco, a_base, no_unkozai;
+    double aycof, xlcof, con41, x1mth2, x7thm1, sinio, cosio;
+    // higher-order drag (zeroed at load for isimp satellites, which disables every term)
+    double omgcof, eta, xmcof, delmo, bc5, sinmao, d2, d3, d4, t3cof, t4cof, t5cof;
+};
+
+// (sin,cos) pairs carried from one time step to the next
+struct Sgp4Carry {
+    double t_prev;
+    double sW, cW; // argpo + argpdot*t
+    double sO, cO; // nodeo + nodedot*t + xnodcf*t^2
+};
+
+AZ_DEVICE void az_load_sgp4(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags,
+                            Sgp4Lane &e)
+{
+#define L(f) el[(size_t)F_##f * n_pad + i]
+    e.mo = L(mo); e.mdot = L(mdot); e.argpo = L(argpo); e.argpdot = L(argpdot);
+    e.nodeo = L(nodeo); e.nodedot = L(nodedot); e.xnodcf = L(xnodcf);
+    e.cc1 = L(cc1); e.bc4 = L(bc4); e.t2cof = L(t2cof); e.ecco = L(ecco);
+    e.a_base = L(a_base); e.no_unkozai = L(no_unkozai);
+    e.aycof = L(aycof); e.xlcof = L(xlcof); e.con41 = L(con41); e.x1mth2 = L(x1mth2);
+    e.x7thm1 = L(x7thm1); e.sinio = L(sinio); e.cosio = L(cosio);
+    const bool ho = !(flags & AZ_FLAG_ISIMP);
+    e.omgcof = ho ? L(omgcof) : 0.0; e.eta = L(eta); e.xmcof = ho ? L(xmcof) : 0.0;
+    e.delmo = L(delmo); e.bc5 = ho ? L(bc5) : 0.0; e.sinmao = L(sinmao);
+    e.d2 = L(d2); e.d3 = L(d3); e.d4 = L(d4);
+    e.t3cof = L(t3cof); e.t4cof = L(t4cof); e.t5cof = L(t5cof);
+#undef L
+}
+
+// ------------------------------------------------------------------------------------------
+// Kepler solve + short-period corrections + orientation  (Sgp4.zig L675-749)
+//   am, em          secular semi-major axis / eccentricity
+//   (su0,cu0)       sin/cos of u0 = mm + argpm + temp*xlcof*axnl   (the Newton start)
+//   axnl, aynl      equinoctial components
+//   (sO,cO)         sin/cos of nodem;  (sI,cI) sin/cos of the (mean) inclination
+//   ra = 1/sqrt(am)
+// returns mrt (corrected radius, Earth radii)
+template <bool VEL>
+AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double axnl, double aynl,
+                                  double su0, double cu0, double sO, double cO, double sI, double cI,
+                                  double con41, double x1mth2, double x7thm1, double r[3], double v[3])
+{
+    // Newton on  E - aynl*cosE + axnl*sinE = u  with eps = E - u carried instead of E.
+    double s = su0, c = cu0, eps = 0.0;
+#pragma unroll 1
+    for (int it = 0; it < 10; ++it) {
+        const double den = fma(-s, aynl, fma(-c, axnl, 1.0));
+        const double num = fma(axnl, s, fma(-aynl, c, -eps));
+        double d = num * az_rcp1(den);
+        d = fmin(fmax(d, -0.95), 0.95);
+        eps += d;
+        const double ad = fabs(d);
+        if (az_any(ad > AZ_ROT_SMALL)) {
+            double sd, cd;
+            az_sincos(d, sd, cd);
+            const double ns = fma(s, cd, c * sd);
+            c = fma(c, cd, -(s * sd));
+            s = ns;
+        } else if (az_any(ad > AZ_ROT_TINY)) {
+            az_rotate_small(s, c, d);
+        } else {
+            az_rotate_tiny(s, c, d);
+        }
+        // quadratic convergence: once |d| < 3e-7 the remaining error is < e/2 * 1e-13
+        if (!az_any(ad >= 3.0e-7)) break;
+    }
+
+    const double inv_am = ra * ra;
+    const double ecose = fma(axnl, c, aynl * s);
+    const double esine = fma(axnl, s, -(aynl * c));
+    const double omel2 = 1.0 - fma(axnl, axnl, aynl * aynl);
+    const double rb = az_rsqrt(omel2);
+    const double betal = omel2 * rb;
+    const double ome = 1.0 - ecose;
+    const double inv_ome = az_rcp(ome); // = am / rl
+    const double rl = am * ome;
+    const double est = esine * az_rcp(1.0 + betal);
+    const double sinu = inv_ome * (s - aynl - axnl * est);
+    const double cosu = inv_ome * (c - axnl + aynl * est);
+    const double sin2u = 2.0 * sinu * cosu;
+    const double cos2u = fma(-2.0 * sinu, sinu, 1.0);
+
+    const double inv_pl = inv_am * rb * rb;
+    const double temp1 = 0.5 * g.j2 * inv_pl;
+    const double temp2 = temp1 * inv_pl;
+
+    const double mrt = fma(rl, fma(-1.5 * temp2 * betal, con41, 1.0), 0.5 * temp1 * x1mth2 * cos2u);
+    const double dsu = -0.25 * temp2 * x7thm1 * sin2u;
+    const double t2c = 1.5 * temp2 * cI;
+    const double dnode = t2c * sin2u;
+    const double dinc = t2c * sI * cos2u;
+
+    double ssu = sinu, csu = cosu, sn = sO, cn = cO, si = sI, ci = cI;
+    az_rotate(ssu, csu, dsu);
+    az_rotate(sn, cn, dnode);
+    az_rotate(si, ci, dinc);
+
+    const double xmx = -sn * ci, xmy = cn * ci;
+    const double ux = fma(xmx, ssu, cn * csu);
+    const double uy = fma(xmy, ssu, sn * csu);
+    const double uz = si * ssu;
+    const double rs = mrt * g.radius_km;
+    r[0] = rs * ux;
+    r[1] = rs * uy;
+    r[2] = rs * uz;
+    if (VEL) {
+        const double sqrt_am = am * ra;
+        const double inv_rl = inv_am * inv_ome;
+        const double rdotl = sqrt_am * esine * inv_rl;
+        const double rvdotl = sqrt_am * betal * inv_rl;
+        const double nx = inv_am * ra; // nm / xke = am^-1.5
+        const double mvt = fma(-nx * temp1 * x1mth2, sin2u, rdotl);
+        const double rvdot = fma(nx * temp1, fma(x1mth2, cos2u, 1.5 * con41), rvdotl);
+        const double vx = fma(xmx, csu, -(cn * ssu));
+        const double vy = fma(xmy, csu, -(sn * ssu));
+        const double vz = si * csu;
+        v[0] = fma(mvt, ux, rvdot * vx) * g.vkmpersec;
+        v[1] = fma(mvt, uy, rvdot * vy) * g.vkmpersec;
+        v[2] = fma(mvt, uz, rvdot * vz) * g.vkmpersec;
+    }
+    return mrt;
+}
+
+// ------------------------------------------------------------------------------------------
+// one near-earth propagation.  `first` (wave-uniform) seeds the carried pairs with full sincos.
+template <bool VEL>
+AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const AzGrav &g, double t, bool first, Sgp4Carry &st,
+                            double r[3], double v[3])
+{
+    const double t2 = t * t;
+    // slowly drifting angles: advance the carried (sin,cos) pairs
+    {
+        const double dt = t - st.t_prev;
+        const double dW = e.argpdot * dt;
+        const double dO = dt * fma(e.xnodcf, t + st.t_prev, e.nodedot);
+        if (first || az_any(fabs(dW) > AZ_ROT_SMALL || fabs(dO) > AZ_ROT_SMALL)) {
+            az_sincos(fma(e.argpdot, t, e.argpo), st.sW, st.cW);
+            az_sincos(fma(e.xnodcf, t2, fma(e.nodedot, t, e.nodeo)), st.sO, st.cO);
+        } else {
+            az_rotate_small(st.sW, st.cW, dW);
+            az_rotate_small(st.sO, st.cO, dO);
+        }
+        st.t_prev = t;
+    }
+
+    // secular gravity + drag (Sgp4Batch.zig L121-154); isimp lanes carry zeros in the ho terms
+    double sA, cA;
+    az_sincos(fma(e.mdot, t, e.mo), sA, cA); // xmdf
+    const double dm = fma(e.eta, cA, 1.0);
+    const double th = fma(e.omgcof, t, e.xmcof * (dm * dm * dm - e.delmo)); // delomg + delm
+    const double t3 = t2 * t, t4 = t3 * t;
+    const double tempa = 1.0 - e.cc1 * t - e.d2 * t2 - e.d3 * t3 - e.d4 * t4;
+    // sin(mm) with mm = xmdf + th
+    double smm = sA, cmm = cA;
+    az_rotate(smm, cmm, th);
+    const double tempe = fma(e.bc5, smm - e.sinmao, e.bc4 * t);
+    const double templ = fma(e.t2cof, t2, fma(e.t3cof, t3, t4 * fma(t, e.t5cof, e.t4cof)));
+
+    const double am = e.a_base * tempa * tempa;
+    const double em = fmax(e.ecco - tempe, 1.0e-6);
+    const double ra = az_rsqrt(am);
+    const double temp = ra * ra * az_rcp(fma(-em, em, 1.0));
+
+    // argpm = argpdf - th
+    double sw = st.sW, cw = st.cW;
+    az_rotate(sw, cw, -th);
+    const double axnl = em * cw;
+    const double aynl = fma(em, sw, temp * e.aycof);
+    // u0 = mm + argpm + temp*xlcof*axnl = xmdf + argpdf + no*templ + temp*xlcof*axnl
+    double su0, cu0;
+    az_angle_add(sA, cA, st.sW, st.cW, su0, cu0);
+    az_rotate(su0, cu0, fma(e.no_unkozai, templ, temp * e.xlcof * axnl));
+
+    az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, st.sO, st.cO, e.sinio, e.cosio, e.con41,
+                          e.x1mth2, e.x7thm1, r, v);
+}
+
+// ------------------------------------------------------------------------------------------
+// deep space
+struct Sdp4Lane {
+    double mo, mdot, argpo, argpdot, nodeo, nodedot, xnodcf;
+    double cc1, bc4, t2cof, ecco, inclo, no_unkozai;
+    double se2, se3, si2, si3, sl2, sl3, sl4, sgh2, sgh3, sgh4, sh2, sh3;
+    double ee2, e3, xi2, xi3, xl2, xl3, xl4, xgh2, xgh3, xgh4, xh2, xh3;
+    double zmol, zmos, dedt, didt, dmdt, domdt, dnodt;
+    double xlamo, xfact, gsto;
+    int irez;
+};
+// resonance coefficients live in their own struct so non-resonant waves never load them
+struct Sdp4Res {
+    double d2201, d2211, d3210, d3222, d4410, d4422, d5220, d5232, d5421, d5433;
+    double del1, del2, del3;
+};
+struct Sdp4Carry {
+    double atime, xli, xni;
+};
+
+AZ_DEVICE void az_load_sdp4(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags,
+                            Sdp4Lane &e, Sdp4Res &q)
+{
+#define L(f) el[(size_t)F_##f * n_pad + i]
+    e.mo = L(mo); e.mdot = L(mdot); e.argpo = L(argpo); e.argpdot = L(argpdot);
+    e.nodeo = L(nodeo); e.nodedot = L(nodedot); e.xnodcf = L(xnodcf);
+    e.cc1 = L(cc1); e.bc4 = L(bc4); e.t2cof = L(t2cof); e.ecco = L(ecco); e.inclo = L(inclo);
+    e.no_unkozai = L(no_unkozai);
+    e.se2 = L(se2); e.se3 = L(se3); e.si2 = L(si2); e.si3 = L(si3); e.sl2 = L(sl2); e.sl3 = L(sl3);
+    e.sl4 = L(sl4); e.sgh2 = L(sgh2); e.sgh3 = L(sgh3); e.sgh4 = L(sgh4); e.sh2 = L(sh2); e.sh3 = L(sh3);
+    e.ee2 = L(ee2); e.e3 = L(e3); e.xi2 = L(xi2); e.xi3 = L(xi3); e.xl2 = L(xl2); e.xl3 = L(xl3);
+    e.xl4 = L(xl4); e.xgh2 = L(xgh2); e.xgh3 = L(xgh3); e.xgh4 = L(xgh4); e.xh2 = L(xh2); e.xh3 = L(xh3);
+    e.zmol = L(zmol); e.zmos = L(zmos); e.dedt = L(dedt); e.didt = L(didt); e.dmdt = L(dmdt);
+    e.domdt = L(domdt); e.dnodt = L(dnodt);
+    e.xlamo = L(xlamo); e.xfact = L(xfact); e.gsto = L(gsto);
+    e.irez = (int)AZ_FLAG_IREZ(flags);
+    q.d2201 = L(d2201); q.d2211 = L(d2211); q.d3210 = L(d3210); q.d3222 = L(d3222);
+    q.d4410 = L(d4410); q.d4422 = L(d4422); q.d5220 = L(d5220); q.d5232 = L(d5232);
+    q.d5421 = L(d5421); q.d5433 = L(d5433);
+    q.del1 = L(del1); q.del2 = L(del2); q.del3 = L(del3);
+#undef L
+}
+
+// model constants, src/Sdp4.zig L15-52
+#define AZ_ZES 0.01675
+#define AZ_ZEL 0.05490
+#define AZ_ZNS 1.19459e-5
+#define AZ_ZNL 1.5835218e-4
+#define AZ_RPTIM 4.37526908801129966e-3
+#define AZ_FASX2 0.13130908
+#define AZ_FASX4 2.8843198
+#define AZ_FASX6 0.37448087
+#define AZ_G22 5.7686396
+#define AZ_G32 0.95240898
+#define AZ_G44 1.8014998
+#define AZ_G52 1.0508330
+#define AZ_G54 4.4108898
+#define AZ_STEPP 720.0
+#define AZ_STEP2 259200.0
+
+// resonance accelerations (Sdp4.computeResonanceAccel, src/Sdp4.zig L824-866).  Unlike the
+// reference batch kernel (Sdp4Batch.zig L347-425: both branches for every lane) the half-day
+// branch is only entered by waves that hold a half-day satellite; the host orders the deep-space
+// index list by resonance class so that waves are uniform.
+AZ_DEVICE void az_resonance_accel(const Sdp4Lane &e, const Sdp4Res &q, double xli, double xni,
+                                  double atime, double &xndt, double &xnddt, double &xldot)
+{
+    xldot = xni + e.xfact;
+    double xndt_h = 0.0, xnddt_h = 0.0;
+    if (az_any(e.irez == 2)) {
+        const double xomi = fma(e.argpdot, atime, e.argpo);
+        const double x2omi = xomi + xomi, x2li = xli + xli;
+        double s1, c1, s2, c2, s3, c3, s4, c4, s5, c5, s6, c6, s7, c7, s8, c8, s9, c9, s10, c10;
+        az_sincos(x2omi + xli - AZ_G22, s1, c1);
+        az_sincos(xli - AZ_G22, s2, c2);
+        az_sincos(xomi + xli - AZ_G32, s3, c3);
+        az_sincos(-xomi + xli - AZ_G32, s4, c4);
+        az_sincos(x2omi + x2li - AZ_G44, s5, c5);
+        az_sincos(x2li - AZ_G44, s6, c6);
+        az_sincos(xomi + xli - AZ_G52, s7, c7);
+        az_sincos(-xomi + xli - AZ_G52, s8, c8);
+        az_sincos(xomi + x2li - AZ_G54, s9, c9);
+        az_sincos(-xomi + x2li - AZ_G54, s10, c10);
+        xndt_h = q.d2201 * s1 + q.d2211 * s2 + q.d3210 * s3 + q.d3222 * s4 + q.d4410 * s5 +
+                 q.d4422 * s6 + q.d5220 * s7 + q.d5232 * s8 + q.d5421 * s9 + q.d5433 * s10;
+        xnddt_h = (q.d2201 * c1 + q.d2211 * c2 + q.d3210 * c3 + q.d3222 * c4 + q.d5220 * c7 +
+                   q.d5232 * c8 + 2.0 * (q.d4410 * c5 + q.d4422 * c6 + q.d5421 * c9 + q.d5433 * c10)) *
+                  xldot;
+    }
+    double xndt_g = 0.0, xnddt_g = 0.0;
+    if (az_any(e.irez == 1)) {
+        // synchronous: phases xli - fasx2, 2(xli - fasx4), 3(xli - fasx6)
+        double s1, c1, s2, c2, s3, c3;
+        az_sincos(xli - AZ_FASX2, s1, c1);
+        az_sincos(2.0 * (xli - AZ_FASX4), s2, c2);
+        az_sincos(3.0 * (xli - AZ_FASX6), s3, c3);
+        xndt_g = q.del1 * s1 + q.del2 * s2 + q.del3 * s3;
+        xnddt_g = (q.del1 * c1 + 2.0 * q.del2 * c2 + 3.0 * q.del3 * c3) * xldot;
+    }
+    xndt = (e.irez == 2) ? xndt_h : xndt_g;
+    xnddt = (e.irez == 2) ? xnddt_h : xnddt_g;
+}
+
+// one deep-space propagation; returns 0 / 1 (eccentricity) / 6 (decayed) per the scalar
+// reference path (src/Sdp4.zig L914-921, L937-938, L967).
+template <bool VEL>
+AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const Sdp4Res &q, const AzGrav &g, double t, Sdp4Carry &cy,
+                           double r[3], double v[3])
+{
+    const double t2 = t * t;
+    const double tempa = 1.0 - e.cc1 * t;
+    const double tempe = e.bc4 * t;
+    const double templ = e.t2cof * t2;
+
+    double em = fma(e.dedt, t, e.ecco);
+    double inclm = fma(e.didt, t, e.inclo);
+    double argpm = fma(e.argpdot, t, e.argpo) + e.domdt * t;
+    double nodem = fma(e.xnodcf, t2, fma(e.nodedot, t, e.nodeo)) + e.dnodt * t;
+    double mm = fma(e.mdot, t, e.mo) + e.dmdt * t;
+    double nm = e.no_unkozai;
+    int rc = 0;
+
+    // resonance integrator (dspace, src/Sdp4.zig L784-819): the state reached after k steps of
+    // +-720 min is a pure function of k, so carrying it and restarting from epoch are equivalent.
+    if (az_any(e.irez != 0)) {
+        const bool res = e.irez != 0;
+        if (res && (cy.atime == 0.0 || t * cy.atime <= 0.0 || fabs(t) < fabs(cy.atime))) {
+            cy.atime = 0.0;
+            cy.xni = e.no_unkozai;
+            cy.xli = e.xlamo;
+        }
+        const double delt = (t > 0.0) ? AZ_STEPP : -AZ_STEPP;
+        double xndt, xnddt, xldot;
+        while (az_any(res && fabs(t - cy.atime) >= AZ_STEPP)) {
+            az_resonance_accel(e, q, cy.xli, cy.xni, cy.atime, xndt, xnddt, xldot);
+            if (res && fabs(t - cy.atime) >= AZ_STEPP) {
+                cy.xli += xldot * delt + xndt * AZ_STEP2;
+                cy.xni += xndt * delt + xnddt * AZ_STEP2;
+                cy.atime += delt;
+            }
+        }
+        az_resonance_accel(e, q, cy.xli, cy.xni, cy.atime, xndt, xnddt, xldot);
+        if (res) {
+            const double ft = t - cy.atime;
+            nm = cy.xni + xndt * ft + xnddt * ft * ft * 0.5;
+            const double xl = cy.xli + xldot * ft + xndt * ft * ft * 0.5;
+            const double theta = az_mod2pi(fma(t, AZ_RPTIM, e.gsto));
+            mm = (e.irez != 2) ? xl - nodem - argpm + theta : xl - 2.0 * nodem + 2.0 * theta;
+            nm = e.no_unkozai + (nm - e.no_unkozai);
+        }
+    }
+
+    if (nm <= 0.0) { rc = 6; nm = e.no_unkozai; }
+    // am = (xke/nm)^(2/3) * tempa^2
+    const double am = cbrt((g.xke / nm) * (g.xke / nm)) * tempa * tempa;
+    em -= tempe;
+    if (rc == 0 && (em >= 1.0 || em < -0.001)) rc = 1;
+    if (em < 1.0e-6) em = 1.0e-6;
+    if (rc == 0 && am < 0.95) rc = 6;
+
+    mm += e.no_unkozai * templ;
+    const double xlm = mm + argpm + nodem;
+    nodem = az_mod2pi(nodem);
+    argpm = az_mod2pi(argpm);
+    mm = az_mod2pi(xlm - argpm - nodem);
+
+    // lunar-solar periodics (dpper, src/Sdp4.zig L681-759)
+    double sI, cI; // sin/cos of the perturbed inclination
+    {
+        double zm = fma(AZ_ZNS, t, e.zmos);
+        double szm, czm, sinzf, coszf;
+        az_sincos(zm, szm, czm);
+        az_sincos(fma(2.0 * AZ_ZES, szm, zm), sinzf, coszf);
+        double f2 = fma(0.5 * sinzf, sinzf, -0.25), f3 = -0.5 * sinzf * coszf;
+        const double ses = e.se2 * f2 + e.se3 * f3;
+        const double sis = e.si2 * f2 + e.si3 * f3;
+        const double sls = e.sl2 * f2 + e.sl3 * f3 + e.sl4 * sinzf;
+        const double sghs = e.sgh2 * f2 + e.sgh3 * f3 + e.sgh4 * sinzf;
+        const double shs = e.sh2 * f2 + e.sh3 * f3;
+        zm = fma(AZ_ZNL, t, e.zmol);
+        az_sincos(zm, szm, czm);
+        az_sincos(fma(2.0 * AZ_ZEL, szm, zm), sinzf, coszf);
+        f2 = fma(0.5 * sinzf, sinzf, -0.25);
+        f3 = -0.5 * sinzf * coszf;
+        const double sel = e.ee2 * f2 + e.e3 * f3;
+        const double sil = e.xi2 * f2 + e.xi3 * f3;
+        const double sll = e.xl2 * f2 + e.xl3 * f3 + e.xl4 * sinzf;
+        const double sghl = e.xgh2 * f2 + e.xgh3 * f3 + e.xgh4 * sinzf;
+        const double shl = e.xh2 * f2 + e.xh3 * f3;
+        const double pe = ses + sel, pinc = sis + sil, pl = sls + sll;
+        double pgh = sghs + sghl, ph = shs + shl;
+
+        inclm += pinc;
+        em += pe;
+        az_sincos(inclm, sI, cI);
+        const double sinip = sI, cosip = cI;
+        const bool lyd = inclm < 0.2;
+        if (az_any(lyd)) {
+            // Lyddane modification for near-equatorial orbits (rare: own branch)
+            if (lyd) {
+                double sinop, cosop;
+                az_sincos(nodem, sinop, cosop);
+                double alfdp = sinip * sinop, betdp = sinip * cosop;
+                alfdp += ph * cosop + pinc * cosip * sinop;
+                betdp += -ph * sinop + pinc * cosip * cosop;
+                nodem = az_mod2pi(nodem);
+                const double xls = mm + argpm + cosip * nodem;
+                const double dls = pl + pgh - pinc * nodem * sinip;
+                const double xnoh = nodem;
+                nodem = atan2(alfdp, betdp);
+                if (fabs(xnoh - nodem) > AZ_PI) nodem += (nodem < xnoh) ? AZ_TWOPI : -AZ_TWOPI;
+                mm += pl;
+                argpm = xls + dls - mm - cosip * nodem;
+            }
+        }
+        if (!lyd) {
+            ph *= az_rcp(sinip);
+            pgh -= cosip * ph;
+            argpm += pgh;
+            nodem += ph;
+            mm += pl;
+        }
+    }
+
+    if (inclm < 0.0) {
+        inclm = -inclm;
+        sI = -sI;
+        nodem += AZ_PI;
+        argpm -= AZ_PI;
+    }
+    if (em < 1.0e-6) em = 1.0e-6;
+    if (rc == 0 && em >= 1.0) rc = 1;
+    if (rc != 0) em = 0.5; // keep the arithmetic below finite; the row is zero-filled by the caller
+
+    const double cI2 = cI * cI;
+    const double aycof = -0.5 * g.j3oj2 * sI;
+    const double den = (fabs(cI + 1.0) > 1.5e-12) ? 1.0 + cI : 1.5e-12;
+    const double xlcof = -0.25 * g.j3oj2 * sI * fma(5.0, cI, 3.0) * az_rcp(den);
+    const double x1mth2 = 1.0 - cI2, con41 = fma(3.0, cI2, -1.0), x7thm1 = fma(7.0, cI2, -1.0);
+
+    const double ra = az_rsqrt(am);
+    const double temp = ra * ra * az_rcp(fma(-em, em, 1.0));
+    double sw, cw, sO, cO, su0, cu0;
+    az_sincos(argpm, sw, cw);
+    az_sincos(nodem, sO, cO);
+    const double axnl = em * cw;
+    const double aynl = fma(em, sw, temp * aycof);
+    az_sincos(mm + argpm + temp * xlcof * axnl, su0, cu0);
+
+    const double mrt = az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, sO, cO, sI, cI, con41, x1mth2,
+                                             x7thm1, r, v);
+    if (rc == 0 && mrt < 1.0) rc = 6;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// output frames (Constellation.zig L54-56, L489-506; WorldCoordinateSystem.zig L98-121)
+AZ_DEVICE void az_to_ecef(double p[3], double sg, double cg)
+{
+    const double x = fma(p[0], cg, p[1] * sg);
+    const double y = fma(p[1], cg, -(p[0] * sg));
+    p[0] = x;
+    p[1] = y;
+}
+
+// ECEF -> (lat rad, lon rad, alt km), WGS84; same fixed-point iteration as the reference (<= 10 trips)
+AZ_DEVICE void az_ecef_to_geodetic(double p[3])
+{
+    const double f = 1.0 / 298.257223563;
+    const double e2 = 2.0 * f - f * f;
+    const double a = 6378.137;
+    const double x = p[0], y = p[1], z = p[2];
+    const double lon = atan2(y, x);
+    const double rho = sqrt(x * x + y * y);
+    double lat = atan2(z, rho * (1.0 - e2));
+    bool done = false;
+#pragma unroll 1
+    for (int i = 0; i < 10; ++i) {
+        const double prev = lat;
+        const double sl = sin(lat);
+        const double N = a / sqrt(1.0 - e2 * sl * sl);
+        const double nl = atan2(z + e2 * N * sl, rho);
+        if (!done) lat = nl;
+        done = done || fabs(lat - prev) < 1e-12;
+        if (!az_any(!done)) break;
+    }
+    const double sl = sin(lat), cl = cos(lat);
+    const double N = a / sqrt(1.0 - e2 * sl * sl);
+    p[0] = lat;
+    p[1] = lon;
+    p[2] = rho / cl - N;
+}

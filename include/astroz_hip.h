@@ -1,0 +1,187 @@
+/*
+ * astroz_hip.h -- C ABI of libastroz_hip.so, the MI355X-native drop-in for astroz's batched
+ * SGP4/SDP4 constellation-propagation path.
+ *
+ * Plain C: pointers, sizes and scalars only.  Every entry point names the reference interface
+ * it replaces (ATTron/astroz v0.12.0, file:line).  All floating-point work happens in HIP
+ * kernels on the GPU; there is NO CPU fallback -- without a usable device every compute entry
+ * point returns AZ_ERR_HIP.
+ *
+ * Two layers:
+ *  (A) the reference's own `c_api` surface (src/c_api/root.zig L13-81), same names, argument
+ *      meaning and error codes, so an existing dlopen/FFI client of libastroz_c.so relinks
+ *      unchanged;
+ *  (B) the coarse-grained constellation boundary (one call = all satellites x all times) that
+ *      mirrors Constellation.zig's propagateConstellation / propagateSdp4Constellation /
+ *      Constellation.propagate and what bindings/python/src/{satrec,sgp4}.zig hand to them.
+ *      The reference's fine-grained plugin ABI (src/simdKernels.zig L9-29: 8 satellites x 1
+ *      time per call through a function pointer) is a CPU-SIMD artefact that cannot drive a GPU
+ *      usefully; the boundary therefore sits one level up, at its only caller
+ *      (src/Constellation.zig L413-476).
+ */
+#ifndef ASTROZ_HIP_H
+#define ASTROZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes: src/c_api/error.zig L3-19 (+ AZ_ERR_HIP for device/runtime failures) ---- */
+enum {
+    AZ_OK = 0,
+    AZ_ERR_BAD_TLE_LENGTH = -1,
+    AZ_ERR_BAD_CHECKSUM = -2,
+    AZ_ERR_DEEP_SPACE_NOT_SUPPORTED = -10,
+    AZ_ERR_INVALID_ECCENTRICITY = -11,
+    AZ_ERR_SATELLITE_DECAYED = -12,
+    AZ_ERR_VALUE = -20,
+    AZ_ERR_ALLOC_FAILED = -100,
+    AZ_ERR_NULL_POINTER = -101,
+    AZ_ERR_NOT_INITIALIZED = -102,
+    AZ_ERR_HIP = -200,
+    AZ_ERR_UNKNOWN = -999
+};
+
+/* gravity model ids: bindings/python/src/shared.zig L21-27, src/c_api/sgp4.zig L17-20 */
+enum { AZ_WGS84 = 0, AZ_WGS72 = 1 };
+/* src/Constellation.zig L30-34 */
+enum { AZ_OUT_TEME = 0, AZ_OUT_ECEF = 1, AZ_OUT_GEODETIC = 2 };
+/* src/Constellation.zig L37-42 */
+enum { AZ_LAYOUT_SAT_MAJOR = 0, AZ_LAYOUT_TIME_MAJOR = 1 };
+
+/* =====================================================================================
+ * (A) reference c_api surface -- src/c_api/root.zig
+ * ===================================================================================== */
+
+/* root.zig L13-15: (major<<16)|(minor<<8)|patch of the C API (0.3.0) */
+uint32_t astroz_version(void);
+/* root.zig L17-23: allocator hooks, no-ops in the reference; here astroz_init() may be used to
+ * fail early when no GPU is present (it never aborts; compute calls report AZ_ERR_HIP). */
+void astroz_init(void);
+void astroz_deinit(void);
+
+/* root.zig L25-45 / src/c_api/tle.zig L12-54.  `str` holds the two 69-column lines. */
+int32_t tle_parse(const char *str, void **out_handle);
+void tle_free(void *handle);
+uint32_t tle_get_satellite_number(void *handle);
+double tle_get_epoch(void *handle); /* seconds since J2000 */
+double tle_get_inclination(void *handle);   /* degrees  */
+double tle_get_eccentricity(void *handle);
+double tle_get_mean_motion(void *handle);   /* rev/day  */
+
+/* root.zig L47-58 / src/c_api/sgp4.zig L18-89.  grav: 0 WGS84, 1 WGS72.  Deep-space element
+ * sets are rejected with AZ_ERR_DEEP_SPACE_NOT_SUPPORTED exactly as the reference does. */
+int32_t sgp4_init(void *tle_handle, int32_t grav, void **out_handle);
+void sgp4_free(void *handle);
+int32_t sgp4_propagate(void *handle, double tsince_min, double pos[3], double vel[3]);
+/* results: count x [x,y,z,vx,vy,vz].  One kernel launch, lane = time. */
+int32_t sgp4_propagate_batch(void *handle, const double *times_min, double *results, uint32_t count);
+
+/* =====================================================================================
+ * (B) constellation boundary
+ * ===================================================================================== */
+
+typedef struct azh_constellation azh_constellation;
+
+/* Every numeric field of one TLE (src/Tle.zig L49-101), for hosts that want the Satrec getters
+ * of bindings/python/src/satrec.zig L390-430 without a second parser.  out16 receives:
+ * [0] satnum [1] epoch year (2 digits) [2] epoch day [3] epoch JD [4] ndot (TLE units)
+ * [5] bstar [6] incl deg [7] raan deg [8] ecc [9] argp deg [10] mean anomaly deg
+ * [11] mean motion rev/day [12] element set no [13] rev no [14] classification char [15] 0 */
+int32_t azh_parse_tle_lines(const char *line1, const char *line2, double *out16);
+
+/* number of visible HIP devices (0 when there is no GPU / no driver) */
+int azh_device_count(void);
+/* last HIP error string of the calling thread's most recent failing call ("" if none) */
+const char *azh_last_error(void);
+
+/*
+ * Build a device-resident constellation.  Replaces Constellation.init (src/Constellation.zig
+ * L101-200), shared.buildBatches (bindings/python/src/shared.zig L62-97) and
+ * Sgp4Constellation.from_tle_text (bindings/python/src/sgp4.zig L293-350): parses the text on
+ * the host, uploads the raw elements, and runs the init kernel (SGP4 + deep-space init and the
+ * near-earth / deep-space classification, src/Sgp4.zig L108-180, src/Sdp4.zig L174-274).
+ * Satellites keep their catalog order; output rows are indexed by that order.
+ * `device` is the HIP device ordinal (one process per GPU: pass LOCAL_RANK).
+ */
+int32_t azh_constellation_from_tle_text(const char *text, size_t len, int32_t grav, int32_t device,
+                                        azh_constellation **out);
+/* n pairs of NUL-terminated lines */
+int32_t azh_constellation_from_tle_lines(const char *const *line1, const char *const *line2, size_t n,
+                                         int32_t grav, int32_t device, azh_constellation **out);
+/* element arrays in TLE units (deg, rev/day), each of length n: for hosts that already hold
+ * parsed elements (a Zig host's []Tle, OMM records, synthetic catalogs of 10^6 members) */
+int32_t azh_constellation_from_elements(size_t n, const double *epoch_jd, const double *mean_motion_revday,
+                                        const double *ecc, const double *incl_deg, const double *raan_deg,
+                                        const double *argp_deg, const double *mean_anom_deg,
+                                        const double *bstar, int32_t grav, int32_t device,
+                                        azh_constellation **out);
+void azh_constellation_free(azh_constellation *c);
+
+size_t azh_num_satellites(const azh_constellation *c);
+size_t azh_num_sgp4(const azh_constellation *c);  /* Constellation.numSgp4, L82 */
+size_t azh_num_sdp4(const azh_constellation *c);  /* Constellation.numSdp4, L89 */
+/* per-satellite epoch JD (the `epochs` getter, bindings/python/src/sgp4.zig L283-291) */
+int32_t azh_get_epochs(const azh_constellation *c, double *out_n);
+/* per-satellite init status: python-sgp4 error code (0, 1 eccentricity, 6 decayed;
+ * bindings/python/src/shared.zig L40-47), deep-space flag, resonance class irez (0,1,2) */
+int32_t azh_get_status(const azh_constellation *c, uint8_t *err_n, uint8_t *is_deep_n, uint8_t *irez_n);
+/* one row of the element table by name ("a", "no_unkozai", "mdot", "gsto", ... see fields.h):
+ * backs the Satrec getters (bindings/python/src/satrec.zig L390-496) and the init parity tests */
+int32_t azh_get_field(const azh_constellation *c, const char *name, double *out_n);
+
+/*
+ * Propagate every satellite to every time.  Replaces propagateConstellation
+ * (src/Constellation.zig L541-605) AND propagateSdp4Constellation (L611-679): near-earth rows run
+ * in the SGP4 kernel, deep-space rows in the SDP4 kernel (own stream, concurrently), both write
+ * straight into the caller's layout at the satellite's catalog index.
+ *   tsince(s,t) = times_min[t] + epoch_offsets_min[s]        (Constellation.zig L423-426)
+ *   epoch_offsets_min == NULL  -> zeros (each satellite relative to its own epoch)
+ *   vel == NULL                -> positions only
+ *   output_mode                -> AZ_OUT_*; ECEF/geodetic use GMST(reference_jd + t/1440)
+ *   sat_mask (n_sats bytes)    -> rows with mask==0 are left untouched
+ *   layout / out_stride_sats   -> index (s*n_times+t)*3 or (t*stride+s)*3 (L46-51); stride 0 = n_sats
+ *   err (n_sats x n_times, optional) -> per-(satellite,time) python-sgp4 codes; failing rows are
+ *                                 zero-filled for that satellite only (scalar-path semantics)
+ * The *_host form takes host pointers (copies in/out, synchronous, like the reference's call);
+ * the *_device form takes device pointers for pos/vel/err and a hipStream_t (NULL = the
+ * constellation's own stream), is asynchronous, and is what keeps results resident in HBM.
+ */
+int32_t azh_propagate_host(azh_constellation *c, const double *times_min, size_t n_times,
+                           const double *epoch_offsets_min, double *pos, double *vel, int32_t output_mode,
+                           double reference_jd, const uint8_t *sat_mask, int32_t layout,
+                           size_t out_stride_sats, uint8_t *err);
+int32_t azh_propagate_device(azh_constellation *c, const double *times_min /*host*/, size_t n_times,
+                             const double *epoch_offsets_min /*host*/, double *d_pos, double *d_vel,
+                             int32_t output_mode, double reference_jd, const uint8_t *sat_mask /*host*/,
+                             int32_t layout, size_t out_stride_sats, uint8_t *d_err, void *stream);
+/* same launch with times/offsets already uploaded by a previous call (no host work at all):
+ * the steady-state form used when the same grid is propagated repeatedly */
+int32_t azh_propagate_device_cached(azh_constellation *c, double *d_pos, double *d_vel, int32_t layout,
+                                    size_t out_stride_sats, uint8_t *d_err, void *stream);
+/* Constellation.propagate (src/Constellation.zig L245-308): absolute times jd[t]+fr[t]; the
+ * reference epoch is the first satellite's epoch (L139-140). Host pointers. */
+int32_t azh_propagate_jd_host(azh_constellation *c, const double *jd, const double *fr, size_t n_times,
+                              double *pos, double *vel, int32_t output_mode, int32_t layout, uint8_t *err);
+int32_t azh_synchronize(azh_constellation *c);
+
+/* one satellite x many times (lane = time): Satrec.sgp4 / sgp4_array
+ * (bindings/python/src/satrec.zig L169-201, L256-343) and dispatch.sgp4Times8 / sdp4Times8
+ * (src/dispatch.zig L32-44).  tsince in minutes from that satellite's epoch.
+ * pos/vel: n x 3 each (host); err: n bytes (optional). */
+int32_t azh_propagate_one_host(azh_constellation *c, size_t sat_index, const double *tsince_min, size_t n,
+                               double *pos, double *vel, uint8_t *err);
+
+/* tuning knobs (kernel time-tile length; 0 = automatic).  Not part of the reference surface. */
+int32_t azh_set_time_tile(azh_constellation *c, uint32_t sgp4_tile, uint32_t sdp4_tile);
+/* elapsed GPU milliseconds of the most recent propagate call's kernels (hipEvent on the
+ * launch stream; valid after azh_synchronize) */
+double azh_last_kernel_ms(azh_constellation *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

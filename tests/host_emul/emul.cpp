@@ -1,0 +1,61 @@
+// TEST-ONLY host emulation harness.
+// Compiles the *device* math headers (astroz_amd/csrc/*.h) for the host with stand-ins for the
+// gfx950 intrinsics (AZ_HOST_EMUL), so that the algebra of the kernels (rotation-carried angles,
+// eps-form Kepler iteration, rcp/rsqrt refinement, no-atan2 short-period step, init formulas)
+// can be checked against the oracle in the CPU-only test tier.  It is a single-lane emulation:
+// wave votes degenerate to the lane's own predicate.  Never built into or loaded by the product.
+#define AZ_HOST_EMUL 1
+#define AZ_DEVICE static inline
+#include <cstddef>
+#include <cstring>
+#include "../../astroz_amd/csrc/init_device.h"
+#include "../../astroz_amd/csrc/propagate_device.h"
+
+extern "C" {
+
+int emul_num_fields() { return AZ_NUM_FIELDS; }
+
+// raw[8] -> fields[AZ_NUM_FIELDS]; returns flags
+unsigned emul_init(const double* raw, const double* grav6, double* fields)
+{
+    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5]};
+    return az_init_satellite(raw, g, fields, 1, 0);
+}
+
+// propagate one satellite (fields as produced by emul_init) over ts[n]; incremental=1 carries the
+// (sin,cos) pairs from step to step exactly as the lane=satellite kernel does.
+void emul_propagate(const double* fields, unsigned flags, const double* grav6, const double* ts, int n,
+                    int incremental, double* out6, int* rc_out)
+{
+    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5]};
+    if (flags & AZ_FLAG_DEEP) {
+        Sdp4Lane e; Sdp4Res q; Sdp4Carry cy;
+        az_load_sdp4(fields, 1, 0, flags, e, q);
+        cy.atime = 0.0; cy.xli = e.xlamo; cy.xni = e.no_unkozai;
+        for (int i = 0; i < n; ++i) {
+            if (!incremental) { cy.atime = 0.0; cy.xli = e.xlamo; cy.xni = e.no_unkozai; }
+            double r[3], v[3];
+            int rc = az_sdp4_step<true>(e, q, g, ts[i], cy, r, v);
+            if (rc) { r[0]=r[1]=r[2]=v[0]=v[1]=v[2]=0.0; }
+            memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
+            rc_out[i] = rc;
+        }
+    } else {
+        Sgp4Lane e; Sgp4Carry st;
+        az_load_sgp4(fields, 1, 0, flags, e);
+        st.t_prev = 0; st.sW = st.cW = st.sO = st.cO = 0;
+        for (int i = 0; i < n; ++i) {
+            double r[3], v[3];
+            az_sgp4_step<true>(e, g, ts[i], (i == 0) || !incremental, st, r, v);
+            memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
+            rc_out[i] = 0;
+        }
+    }
+}
+
+void emul_sincos(double x, double* s, double* c) { az_sincos(x, *s, *c); }
+double emul_rcp(double x) { return az_rcp(x); }
+double emul_rsqrt(double x) { return az_rsqrt(x); }
+void emul_rotate(double* s, double* c, double d) { az_rotate(*s, *c, d); }
+void emul_geodetic(double* p) { az_ecef_to_geodetic(p); }
+}
