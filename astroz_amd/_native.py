@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libastroz_hip.so")
+# ASTROZ_AMD_LIB selects an alternative build of the SAME library (kernel tuning sweeps)
+LIB_PATH = os.environ.get("ASTROZ_AMD_LIB") or os.path.join(_HERE, "libastroz_hip.so")
 
 WGS84, WGS72 = 0, 1
 OUT_TEME, OUT_ECEF, OUT_GEODETIC = 0, 1, 2

@@ -49,6 +49,7 @@ AzGrav make_grav(int which)
         g.j3oj2 = -0.00233899967218727;
     }
     g.vkmpersec = g.xke * g.radius_km / 60.0; // src/Sgp4.zig L177
+    g.half_j2 = 0.5 * g.j2;
     return g;
 }
 
@@ -92,7 +93,7 @@ struct azh_constellation {
     std::vector<unsigned> h_flags;
     std::vector<double> h_epoch;
     // launch lists (table indices)
-    DevBuf<unsigned> d_list; // [sgp4 | sdp4 (ordered by irez) | bad]
+    DevBuf<unsigned> d_list; // [near-earth | deep (by irez) | bad]
     unsigned n_sgp4 = 0, n_sdp4 = 0, n_bad = 0;
     // per-call scratch
     DevBuf<double> d_times, d_offsets, d_sin, d_cos;
@@ -177,7 +178,7 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
             rc = AZ_ERR_HIP;
             break;
         }
-        hipLaunchKernelGGL(k_init, dim3((unsigned)(np / AZ_BLOCK)), dim3(AZ_BLOCK), 0, c->s_main, d_raw, n, np, c->g, c->d_el, c->d_flags);
+        hipLaunchKernelGGL(k_init, dim3((unsigned)(np / 64)), dim3(64), 0, c->s_main, d_raw, n, np, c->g, c->d_el, c->d_flags);
         if (!hip_ok(hipGetLastError(), "k_init launch")) { rc = AZ_ERR_HIP; break; }
         c->h_flags.resize(n);
         if (!hip_ok(hipMemcpyAsync(c->h_flags.data(), c->d_flags, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->s_main), "D2H flags") ||
@@ -186,13 +187,26 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
             break;
         }
         c->h_epoch = cols[R_epoch_jd];
-        // launch lists: near-earth in catalog order; deep-space grouped by resonance class so that
-        // waves are uniform in the integrator branch; failed inits last
+        // launch lists.
+        //  [near-earth]  catalog order, except that inside every group of AZ_BLOCK consecutive
+        //      members (= one workgroup = 4 waves) the members are ordered by eccentricity class.
+        //      A single e = 0.2 satellite needs ~4 Kepler-Newton trips and the wide rotation tier and
+        //      would drag the 63 other lanes of its wave along (4% such members touch 93% of the
+        //      waves of an unsorted catalog); after the in-group ordering they share the group's last
+        //      wave.  The group still writes the same contiguous span of rows.
+        //  [deep-space by resonance class]  uniform integrator branch per wave.
+        //  [failed inits]
         std::vector<unsigned> list;
         list.reserve(n);
         for (size_t s = 0; s < n; ++s)
             if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && !(c->h_flags[s] & AZ_FLAG_DEEP)) list.push_back((unsigned)s);
         c->n_sgp4 = (unsigned)list.size();
+        for (size_t g0 = 0; g0 < list.size(); g0 += AZ_BLOCK) {
+            const size_t g1 = std::min(g0 + (size_t)AZ_BLOCK, list.size());
+            std::stable_sort(list.begin() + g0, list.begin() + g1, [&](unsigned x, unsigned y) {
+                return AZ_FLAG_ECLASS(c->h_flags[x]) < AZ_FLAG_ECLASS(c->h_flags[y]);
+            });
+        }
         for (unsigned cls = 0; cls < 3; ++cls)
             for (size_t s = 0; s < n; ++s)
                 if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && (c->h_flags[s] & AZ_FLAG_DEEP) && AZ_FLAG_IREZ(c->h_flags[s]) == cls)
@@ -239,7 +253,7 @@ unsigned auto_tile(unsigned n_list, unsigned n_times, unsigned forced, unsigned 
     if (forced) return std::min(std::max(forced, 1u), std::max(n_times, 1u));
     // aim for ~16k waves (4 per SIMD x 4 rounds over 1,024 SIMDs) without making tiles so short
     // that the per-tile element loads and full-sincos seeding dominate
-    const unsigned waves_x = (n_list + AZ_BLOCK - 1) / AZ_BLOCK;
+    const unsigned waves_x = (n_list + 63) / 64;
     unsigned n_tiles = (16384 + waves_x - 1) / std::max(waves_x, 1u);
     n_tiles = std::max(1u, std::min(n_tiles, n_times));
     unsigned tile = (n_times + n_tiles - 1) / n_tiles;
@@ -247,21 +261,33 @@ unsigned auto_tile(unsigned n_list, unsigned n_times, unsigned forced, unsigned 
     return std::max(tile, 1u);
 }
 
-template <bool DEEP>
-void launch_propagate(const PropArgs &a, int layout, bool vel, hipStream_t st)
+template <bool DEEP, bool FRAME>
+void launch_propagate2(const PropArgs &a, int layout, bool vel, hipStream_t st)
 {
     dim3 grid((a.n_list + AZ_BLOCK - 1) / AZ_BLOCK, (a.n_times + a.tile - 1) / a.tile);
     dim3 block(AZ_BLOCK);
     if (layout == AZ_LAYOUT_TIME_MAJOR) {
         if (vel)
-            hipLaunchKernelGGL((k_propagate<1, true, DEEP>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((k_propagate<1, true, DEEP, FRAME>), grid, block, 0, st, a);
         else
-            hipLaunchKernelGGL((k_propagate<1, false, DEEP>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((k_propagate<1, false, DEEP, FRAME>), grid, block, 0, st, a);
     } else {
         if (vel)
-            hipLaunchKernelGGL((k_propagate<0, true, DEEP>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((k_propagate<0, true, DEEP, FRAME>), grid, block, 0, st, a);
         else
-            hipLaunchKernelGGL((k_propagate<0, false, DEEP>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((k_propagate<0, false, DEEP, FRAME>), grid, block, 0, st, a);
+    }
+}
+
+void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStream_t st)
+{
+    const bool frame = a.mode != AZ_OUT_TEME;
+    if (deep) {
+        if (frame) launch_propagate2<true, true>(a, layout, vel, st);
+        else launch_propagate2<true, false>(a, layout, vel, st);
+    } else {
+        if (frame) launch_propagate2<false, true>(a, layout, vel, st);
+        else launch_propagate2<false, false>(a, layout, vel, st);
     }
 }
 
@@ -330,7 +356,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         d.list = c->d_list.p + c->n_sgp4;
         d.n_list = c->n_sdp4;
         d.tile = auto_tile(c->n_sdp4, n_times, c->tile_sdp4, 8);
-        launch_propagate<true>(d, layout, d_vel != nullptr, c->s_deep);
+        launch_propagate(d, layout, d_vel != nullptr, true, c->s_deep);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_join, c->s_deep));
     }
@@ -338,7 +364,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         a.list = c->d_list.p;
         a.n_list = c->n_sgp4;
         a.tile = auto_tile(c->n_sgp4, n_times, c->tile_sgp4, 8);
-        launch_propagate<false>(a, layout, d_vel != nullptr, st);
+        launch_propagate(a, layout, d_vel != nullptr, false, st);
         HIP_TRY(hipGetLastError());
     }
     if (c->n_bad > 0) {
@@ -576,7 +602,7 @@ int32_t azh_propagate_one_host(azh_constellation *c, size_t sat, const double *t
             !hip_ok(hipMalloc((void **)&d_v, sizeof(double) * 3 * n), "hipMalloc") ||
             !hip_ok(hipMalloc((void **)&d_e, n), "hipMalloc")) { rc = AZ_ERR_HIP; break; }
         if (!hip_ok(hipMemcpyAsync(d_t, tsince, sizeof(double) * n, hipMemcpyHostToDevice, st), "H2D")) { rc = AZ_ERR_HIP; break; }
-        hipLaunchKernelGGL(k_one_satellite, dim3((unsigned)((n + AZ_BLOCK - 1) / AZ_BLOCK)), dim3(AZ_BLOCK), 0, st, c->d_el,
+        hipLaunchKernelGGL(k_one_satellite, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->d_el,
                            c->d_flags, c->n_pad, (unsigned)sat, d_t, (unsigned)n, d_p, d_v, d_e, 0, c->g);
         if (!hip_ok(hipGetLastError(), "k_one_satellite")) { rc = AZ_ERR_HIP; break; }
         if (!hip_ok(hipMemcpyAsync(pos, d_p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st), "D2H")) { rc = AZ_ERR_HIP; break; }
@@ -682,7 +708,7 @@ int32_t sgp4_propagate_batch(void *h, const double *times, double *results, uint
         if (!hip_ok(hipMalloc((void **)&d_t, sizeof(double) * count), "hipMalloc") ||
             !hip_ok(hipMalloc((void **)&d_o, sizeof(double) * 6 * count), "hipMalloc")) { rc = AZ_ERR_HIP; break; }
         if (!hip_ok(hipMemcpyAsync(d_t, times, sizeof(double) * count, hipMemcpyHostToDevice, st), "H2D")) { rc = AZ_ERR_HIP; break; }
-        hipLaunchKernelGGL(k_one_satellite, dim3((count + AZ_BLOCK - 1) / AZ_BLOCK), dim3(AZ_BLOCK), 0, st, c->d_el, c->d_flags,
+        hipLaunchKernelGGL(k_one_satellite, dim3((count + 63) / 64), dim3(64), 0, st, c->d_el, c->d_flags,
                            c->n_pad, 0u, d_t, count, d_o, (double *)nullptr, (unsigned char *)nullptr, 1, c->g);
         if (!hip_ok(hipGetLastError(), "k_one_satellite")) { rc = AZ_ERR_HIP; break; }
         if (!hip_ok(hipMemcpyAsync(results, d_o, sizeof(double) * 6 * count, hipMemcpyDeviceToHost, st), "D2H")) { rc = AZ_ERR_HIP; break; }

@@ -38,32 +38,26 @@ AZ_DEVICE double az_rint(double x) { return __builtin_rint(x); }
 #define AZ_TWOPI 6.28318530717958647692
 
 // ---------------------------------------------------------------- reciprocal / rsqrt
-// 1/x to ~1 ulp: seed 2^-23 -> 2^-46 -> 2^-92 (rounded).  x > 0, normal.
+// 1/x to ~1 ulp with ONE cubically convergent step: seed error e0 ~ 2^-23 -> e0^3 ~ 2^-69.
+//   r' = r (1 + e + e^2),  e = 1 - x r            (3 FMA-class ops after the seed)
 AZ_DEVICE double az_rcp(double x)
 {
-    double r = az_hw_rcp(x);
-    double e = fma(-x, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-x, r, 1.0);
-    return fma(r, e, r);
+    const double r = az_hw_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, fma(e, e, e), r);
 }
 // 1/x to ~2^-46: enough for a Newton *step* (the step is re-evaluated next trip)
 AZ_DEVICE double az_rcp1(double x)
 {
-    double r = az_hw_rcp(x);
-    double e = fma(-x, r, 1.0);
-    return fma(r, e, r);
+    const double r = az_hw_rcp(x);
+    return fma(r, fma(-x, r, 1.0), r);
 }
-// 1/sqrt(x) to ~1 ulp
+// 1/sqrt(x) to ~1 ulp, one cubic step:  y' = y (1 + e/2 + 3 e^2/8),  e = 1 - x y^2
 AZ_DEVICE double az_rsqrt(double x)
 {
-    double y = az_hw_rsq(x);
-    double h = 0.5 * y;
-    double e = fma(-x * y, h, 0.5); // 0.5 - 0.5*x*y^2
-    y = fma(y, e, y);
-    h = 0.5 * y;
-    e = fma(-x * y, h, 0.5);
-    return fma(y, e, y);
+    const double y = az_hw_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);
+    return fma(y, e * fma(e, 0.375, 0.5), y);
 }
 
 // ---------------------------------------------------------------- full-range sincos
@@ -98,8 +92,10 @@ AZ_DEVICE void az_sincos(double x, double &s, double &c)
 // ---------------------------------------------------------------- small rotations
 // (s,c) <- (sin,cos)(angle + d).  Written as s += (s*q + c*p), q = cos d - 1, p = sin d, so the
 // rounding error is that of one addition to s (c), not of a product.
-#define AZ_ROT_SMALL 0.0078125 /* 2^-7: truncation  d^7/5040 < 4e-19, d^8/40320 < 4e-22 */
-#define AZ_ROT_TINY 1.0e-4     /* d^3 term kept: d^5/120 < 1e-22, d^4/24 < 5e-18        */
+#define AZ_ROT_MED 0.125       /* sin to d^9, cos to d^10: truncation d^11/11! < 3e-18, d^12/12! < 2e-20 */
+#define AZ_ROT_SMALL 0.0078125 /* 2^-7 : sin to d^5, cos to d^6: d^7/5040 < 4e-19, d^8/40320 < 4e-22       */
+#define AZ_ROT_MILLI 0.0009765625 /* 2^-10: sin to d^3, cos to d^4: d^5/120 < 8e-18, d^6/720 < 2e-21        */
+#define AZ_ROT_TINY 1.0e-4     /* same polynomial as MILLI; kept as the Newton tail threshold              */
 
 AZ_DEVICE void az_rot_apply(double &s, double &c, double p, double q)
 {
@@ -107,6 +103,20 @@ AZ_DEVICE void az_rot_apply(double &s, double &c, double p, double q)
     const double nc = c + fma(c, q, -(s * p));
     s = ns;
     c = nc;
+}
+// |d| <= 1/8
+AZ_DEVICE void az_rotate_med(double &s, double &c, double d)
+{
+    const double d2 = d * d;
+    double q = fma(d2, -1.0 / 3628800.0, 1.0 / 40320.0);
+    q = fma(d2, q, -1.0 / 720.0);
+    q = fma(d2, q, 1.0 / 24.0);
+    q = d2 * fma(d2, q, -0.5);
+    double p = fma(d2, 1.0 / 362880.0, -1.0 / 5040.0);
+    p = fma(d2, p, 1.0 / 120.0);
+    p = fma(d2, p, -1.0 / 6.0);
+    p = d * fma(d2, p, 1.0);
+    az_rot_apply(s, c, p, q);
 }
 // |d| <= 2^-7
 AZ_DEVICE void az_rotate_small(double &s, double &c, double d)
@@ -116,7 +126,7 @@ AZ_DEVICE void az_rotate_small(double &s, double &c, double d)
     const double p = d * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
     az_rot_apply(s, c, p, q);
 }
-// |d| <= 1e-4
+// |d| <= 2^-10
 AZ_DEVICE void az_rotate_tiny(double &s, double &c, double d)
 {
     const double d2 = d * d;
@@ -124,19 +134,70 @@ AZ_DEVICE void az_rotate_tiny(double &s, double &c, double d)
     const double p = d * fma(d2, -1.0 / 6.0, 1.0);
     az_rot_apply(s, c, p, q);
 }
-// any d: wave-uniform choice between the Taylor rotation and sincos(d) + angle addition
+// sincos(d) + angle addition, any d
+AZ_DEVICE void az_rotate_full(double &s, double &c, double d)
+{
+    double sd, cd;
+    az_sincos(d, sd, cd);
+    const double ns = fma(s, cd, c * sd);
+    const double nc = fma(c, cd, -(s * sd));
+    s = ns;
+    c = nc;
+}
+// |d| <= 1/2: sin to d^15, cos to d^16 (truncation 0.5^17/17! = 2e-20); no integer work, no
+// range reduction -- cheaper than sincos(d) + angle addition for the first Newton step of an
+// eccentric orbit
+AZ_DEVICE void az_rotate_large(double &s, double &c, double d)
+{
+    const double d2 = d * d;
+    double q = fma(d2, 1.0 / 20922789888000.0, -1.0 / 87178291200.0);
+    q = fma(d2, q, 1.0 / 479001600.0);
+    q = fma(d2, q, -1.0 / 3628800.0);
+    q = fma(d2, q, 1.0 / 40320.0);
+    q = fma(d2, q, -1.0 / 720.0);
+    q = fma(d2, q, 1.0 / 24.0);
+    q = d2 * fma(d2, q, -0.5);
+    double p = fma(d2, -1.0 / 1307674368000.0, 1.0 / 6227020800.0);
+    p = fma(d2, p, -1.0 / 39916800.0);
+    p = fma(d2, p, 1.0 / 362880.0);
+    p = fma(d2, p, -1.0 / 5040.0);
+    p = fma(d2, p, 1.0 / 120.0);
+    p = fma(d2, p, -1.0 / 6.0);
+    p = d * fma(d2, p, 1.0);
+    az_rot_apply(s, c, p, q);
+}
+// any d: wave-uniform choice of the cheapest valid tier (up to four votes: use the az_rotate_le_*
+// forms below where the usual magnitude is known)
 AZ_DEVICE void az_rotate(double &s, double &c, double d)
 {
-    if (az_any(fabs(d) > AZ_ROT_SMALL)) {
-        double sd, cd;
-        az_sincos(d, sd, cd);
-        const double ns = fma(s, cd, c * sd);
-        const double nc = fma(c, cd, -(s * sd));
-        s = ns;
-        c = nc;
+    const double ad = fabs(d);
+    if (!az_any(ad > AZ_ROT_SMALL)) {
+        if (!az_any(ad > AZ_ROT_MILLI))
+            az_rotate_tiny(s, c, d);
+        else
+            az_rotate_small(s, c, d);
+    } else if (!az_any(ad > AZ_ROT_MED)) {
+        az_rotate_med(s, c, d);
+    } else if (!az_any(ad > 0.5)) {
+        az_rotate_large(s, c, d);
     } else {
-        az_rotate_small(s, c, d);
+        az_rotate_full(s, c, d);
     }
+}
+// one vote for the expected tier, generic fallback otherwise
+AZ_DEVICE void az_rotate_le_tiny(double &s, double &c, double d)
+{
+    if (!az_any(fabs(d) > AZ_ROT_MILLI))
+        az_rotate_tiny(s, c, d);
+    else
+        az_rotate(s, c, d);
+}
+AZ_DEVICE void az_rotate_le_small(double &s, double &c, double d)
+{
+    if (!az_any(fabs(d) > AZ_ROT_SMALL))
+        az_rotate_small(s, c, d);
+    else
+        az_rotate(s, c, d);
 }
 // (s,c) of a+b from (sa,ca),(sb,cb)
 AZ_DEVICE void az_angle_add(double sa, double ca, double sb, double cb, double &s, double &c)

@@ -38,10 +38,14 @@ enum AzField {
 #define AZ_FLAG_DEEP (1u << 8)
 #define AZ_FLAG_ISIMP (1u << 9)
 #define AZ_FLAG_IREZ(f) (((f) >> 10) & 3u)
+//  bits 12-13 eccentricity class of near-earth satellites (0: e < 0.0075, 1: e < 0.1, 2: rest);
+//             classes 1-2 need more Kepler-Newton trips / wider rotation tiers; the host groups
+//             them inside each workgroup so they do not drag whole waves through the slow path
+#define AZ_FLAG_ECLASS(f) (((f) >> 12) & 3u)
 
 // raw TLE-unit inputs to the init kernel: in[k * n_pad + sat]
 enum AzRawField { R_epoch_jd, R_mm_revday, R_ecc, R_incl_deg, R_raan_deg, R_argp_deg, R_ma_deg, R_bstar, AZ_NUM_RAW };
 
 struct AzGrav {
-    double radius_km, j2, j4, xke, j3oj2, vkmpersec;
+    double radius_km, j2, j4, xke, j3oj2, vkmpersec, half_j2;
 };

@@ -27,6 +27,9 @@ AZ_DEVICE double az_poly3(double x, double c0, double c1, double c2, double c3)
 
 AZ_DEVICE double az_gstime(double jdut1)
 {
+// plain IEEE operations, no FMA contraction: the argument reaches ~1.5e5 rad before the modulo, so a
+// single fused rounding would move the result by 3e-11 rad relative to any host evaluation
+#pragma clang fp contract(off)
     const double tut1 = (jdut1 - 2451545.0) / 36525.0;
     double temp = -6.2e-6 * tut1 * tut1 * tut1 + 0.093104 * tut1 * tut1 +
                   (876600.0 * 3600.0 + 8640184.812866) * tut1 + 67310.54841;
@@ -165,6 +168,7 @@ AZ_DEVICE unsigned az_init_satellite(const double raw[AZ_NUM_RAW], const AzGrav 
         S(t5cof, 0.2 * (3.0 * d4 + 12.0 * cc1 * d3 + 6.0 * d2 * d2 + 15.0 * cc1sq * (2.0 * d2 + cc1sq)));
     }
     if (isimp) flags |= AZ_FLAG_ISIMP;
+    flags |= (ecco < 0.0075 ? 0u : (ecco < 0.1 ? 1u : 2u)) << 12;
 
     // ---------------------------------------------------------------- deep space
     unsigned irez = 0;

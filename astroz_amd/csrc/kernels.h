@@ -13,7 +13,16 @@
 #include "init_device.h"
 #include "propagate_device.h"
 
-#define AZ_BLOCK 64 /* one wave per workgroup: no cross-wave barriers anywhere */
+#ifndef AZ_BLOCK
+// 256 satellites per workgroup = four independent waves (no barriers anywhere).  The host orders
+// each 256-satellite group by eccentricity class, so the few members that need extra
+// Kepler-Newton trips share one wave instead of slowing all four, while the group's output rows
+// stay one contiguous 6-KB span per step that a single CU fills within microseconds.
+#define AZ_BLOCK 256
+#endif
+#ifndef AZ_MIN_WAVES
+#define AZ_MIN_WAVES 1 /* __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow */
+#endif
 #define AZ_RESEED 256 /* re-seed carried (sin,cos) pairs with a full sincos every 256 steps */
 #define AZ_SM_CHUNK 4 /* time steps staged in LDS per flush in the satellite-major store path */
 
@@ -47,25 +56,53 @@ __device__ __forceinline__ void az_epilogue(double r[3], double v[3], int mode, 
     }
 }
 
-// Stores of one time step.
-//  time-major  (t, s, 3): lane = satellite -> a wave writes 64 x 24 B = 1,536 contiguous bytes
-//  sat-major   (s, t, 3): rows are n_times*24 B apart, so AZ_SM_CHUNK steps are staged in LDS and
-//                         flushed as 8-byte words that are contiguous along each satellite's row
-template <int LAYOUT, bool VEL>
-struct Stager {
-    // [pos|vel][lane][AZ_SM_CHUNK*3 + 1]: the +1 double of padding makes the per-lane row stride
-    // 13 doubles = 26 banks, so the 16-lane groups of ds_write_b64 hit distinct bank pairs
-    static constexpr int ROW = AZ_SM_CHUNK * 3 + 1;
-};
+// LDS staging.  All staging is wave-private (each wave owns a slice of the array and only ever
+// exchanges data between its own lanes), so no s_barrier and -- more importantly -- no
+// `s_waitcnt vmcnt(0)` is needed: DS operations of one wave execute in issue order, and the
+// outstanding global stores of earlier steps keep draining underneath the arithmetic.
+//  time-major (t, s, 3): the wave's 64 x 24 B of one step are contiguous in memory when its
+//      satellites are consecutive; they are transposed through LDS so that every lane stores
+//      16 aligned bytes (global_store_dwordx4: 1,024 + 512 contiguous bytes per wave) instead of
+//      three 8-byte pieces at a 24-byte stride.  Full cache lines leave the CU -> no partial-line
+//      read-modify-write at the memory side.
+//  sat-major (s, t, 3): rows are n_times*24 B apart; AZ_SM_CHUNK steps are staged and flushed as
+//      8-byte words that are contiguous along each satellite's row.
+#define AZ_TM_ROW 192 /* doubles per wave and per array in the time-major staging slice */
+#define AZ_SM_ROW (AZ_SM_CHUNK * 3 + 1) /* +1 double: 26-bank row stride, conflict-free ds_write_b64 */
 
-template <int LAYOUT, bool VEL, bool DEEP>
-__global__ void __launch_bounds__(AZ_BLOCK) k_propagate(PropArgs p)
+__device__ __forceinline__ double az_readlane_f64(double x, unsigned lane_uniform)
 {
-    __shared__ double lds[(LAYOUT == 0) ? (VEL ? 2 : 1) * AZ_BLOCK * Stager<LAYOUT, VEL>::ROW : 1];
-    constexpr int ROW = Stager<LAYOUT, VEL>::ROW;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), (int)lane_uniform);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), (int)lane_uniform);
+    return __hiloint2double(hi, lo);
+}
 
-    const unsigned lane = threadIdx.x;
-    const unsigned li = blockIdx.x * AZ_BLOCK + lane;
+__device__ __forceinline__ void az_wave_lds_fence()
+{
+    // compiler-level ordering of LDS accesses within the wave (the hardware already executes one
+    // wave's DS instructions in order); emits no instruction
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// FRAME = false: TEME output, no epilogue code at all (keeps its registers and SGPRs out of the
+// hot kernel); FRAME = true: ECEF / geodetic chosen at run time by p.mode.
+template <int LAYOUT, bool VEL, bool DEEP, bool FRAME>
+__global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : ((DEEP || FRAME) ? 1 : 2))) k_propagate(PropArgs p)
+{
+    constexpr int WAVES = AZ_BLOCK / 64;
+    constexpr int SLICE = (LAYOUT == 1) ? AZ_TM_ROW : 64 * AZ_SM_ROW;
+    __shared__ __attribute__((aligned(16))) double lds[(VEL ? 2 : 1) * WAVES * SLICE];
+
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = threadIdx.x >> 6;
+    double *lds_p = lds + wave * SLICE;
+    double *lds_v = lds + (WAVES + wave) * SLICE;
+
+    const unsigned li0 = blockIdx.x * AZ_BLOCK + wave * 64; // first list slot of this wave
+    if (li0 >= p.n_list) return;                            // whole wave beyond the list (AZ_BLOCK > 64 only)
+    const unsigned li = li0 + lane;
     const bool in_range = li < p.n_list;
     // out-of-range lanes shadow the last satellite (the reference pads its last batch the same way,
     // Constellation.zig L145-147) so the wave stays convergent; they never store
@@ -75,6 +112,11 @@ __global__ void __launch_bounds__(AZ_BLOCK) k_propagate(PropArgs p)
     const double off = p.offsets ? p.offsets[s] : 0.0;
     const unsigned t0 = blockIdx.y * p.tile;
     const unsigned t1 = min(t0 + p.tile, p.n_times);
+
+    // time-major fast path: this wave's 64 satellites are consecutive catalog rows
+    const unsigned s_first = p.list[li0];
+    const bool dense = (LAYOUT == 1) && (li0 + 63 < p.n_list) && (p.list[min(li0 + 63, p.n_list - 1)] - s_first == 63u) &&
+                       (p.mask == nullptr);
 
     Sgp4Lane e4;
     Sgp4Carry c4;
@@ -89,25 +131,33 @@ __global__ void __launch_bounds__(AZ_BLOCK) k_propagate(PropArgs p)
     } else {
         az_load_sgp4(p.el, p.n_pad, s, fl, e4);
         c4.t_prev = 0.0;
-        c4.sW = c4.sO = 0.0;
-        c4.cW = c4.cO = 1.0;
+        c4.sW = c4.sO = c4.sA = 0.0;
+        c4.cW = c4.cO = c4.cA = 1.0;
     }
 
-    // block of satellite rows this wave flushes in the sat-major path
-    const unsigned li0 = blockIdx.x * AZ_BLOCK;
-
+    double tcache = 0.0;
 #pragma unroll 1
     for (unsigned i = t0; i < t1; ++i) {
-        const double t = p.times[i] + off;
+        // Time values: one coalesced 512-B vector load per 64 steps parks 64 of them in a VGPR (one
+        // per lane); each step then broadcasts its value with v_readlane.  A per-step load would be
+        // followed by s_waitcnt vmcnt(0), which also waits for every outstanding global STORE of the
+        // previous steps and serialises the arithmetic against the write stream.
+        const unsigned k64 = __builtin_amdgcn_readfirstlane((i - t0) & 63u);
+        if (k64 == 0) tcache = p.times[min(i + lane, p.n_times - 1)];
+        const double t = az_readlane_f64(tcache, k64) + off;
         double r[3], v[3];
         int rc = 0;
+#if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
+        r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
+#else
         if (DEEP) {
             rc = az_sdp4_step<VEL>(e8, q8, p.g, t, c8, r, v);
         } else {
             const bool first = ((i - t0) % AZ_RESEED) == 0;
             az_sgp4_step<VEL>(e4, p.g, t, first, c4, r, v);
         }
-        az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, i);
+#endif
+        if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, i);
         if (DEEP) {
             if (rc != 0) {
                 r[0] = r[1] = r[2] = 0.0;
@@ -116,8 +166,33 @@ __global__ void __launch_bounds__(AZ_BLOCK) k_propagate(PropArgs p)
             }
         }
 
+#if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only */
+        if (r[0] != 1.2345e300) continue;
+#endif
         if (LAYOUT == 1) {
-            if (wr) {
+            if (dense) {
+                lds_p[lane * 3 + 0] = r[0];
+                lds_p[lane * 3 + 1] = r[1];
+                lds_p[lane * 3 + 2] = r[2];
+                if (VEL) {
+                    lds_v[lane * 3 + 0] = v[0];
+                    lds_v[lane * 3 + 1] = v[1];
+                    lds_v[lane * 3 + 2] = v[2];
+                }
+                az_wave_lds_fence();
+                const size_t ob = ((size_t)i * p.stride_sats + s_first) * 3;
+                double2 *gp = reinterpret_cast<double2 *>(p.pos + ob);
+                const double2 *lp = reinterpret_cast<const double2 *>(lds_p);
+                gp[lane] = lp[lane];
+                if (lane < 32) gp[64 + lane] = lp[64 + lane];
+                if (VEL) {
+                    double2 *gv = reinterpret_cast<double2 *>(p.vel + ob);
+                    const double2 *lv = reinterpret_cast<const double2 *>(lds_v);
+                    gv[lane] = lv[lane];
+                    if (lane < 32) gv[64 + lane] = lv[64 + lane];
+                }
+                az_wave_lds_fence();
+            } else if (wr) {
                 const size_t ob = ((size_t)i * p.stride_sats + s) * 3;
                 p.pos[ob] = r[0];
                 p.pos[ob + 1] = r[1];
@@ -130,36 +205,36 @@ __global__ void __launch_bounds__(AZ_BLOCK) k_propagate(PropArgs p)
             }
         } else {
             const unsigned k = (i - t0) % AZ_SM_CHUNK;
-            double *row = lds + lane * ROW + k * 3;
+            double *row = lds_p + lane * AZ_SM_ROW + k * 3;
             row[0] = r[0];
             row[1] = r[1];
             row[2] = r[2];
             if (VEL) {
-                double *vrow = row + AZ_BLOCK * ROW;
+                double *vrow = lds_v + lane * AZ_SM_ROW + k * 3;
                 vrow[0] = v[0];
                 vrow[1] = v[1];
                 vrow[2] = v[2];
             }
             const bool flush = (k == AZ_SM_CHUNK - 1) || (i + 1 == t1);
             if (flush) {
-                __syncthreads(); // single wave: orders the LDS writes before the transposed reads
+                az_wave_lds_fence();
                 const unsigned nsteps = k + 1;
                 const unsigned tb = i - k; // first time index of this chunk
                 const unsigned words = nsteps * 3;
-                const unsigned total = AZ_BLOCK * words;
-                for (unsigned w = lane; w < total; w += AZ_BLOCK) {
+                const unsigned total = 64 * words;
+                for (unsigned w = lane; w < total; w += 64) {
                     const unsigned rl = w / words, cw = w - rl * words;
                     const unsigned lj = li0 + rl;
                     if (lj < p.n_list) {
                         const unsigned sj = p.list[lj];
                         if (p.mask == nullptr || p.mask[sj] != 0) {
                             const size_t ob = ((size_t)sj * p.n_times + tb) * 3 + cw;
-                            p.pos[ob] = lds[rl * ROW + cw];
-                            if (VEL) p.vel[ob] = lds[AZ_BLOCK * ROW + rl * ROW + cw];
+                            p.pos[ob] = lds_p[rl * AZ_SM_ROW + cw];
+                            if (VEL) p.vel[ob] = lds_v[rl * AZ_SM_ROW + cw];
                         }
                     }
                 }
-                __syncthreads();
+                az_wave_lds_fence();
             }
         }
     }
@@ -168,12 +243,12 @@ __global__ void __launch_bounds__(AZ_BLOCK) k_propagate(PropArgs p)
 // one satellite x many times: lane = time, the satellite's constants are wave-uniform.  Every
 // evaluation is a 'first' step (full sincos seeds); deep-space lanes integrate the resonance from
 // epoch themselves, like the reference's sdp4Times8 (src/Sdp4.zig L1105-1128).
-__global__ void __launch_bounds__(AZ_BLOCK) k_one_satellite(const double *el, const unsigned *flags,
+__global__ void __launch_bounds__(64) k_one_satellite(const double *el, const unsigned *flags,
                                                             size_t n_pad, unsigned sat, const double *tsince,
                                                             unsigned n, double *pos, double *vel,
                                                             unsigned char *err, int interleaved, AzGrav g)
 {
-    const unsigned i = blockIdx.x * AZ_BLOCK + threadIdx.x;
+    const unsigned i = blockIdx.x * 64 + threadIdx.x;
     const double t = tsince[i < n ? i : n - 1];
     const unsigned fl = flags[sat];
     double r[3], v[3];
@@ -245,10 +320,10 @@ __global__ void k_gmst(const double *times, unsigned n, double reference_jd, dou
 }
 
 // element initialisation: raw[k*n_pad + s] -> el rows + flags
-__global__ void __launch_bounds__(AZ_BLOCK) k_init(const double *raw, size_t n, size_t n_pad, AzGrav g, double *el,
+__global__ void __launch_bounds__(64) k_init(const double *raw, size_t n, size_t n_pad, AzGrav g, double *el,
                                                    unsigned *flags)
 {
-    const size_t s = (size_t)blockIdx.x * AZ_BLOCK + threadIdx.x;
+    const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (s >= n) return;
     double in[AZ_NUM_RAW];
 #pragma unroll

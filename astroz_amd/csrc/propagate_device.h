@@ -18,7 +18,9 @@
 struct Sgp4Lane {
     double mo, mdot, argpo, argpdot, nodeo, nodedot, xnodcf;
     double cc1, bc4, t2cof, ecco, a_base, no_unkozai;
-    double aycof, xlcof, con41, x1mth2, x7thm1, sinio, cosio;
+    double aycof, xlcof, sinio, cosio;
+    // J2 short-period factors, formed once per tile from con41 / x1mth2 / x7thm1 / sinio / cosio
+    double k_mrt, k_c2u, k_su, k_node, k_inc, x1mth2, k_rv;
     // higher-order drag (zeroed at load for isimp satellites, which disables every term)
     double omgcof, eta, xmcof, delmo, bc5, sinmao, d2, d3, d4, t3cof, t4cof, t5cof;
 };
@@ -28,7 +30,20 @@ struct Sgp4Carry {
     double t_prev;
     double sW, cW; // argpo + argpdot*t
     double sO, cO; // nodeo + nodedot*t + xnodcf*t^2
+    double sA, cA; // mo + mdot*t
 };
+
+// products of the inclination-dependent constants that the short-period step uses
+AZ_DEVICE void az_j2_factors(double con41, double x1mth2, double x7thm1, double sI, double cI, double &k_mrt,
+                             double &k_c2u, double &k_su, double &k_node, double &k_inc, double &k_rv)
+{
+    k_mrt = -1.5 * con41;     // mrt   = rl (1 + k_mrt temp2 betal) + k_c2u temp1 cos2u
+    k_c2u = 0.5 * x1mth2;
+    k_su = -0.25 * x7thm1;    // dsu   = k_su temp2 sin2u
+    k_node = 1.5 * cI;        // dnode = k_node temp2 sin2u
+    k_inc = 1.5 * cI * sI;    // dinc  = k_inc temp2 cos2u
+    k_rv = 1.5 * con41;       // rvdot = rvdotl + nx temp1 (x1mth2 cos2u + k_rv)
+}
 
 AZ_DEVICE void az_load_sgp4(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags,
                             Sgp4Lane &e)
@@ -38,8 +53,10 @@ AZ_DEVICE void az_load_sgp4(const double *__restrict__ el, size_t n_pad, size_t 
     e.nodeo = L(nodeo); e.nodedot = L(nodedot); e.xnodcf = L(xnodcf);
     e.cc1 = L(cc1); e.bc4 = L(bc4); e.t2cof = L(t2cof); e.ecco = L(ecco);
     e.a_base = L(a_base); e.no_unkozai = L(no_unkozai);
-    e.aycof = L(aycof); e.xlcof = L(xlcof); e.con41 = L(con41); e.x1mth2 = L(x1mth2);
-    e.x7thm1 = L(x7thm1); e.sinio = L(sinio); e.cosio = L(cosio);
+    e.aycof = L(aycof); e.xlcof = L(xlcof); e.sinio = L(sinio); e.cosio = L(cosio);
+    az_j2_factors(L(con41), L(x1mth2), L(x7thm1), e.sinio, e.cosio, e.k_mrt, e.k_c2u, e.k_su, e.k_node, e.k_inc,
+                  e.k_rv);
+    e.x1mth2 = L(x1mth2);
     const bool ho = !(flags & AZ_FLAG_ISIMP);
     e.omgcof = ho ? L(omgcof) : 0.0; e.eta = L(eta); e.xmcof = ho ? L(xmcof) : 0.0;
     e.delmo = L(delmo); e.bc5 = ho ? L(bc5) : 0.0; e.sinmao = L(sinmao);
@@ -56,12 +73,18 @@ AZ_DEVICE void az_load_sgp4(const double *__restrict__ el, size_t n_pad, size_t 
 //   (sO,cO)         sin/cos of nodem;  (sI,cI) sin/cos of the (mean) inclination
 //   ra = 1/sqrt(am)
 // returns mrt (corrected radius, Earth radii)
+struct J2Factors {
+    double k_mrt, k_c2u, k_su, k_node, k_inc, x1mth2, k_rv;
+};
+
 template <bool VEL>
 AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double axnl, double aynl,
                                   double su0, double cu0, double sO, double cO, double sI, double cI,
-                                  double con41, double x1mth2, double x7thm1, double r[3], double v[3])
+                                  const J2Factors &k, double r[3], double v[3])
 {
     // Newton on  E - aynl*cosE + axnl*sinE = u  with eps = E - u carried instead of E.
+    // Exit test: the step after d would be ~ (el/2) d^2, so stop once el2 * d^4 < (2e-13)^2.
+    const double el2 = fma(axnl, axnl, aynl * aynl);
     double s = su0, c = cu0, eps = 0.0;
 #pragma unroll 1
     for (int it = 0; it < 10; ++it) {
@@ -70,26 +93,18 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
         double d = num * az_rcp1(den);
         d = fmin(fmax(d, -0.95), 0.95);
         eps += d;
-        const double ad = fabs(d);
-        if (az_any(ad > AZ_ROT_SMALL)) {
-            double sd, cd;
-            az_sincos(d, sd, cd);
-            const double ns = fma(s, cd, c * sd);
-            c = fma(c, cd, -(s * sd));
-            s = ns;
-        } else if (az_any(ad > AZ_ROT_TINY)) {
-            az_rotate_small(s, c, d);
-        } else {
-            az_rotate_tiny(s, c, d);
-        }
-        // quadratic convergence: once |d| < 3e-7 the remaining error is < e/2 * 1e-13
-        if (!az_any(ad >= 3.0e-7)) break;
+        if (it == 0)
+            az_rotate_le_small(s, c, d);
+        else
+            az_rotate_le_tiny(s, c, d);
+        const double d2 = d * d;
+        if (!az_any(el2 * d2 * d2 >= 4.0e-26)) break;
     }
 
     const double inv_am = ra * ra;
     const double ecose = fma(axnl, c, aynl * s);
     const double esine = fma(axnl, s, -(aynl * c));
-    const double omel2 = 1.0 - fma(axnl, axnl, aynl * aynl);
+    const double omel2 = 1.0 - el2;
     const double rb = az_rsqrt(omel2);
     const double betal = omel2 * rb;
     const double ome = 1.0 - ecose;
@@ -102,19 +117,22 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
     const double cos2u = fma(-2.0 * sinu, sinu, 1.0);
 
     const double inv_pl = inv_am * rb * rb;
-    const double temp1 = 0.5 * g.j2 * inv_pl;
+    const double temp1 = g.half_j2 * inv_pl;
     const double temp2 = temp1 * inv_pl;
 
-    const double mrt = fma(rl, fma(-1.5 * temp2 * betal, con41, 1.0), 0.5 * temp1 * x1mth2 * cos2u);
-    const double dsu = -0.25 * temp2 * x7thm1 * sin2u;
-    const double t2c = 1.5 * temp2 * cI;
-    const double dnode = t2c * sin2u;
-    const double dinc = t2c * sI * cos2u;
-
+    const double mrt = fma(rl, fma(k.k_mrt * temp2, betal, 1.0), k.k_c2u * temp1 * cos2u);
+    const double t2s = temp2 * sin2u;
     double ssu = sinu, csu = cosu, sn = sO, cn = cO, si = sI, ci = cI;
-    az_rotate(ssu, csu, dsu);
-    az_rotate(sn, cn, dnode);
-    az_rotate(si, ci, dinc);
+    // the three corrections are bounded by 1.5*temp2 = 0.75 J2 / pl^2 (8e-4 for pl = 1): one vote
+    if (!az_any(temp2 > 6.0e-4)) {
+        az_rotate_tiny(ssu, csu, k.k_su * t2s);
+        az_rotate_tiny(sn, cn, k.k_node * t2s);
+        az_rotate_tiny(si, ci, k.k_inc * temp2 * cos2u);
+    } else {
+        az_rotate(ssu, csu, k.k_su * t2s);
+        az_rotate(sn, cn, k.k_node * t2s);
+        az_rotate(si, ci, k.k_inc * temp2 * cos2u);
+    }
 
     const double xmx = -sn * ci, xmy = cn * ci;
     const double ux = fma(xmx, ssu, cn * csu);
@@ -127,17 +145,16 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
     if (VEL) {
         const double sqrt_am = am * ra;
         const double inv_rl = inv_am * inv_ome;
-        const double rdotl = sqrt_am * esine * inv_rl;
-        const double rvdotl = sqrt_am * betal * inv_rl;
-        const double nx = inv_am * ra; // nm / xke = am^-1.5
-        const double mvt = fma(-nx * temp1 * x1mth2, sin2u, rdotl);
-        const double rvdot = fma(nx * temp1, fma(x1mth2, cos2u, 1.5 * con41), rvdotl);
+        const double vk = sqrt_am * inv_rl * g.vkmpersec; // common factor of rdotl, rvdotl (km/s)
+        const double nxt = inv_am * ra * temp1 * g.vkmpersec; // (nm/xke) temp1, km/s
+        const double mvt = fma(-nxt * k.x1mth2, sin2u, vk * esine);
+        const double rvdot = fma(nxt, fma(k.x1mth2, cos2u, k.k_rv), vk * betal);
         const double vx = fma(xmx, csu, -(cn * ssu));
         const double vy = fma(xmy, csu, -(sn * ssu));
         const double vz = si * csu;
-        v[0] = fma(mvt, ux, rvdot * vx) * g.vkmpersec;
-        v[1] = fma(mvt, uy, rvdot * vy) * g.vkmpersec;
-        v[2] = fma(mvt, uz, rvdot * vz) * g.vkmpersec;
+        v[0] = fma(mvt, ux, rvdot * vx);
+        v[1] = fma(mvt, uy, rvdot * vy);
+        v[2] = fma(mvt, uz, rvdot * vz);
     }
     return mrt;
 }
@@ -154,26 +171,45 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const AzGrav &g, double t, bool f
         const double dt = t - st.t_prev;
         const double dW = e.argpdot * dt;
         const double dO = dt * fma(e.xnodcf, t + st.t_prev, e.nodedot);
-        if (first || az_any(fabs(dW) > AZ_ROT_SMALL || fabs(dO) > AZ_ROT_SMALL)) {
+        const double dA = e.mdot * dt;
+        if (first) {
             az_sincos(fma(e.argpdot, t, e.argpo), st.sW, st.cW);
             az_sincos(fma(e.xnodcf, t2, fma(e.nodedot, t, e.nodeo)), st.sO, st.cO);
+            az_sincos(fma(e.mdot, t, e.mo), st.sA, st.cA);
+        } else if (!az_any(fmax(fabs(dW), fabs(dO)) > AZ_ROT_MILLI || fabs(dA) > AZ_ROT_MED)) {
+            // a one-minute grid lands here: J2 rates are ~1e-4 rad/min, the mean motion < 0.08
+            az_rotate_tiny(st.sW, st.cW, dW);
+            az_rotate_tiny(st.sO, st.cO, dO);
+            az_rotate_med(st.sA, st.cA, dA);
         } else {
-            az_rotate_small(st.sW, st.cW, dW);
-            az_rotate_small(st.sO, st.cO, dO);
+            // any other grid: per-angle tier votes (increments formed from dt: no cancellation)
+            az_rotate(st.sW, st.cW, dW);
+            az_rotate(st.sO, st.cO, dO);
+            az_rotate(st.sA, st.cA, dA);
         }
         st.t_prev = t;
     }
 
     // secular gravity + drag (Sgp4Batch.zig L121-154); isimp lanes carry zeros in the ho terms
-    double sA, cA;
-    az_sincos(fma(e.mdot, t, e.mo), sA, cA); // xmdf
+    const double sA = st.sA, cA = st.cA; // (sin,cos) of xmdf = mo + mdot*t
     const double dm = fma(e.eta, cA, 1.0);
     const double th = fma(e.omgcof, t, e.xmcof * (dm * dm * dm - e.delmo)); // delomg + delm
     const double t3 = t2 * t, t4 = t3 * t;
     const double tempa = 1.0 - e.cc1 * t - e.d2 * t2 - e.d3 * t3 - e.d4 * t4;
-    // sin(mm) with mm = xmdf + th
-    double smm = sA, cmm = cA;
-    az_rotate(smm, cmm, th);
+    // sin(mm), mm = xmdf + th, and (sin,cos)(argpm), argpm = argpdf - th: one (p,q) pair serves both
+    double smm, sw = st.sW, cw = st.cW;
+    if (!az_any(fabs(th) > AZ_ROT_SMALL)) {
+        const double d2 = th * th;
+        const double q = d2 * fma(d2, fma(d2, -1.0 / 720.0, 1.0 / 24.0), -0.5);
+        const double p = th * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+        smm = sA + fma(sA, q, cA * p);
+        az_rot_apply(sw, cw, -p, q);
+    } else {
+        double sm = sA, cm = cA;
+        az_rotate(sm, cm, th);
+        smm = sm;
+        az_rotate(sw, cw, -th);
+    }
     const double tempe = fma(e.bc5, smm - e.sinmao, e.bc4 * t);
     const double templ = fma(e.t2cof, t2, fma(e.t3cof, t3, t4 * fma(t, e.t5cof, e.t4cof)));
 
@@ -182,18 +218,15 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const AzGrav &g, double t, bool f
     const double ra = az_rsqrt(am);
     const double temp = ra * ra * az_rcp(fma(-em, em, 1.0));
 
-    // argpm = argpdf - th
-    double sw = st.sW, cw = st.cW;
-    az_rotate(sw, cw, -th);
     const double axnl = em * cw;
     const double aynl = fma(em, sw, temp * e.aycof);
     // u0 = mm + argpm + temp*xlcof*axnl = xmdf + argpdf + no*templ + temp*xlcof*axnl
     double su0, cu0;
     az_angle_add(sA, cA, st.sW, st.cW, su0, cu0);
-    az_rotate(su0, cu0, fma(e.no_unkozai, templ, temp * e.xlcof * axnl));
+    az_rotate_le_small(su0, cu0, fma(e.no_unkozai, templ, temp * e.xlcof * axnl));
 
-    az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, st.sO, st.cO, e.sinio, e.cosio, e.con41,
-                          e.x1mth2, e.x7thm1, r, v);
+    const J2Factors k = {e.k_mrt, e.k_c2u, e.k_su, e.k_node, e.k_inc, e.x1mth2, e.k_rv};
+    az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, st.sO, st.cO, e.sinio, e.cosio, k, r, v);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -434,7 +467,10 @@ AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const Sdp4Res &q, const AzGrav &g,
     const double aycof = -0.5 * g.j3oj2 * sI;
     const double den = (fabs(cI + 1.0) > 1.5e-12) ? 1.0 + cI : 1.5e-12;
     const double xlcof = -0.25 * g.j3oj2 * sI * fma(5.0, cI, 3.0) * az_rcp(den);
-    const double x1mth2 = 1.0 - cI2, con41 = fma(3.0, cI2, -1.0), x7thm1 = fma(7.0, cI2, -1.0);
+    J2Factors k;
+    az_j2_factors(fma(3.0, cI2, -1.0), 1.0 - cI2, fma(7.0, cI2, -1.0), sI, cI, k.k_mrt, k.k_c2u, k.k_su, k.k_node,
+                  k.k_inc, k.k_rv);
+    k.x1mth2 = 1.0 - cI2;
 
     const double ra = az_rsqrt(am);
     const double temp = ra * ra * az_rcp(fma(-em, em, 1.0));
@@ -445,8 +481,7 @@ AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const Sdp4Res &q, const AzGrav &g,
     const double aynl = fma(em, sw, temp * aycof);
     az_sincos(mm + argpm + temp * xlcof * axnl, su0, cu0);
 
-    const double mrt = az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, sO, cO, sI, cI, con41, x1mth2,
-                                             x7thm1, r, v);
+    const double mrt = az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, sO, cO, sI, cI, k, r, v);
     if (rc == 0 && mrt < 1.0) rc = 6;
     return rc;
 }

@@ -18,7 +18,7 @@ int emul_num_fields() { return AZ_NUM_FIELDS; }
 // raw[8] -> fields[AZ_NUM_FIELDS]; returns flags
 unsigned emul_init(const double* raw, const double* grav6, double* fields)
 {
-    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5]};
+    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
     return az_init_satellite(raw, g, fields, 1, 0);
 }
 
@@ -27,7 +27,7 @@ unsigned emul_init(const double* raw, const double* grav6, double* fields)
 void emul_propagate(const double* fields, unsigned flags, const double* grav6, const double* ts, int n,
                     int incremental, double* out6, int* rc_out)
 {
-    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5]};
+    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
     if (flags & AZ_FLAG_DEEP) {
         Sdp4Lane e; Sdp4Res q; Sdp4Carry cy;
         az_load_sdp4(fields, 1, 0, flags, e, q);
@@ -43,7 +43,7 @@ void emul_propagate(const double* fields, unsigned flags, const double* grav6, c
     } else {
         Sgp4Lane e; Sgp4Carry st;
         az_load_sgp4(fields, 1, 0, flags, e);
-        st.t_prev = 0; st.sW = st.cW = st.sO = st.cO = 0;
+        st.t_prev = 0; st.sW = st.cW = st.sO = st.cO = st.sA = st.cA = 0;
         for (int i = 0; i < n; ++i) {
             double r[3], v[3];
             az_sgp4_step<true>(e, g, ts[i], (i == 0) || !incremental, st, r, v);
