@@ -1,0 +1,217 @@
+"""CPU tier (-m "not gpu"): host logic, the C-ABI surface, and the kernel algebra compiled for the host.
+
+No compute call of the product is made here (there is no GPU); what IS checked:
+  * libastroz_hip.so loads and exports every function include/astroz_hip.h declares;
+  * its host-only entry points (TLE text ingest) agree with the oracle's parser;
+  * compute entry points fail loudly (AZ_ERR_HIP) instead of falling back to a CPU path;
+  * the python-sgp4 helper functions (jday, days2mdhms) reproduce the reference's vectors (G7);
+  * the synthetic catalog generator emits valid 69-column TLEs that pass the reference's init checks;
+  * the DEVICE math headers, compiled for the host by the test-only emulation harness, reproduce the
+    oracle (catches algebra errors in the kernels without a GPU).
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def native():
+    import __graft_entry__ as g
+    g.build()
+    from astroz_amd import _native
+    return _native
+
+
+def test_header_symbols_exported(native):
+    hdr = open(os.path.join(ROOT, "include", "astroz_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b((?:azh|tle|sgp4|astroz)_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 30
+    L = native.lib()
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(native.EXPORTS) == names
+    assert L.astroz_version() == 0x000300
+
+
+def test_tle_ingest_matches_oracle(native, orc, golden):
+    L = native.lib()
+    for l1, l2 in golden["G9_structural"]["tles"]:
+        f = native.parse_tle_lines(l1, l2)
+        t = orc.parse_lines(l1, l2)
+        assert int(f[0]) == t.satnum and int(f[1]) == t.epoch_year
+        for a, b in ((f[2], t.epoch_day), (f[3], t.epoch_jd), (f[4], t.ndot), (f[5], t.bstar), (f[6], t.incl_deg),
+                     (f[7], t.raan_deg), (f[8], t.ecc), (f[9], t.argp_deg), (f[10], t.ma_deg), (f[11], t.mm_revday)):
+            assert a == b  # bit-exact: same decimal strings, same operations
+    # c_api tle_* (src/c_api/tle.zig): CRLF / blank lines / padding, short input
+    l1, l2 = golden["G9_structural"]["tles"][2]
+    h = C.c_void_p()
+    assert L.tle_parse(("  " + l1 + "  \r\n\r\n  " + l2 + "  ").encode(), C.byref(h)) == 0
+    assert L.tle_get_satellite_number(h) == 55909
+    assert abs(L.tle_get_inclination(h) - 43.9978) < 1e-12
+    assert abs(L.tle_get_eccentricity(h) - 0.0011446) < 1e-15
+    assert abs(L.tle_get_mean_motion(h) - 15.05761711) < 1e-12
+    L.tle_free(h)
+    assert L.tle_parse(l1.encode(), C.byref(h)) == -1  # badTleLength
+    with pytest.raises(ValueError):
+        native.parse_tle_lines(l1[:40], l2)
+    # alpha-5 catalog numbers (src/Tle.zig L281-290)
+    a5 = native.parse_tle_lines("1 B1234U" + l1[8:], "2 B1234" + l2[7:])
+    assert int(a5[0]) == 111234
+
+
+def test_no_cpu_fallback(native):
+    """Without a GPU every compute entry point must fail loudly, never compute on the host."""
+    if native.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    l1 = "1 25544U 98067A   24127.82853009  .00015698  00000+0  27310-3 0  9995"
+    l2 = "2 25544  51.6393 160.4574 0003580 140.6673 205.7250 15.50957674452123"
+    with pytest.raises(native.NativeError) as ei:
+        native.DeviceConstellation.from_tle_lines([(l1, l2)])
+    assert ei.value.code == native.AZ_ERR_HIP
+    from astroz_amd.api import Satrec
+    sat = Satrec.twoline2rv(l1, l2)          # text parsing only: fine without a GPU
+    assert sat.satnum == 25544 and abs(sat.jdsatepoch + sat.jdsatepochF - 2460437.32853009) < 1e-6
+    with pytest.raises(native.NativeError):
+        sat.sgp4(2460437.5, 0.0)
+    L = native.lib()
+    h, s = C.c_void_p(), C.c_void_p()
+    assert L.tle_parse((l1 + "\n" + l2).encode(), C.byref(h)) == 0
+    assert L.sgp4_init(h, 1, C.byref(s)) == native.AZ_ERR_HIP
+    L.tle_free(h)
+
+
+def test_time_helpers(golden):
+    from astroz_amd.api import days2mdhms, jday
+    g = golden["G7_time"]
+    jd, fr = jday(*g["jday"]["args"])
+    assert jd == g["jday"]["jd"] and abs(fr - g["jday"]["fr"]) < g["jday"]["tol"]
+    mon, day, hr, mi, sec = days2mdhms(*g["days2mdhms"]["args"])
+    assert [mon, day, hr, mi] == g["days2mdhms"]["value"][:4]
+    assert abs(sec - g["days2mdhms"]["value"][4]) < g["days2mdhms"]["tol_sec"]
+    assert days2mdhms(2024, 60.5)[:3] == (2, 29, 12)      # leap day
+    assert days2mdhms(2023, 60.0)[:2] == (3, 1)
+    assert jday(2024, 5, 6, 12, 0, 0.0) == (2460436.5, 0.5)
+
+
+def test_text_front_ends(orc):
+    import astroz_amd as az
+    l1 = "1 25544U 98067A   24127.82853009  .00015698  00000+0  27310-3 0  9995"
+    l2 = "2 25544  51.6393 160.4574 0003580 140.6673 205.7250 15.50957674452123"
+    text = "ISS (ZARYA)\n" + l1 + "\n" + l2 + "\nORPHAN\n" + l1 + "\n"
+    assert az._parse_tle_pairs(text) == [(l1, l2)]
+    assert az._load_tle_text(text) == (text, "tle")
+    omm = ('[{"NORAD_CAT_ID": 25544, "OBJECT_ID": "1998-067A", "EPOCH": "2024-05-06T19:53:05.000000",'
+           ' "MEAN_MOTION": 15.50957674, "ECCENTRICITY": 0.000358, "INCLINATION": 51.6393,'
+           ' "RA_OF_ASC_NODE": 160.4574, "ARG_OF_PERICENTER": 140.6673, "MEAN_ANOMALY": 205.725,'
+           ' "BSTAR": 0.0002731, "MEAN_MOTION_DOT": 0.00015698, "MEAN_MOTION_DDOT": 0,'
+           ' "ELEMENT_SET_NO": 999, "REV_AT_EPOCH": 45212, "CLASSIFICATION_TYPE": "U", "EPHEMERIS_TYPE": 0}]')
+    (o1, o2), = az._omm_to_tle_pairs(omm)
+    assert len(o1) == 69 and len(o2) == 69
+    t = orc.parse_lines(o1, o2)
+    assert t.satnum == 25544 and abs(t.bstar - 0.0002731) < 1e-12 and abs(t.ecc - 0.000358) < 1e-12
+    assert abs(t.mm_revday - 15.50957674) < 1e-9 and abs(t.epoch_day - 127.82853009) < 2e-8
+    from datetime import datetime, timezone
+    assert az._start_jd(datetime(2000, 1, 1, 12, tzinfo=timezone.utc)) == 2451545.0
+
+
+def test_synthetic_catalog_is_valid(orc):
+    from astroz_amd import synth
+    pairs = synth.synth_catalog(n_near=3000, n_deep=340, seed=20260926)
+    assert len(pairs) == 3340
+    for l1, l2 in pairs[:400]:
+        assert len(l1) == 69 and len(l2) == 69
+        if (l1, l2) in synth.REFERENCE_DEEP_TLES:
+            continue  # the reference's own deep-space test TLEs carry meaningless checksums
+        assert int(l1[68]) == synth._checksum(l1[:68]) and int(l2[68]) == synth._checksum(l2[:68])
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    assert not cat.init_rc.any()                       # every member passes the reference's init checks
+    assert int(cat.is_deep.sum()) == 340
+    irez = cat.fields("irez")[cat.is_deep]
+    assert (irez == 1).sum() > 50 and (irez == 2).sum() > 3 and (irez == 0).sum() > 50
+    incl = cat.fields("inclo")[cat.is_deep]
+    assert (incl < 0.2).any()                          # Lyddane branch is exercised
+    assert (cat.fields("isimp")[~cat.is_deep] == 1).sum() > 5   # simplified-drag branch too
+    # deterministic
+    assert synth.synth_catalog(50, 10, seed=4) == synth.synth_catalog(50, 10, seed=4)
+
+
+@pytest.fixture(scope="module")
+def emul():
+    """Host build of the device math headers (tests/host_emul/emul.cpp)."""
+    src = os.path.join(ROOT, "tests", "host_emul", "emul.cpp")
+    lib = os.path.join(ROOT, "tests", "host_emul", "libemul.so")
+    hdrs = [os.path.join(ROOT, "astroz_amd", "csrc", h) for h in ("devmath.h", "fields.h", "init_device.h", "propagate_device.h")]
+    if not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-Wno-unknown-pragmas", "-o", lib, src])
+    E = C.CDLL(lib)
+    E.emul_init.restype = C.c_uint
+    E.emul_init.argtypes = [C.c_void_p] * 3
+    E.emul_propagate.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    E.emul_sincos.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
+    E.emul_rcp.restype = C.c_double
+    E.emul_rcp.argtypes = [C.c_double]
+    E.emul_rsqrt.restype = C.c_double
+    E.emul_rsqrt.argtypes = [C.c_double]
+    E.emul_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
+    return E
+
+
+def test_device_math_kats(emul):
+    """G10: the reference's simdMath KAT inputs (src/simdMath.zig L214-286); expected = libm."""
+    s, c = C.c_double(), C.c_double()
+    xs = [0.0, np.pi / 6, np.pi / 4, np.pi / 2, -np.pi / 3, np.pi, 2 * np.pi, 10.0, 100.0, 1000.0, -777.7, 1e5]
+    xs += list(np.random.default_rng(1).uniform(-2000, 2000, 2000))
+    for x in xs:
+        emul.emul_sincos(x, C.byref(s), C.byref(c))
+        assert abs(s.value - np.sin(x)) < 4e-16 and abs(c.value - np.cos(x)) < 4e-16, x
+    for x in np.random.default_rng(2).uniform(0.05, 50.0, 2000):
+        assert abs(emul.emul_rcp(x) * x - 1.0) < 5e-16
+        assert abs(emul.emul_rsqrt(x) ** 2 * x - 1.0) < 1e-15
+    for d in [0.0, 1e-9, -3e-5, 9e-4, -7e-3, 0.06, -0.12, 0.4, -0.49, 1.3, -2.9]:
+        a = 0.7321
+        ss, cc = C.c_double(np.sin(a)), C.c_double(np.cos(a))
+        emul.emul_rotate(C.byref(ss), C.byref(cc), d)
+        assert abs(ss.value - np.sin(a + d)) < 5e-16 and abs(cc.value - np.cos(a + d)) < 5e-16, d
+
+
+def _grav6(which):
+    g = {1: (6378.135, 0.001082616, -0.00000165597, 0.0743669161331734132, -0.00234506972242078),
+         0: (6378.137, 0.00108262998905, -0.00000161098761, 0.07436685316871385, -0.00233899967218727)}[which]
+    return np.array([g[0], g[1], g[2], g[3], g[4], g[3] * g[0] / 60.0])
+
+
+@pytest.mark.parametrize("step", [1.0, 7.0])
+def test_emulated_kernels_match_oracle(emul, orc, step):
+    """init + SGP4 (carried-rotation form) + SDP4 device code, host-compiled, vs the oracle."""
+    from astroz_amd import synth
+    pairs = synth.synth_catalog(150, 40, seed=5)
+    tles = [orc.parse_lines(a, b) for a, b in pairs]
+    cat = orc.Catalog(tles, 1)
+    g = _grav6(1)
+    nf = emul.emul_num_fields()
+    ts = np.arange(0.0, 1440.0, step)[:400]
+    off = (synth.START_JD - cat.epoch_jd) * 1440.0
+    worst_r = worst_v = 0.0
+    for i, t in enumerate(tles):
+        raw = np.array([t.epoch_jd, t.mm_revday, t.ecc, t.incl_deg, t.raan_deg, t.argp_deg, t.ma_deg, t.bstar])
+        fields = np.zeros(nf)
+        flags = emul.emul_init(raw.ctypes.data, g.ctypes.data, fields.ctypes.data)
+        assert (flags & 0xff) == 0 and bool(flags & 0x100) == bool(cat.is_deep[i])
+        tt = ts + off[i]
+        out = np.zeros((len(tt), 6))
+        rc = np.zeros(len(tt), dtype=np.int32)
+        emul.emul_propagate(fields.ctypes.data, flags, g.ctypes.data, tt.ctypes.data, len(tt), 1, out.ctypes.data, rc.ctypes.data)
+        for k in range(0, len(tt), 7):
+            orc_rc, r, v = cat.propagate_one(i, tt[k])
+            assert orc_rc == rc[k]
+            worst_r = max(worst_r, np.abs(out[k, :3] - r).max())
+            worst_v = max(worst_v, np.abs(out[k, 3:] - v).max())
+    assert worst_r < 1e-6 and worst_v < 1e-9, (worst_r, worst_v)
