@@ -70,6 +70,19 @@ __device__ __forceinline__ void az_epilogue(double r[3], double v[3], int mode, 
 #define AZ_TM_ROW 192 /* doubles per wave and per array in the time-major staging slice */
 #define AZ_SM_ROW (AZ_SM_CHUNK * 3 + 1) /* +1 double: 26-bank row stride, conflict-free ds_write_b64 */
 
+typedef double az_d2 __attribute__((ext_vector_type(2)));
+
+// output stores.  Plain (L2 write-back) stores are the default: measured on config 2, `nt` stores
+// leave the full kernel unchanged (0.431 vs 0.433 ms) but halve the rate of a pure write stream
+// (0.56 vs 0.24 ms) because partial-line pieces no longer combine in L2.
+#if defined(AZ_STORE_POLICY) && AZ_STORE_POLICY == 1
+#define AZ_ST1(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define AZ_ST2(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define AZ_ST1(ptr, val) (*(ptr) = (val))
+#define AZ_ST2(ptr, val) (*(ptr) = (val))
+#endif
+
 __device__ __forceinline__ double az_readlane_f64(double x, unsigned lane_uniform)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), (int)lane_uniform);
@@ -93,12 +106,15 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
 {
     constexpr int WAVES = AZ_BLOCK / 64;
     constexpr int SLICE = (LAYOUT == 1) ? AZ_TM_ROW : 64 * AZ_SM_ROW;
-    __shared__ __attribute__((aligned(16))) double lds[(VEL ? 2 : 1) * WAVES * SLICE];
+    constexpr int COLD = DEEP ? 0 : C_NUM * 64; // near-earth once-per-step constants, one column per lane
+    __shared__ __attribute__((aligned(16))) double lds[WAVES * ((VEL ? 2 : 1) * SLICE + COLD)];
 
     const unsigned lane = threadIdx.x & 63u;
     const unsigned wave = threadIdx.x >> 6;
-    double *lds_p = lds + wave * SLICE;
-    double *lds_v = lds + (WAVES + wave) * SLICE;
+    double *lds_w = lds + wave * ((VEL ? 2 : 1) * SLICE + COLD); // this wave's private slice
+    double *lds_p = lds_w;
+    double *lds_v = lds_w + SLICE;
+    double *cold = lds_w + (VEL ? 2 : 1) * SLICE + lane;
 
     const unsigned li0 = blockIdx.x * AZ_BLOCK + wave * 64; // first list slot of this wave
     if (li0 >= p.n_list) return;                            // whole wave beyond the list (AZ_BLOCK > 64 only)
@@ -129,7 +145,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
         c8.xli = e8.xlamo;
         c8.xni = e8.no_unkozai;
     } else {
-        az_load_sgp4(p.el, p.n_pad, s, fl, e4);
+        az_load_sgp4(p.el, p.n_pad, s, fl, e4, cold);
         c4.t_prev = 0.0;
         c4.sW = c4.sO = c4.sA = 0.0;
         c4.cW = c4.cO = c4.cA = 1.0;
@@ -154,7 +170,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
             rc = az_sdp4_step<VEL>(e8, q8, p.g, t, c8, r, v);
         } else {
             const bool first = ((i - t0) % AZ_RESEED) == 0;
-            az_sgp4_step<VEL>(e4, p.g, t, first, c4, r, v);
+            az_sgp4_step<VEL>(e4, cold, p.el, p.n_pad, s, p.g, t, first, c4, r, v);
         }
 #endif
         if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, i);
@@ -180,27 +196,35 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
                     lds_v[lane * 3 + 2] = v[2];
                 }
                 az_wave_lds_fence();
+#if defined(AZ_ABLATE) && AZ_ABLATE == 3 /* tuning experiment: all stores hit one L2-resident 1.5-MB window */
+                const size_t ob = ((((size_t)i * p.stride_sats + s_first) * 3) & 0x1ffffu) & ~1ull;
+#else
                 const size_t ob = ((size_t)i * p.stride_sats + s_first) * 3;
-                double2 *gp = reinterpret_cast<double2 *>(p.pos + ob);
-                const double2 *lp = reinterpret_cast<const double2 *>(lds_p);
-                gp[lane] = lp[lane];
-                if (lane < 32) gp[64 + lane] = lp[64 + lane];
+#endif
+                az_d2 *gp = reinterpret_cast<az_d2 *>(p.pos + ob);
+                const az_d2 *lp = reinterpret_cast<const az_d2 *>(lds_p);
+                AZ_ST2(gp + lane, lp[lane]);
+                if (lane < 32) AZ_ST2(gp + 64 + lane, lp[64 + lane]);
                 if (VEL) {
-                    double2 *gv = reinterpret_cast<double2 *>(p.vel + ob);
-                    const double2 *lv = reinterpret_cast<const double2 *>(lds_v);
-                    gv[lane] = lv[lane];
-                    if (lane < 32) gv[64 + lane] = lv[64 + lane];
+                    az_d2 *gv = reinterpret_cast<az_d2 *>(p.vel + ob);
+                    const az_d2 *lv = reinterpret_cast<const az_d2 *>(lds_v);
+                    AZ_ST2(gv + lane, lv[lane]);
+                    if (lane < 32) AZ_ST2(gv + 64 + lane, lv[64 + lane]);
                 }
                 az_wave_lds_fence();
             } else if (wr) {
+#if defined(AZ_ABLATE) && AZ_ABLATE == 3
+                const size_t ob = (((size_t)i * p.stride_sats + s) * 3) & 0x1ffffu;
+#else
                 const size_t ob = ((size_t)i * p.stride_sats + s) * 3;
-                p.pos[ob] = r[0];
-                p.pos[ob + 1] = r[1];
-                p.pos[ob + 2] = r[2];
+#endif
+                AZ_ST1(p.pos + ob, r[0]);
+                AZ_ST1(p.pos + ob + 1, r[1]);
+                AZ_ST1(p.pos + ob + 2, r[2]);
                 if (VEL) {
-                    p.vel[ob] = v[0];
-                    p.vel[ob + 1] = v[1];
-                    p.vel[ob + 2] = v[2];
+                    AZ_ST1(p.vel + ob, v[0]);
+                    AZ_ST1(p.vel + ob + 1, v[1]);
+                    AZ_ST1(p.vel + ob + 2, v[2]);
                 }
             }
         } else {
@@ -266,9 +290,11 @@ __global__ void __launch_bounds__(64) k_one_satellite(const double *el, const un
         } else {
             Sgp4Lane e;
             Sgp4Carry c;
-            az_load_sgp4(el, n_pad, sat, fl, e);
+            __shared__ double cold_lds[C_NUM * 64];
+            double *cold = cold_lds + threadIdx.x;
+            az_load_sgp4(el, n_pad, sat, fl, e, cold);
             c.t_prev = 0.0;
-            az_sgp4_step<true>(e, g, t, true, c, r, v);
+            az_sgp4_step<true>(e, cold, el, n_pad, sat, g, t, true, c, r, v);
         }
     }
     if (rc != 0) {

@@ -14,16 +14,28 @@
 #include "fields.h"
 
 // ------------------------------------------------------------------------------------------
-// near-earth constants of one satellite, register resident for the whole time tile
+// near-earth constants of one satellite, split by how they are used inside the time loop:
+//   Sgp4Lane  -- touched several times per step, or on the critical path: VGPR resident (15 doubles)
+//   cold[]    -- touched exactly once per step by the secular update (18 doubles): staged in LDS,
+//                one column per lane (cold[k*AZ_COLD_STRIDE]: conflict-free ds_read_b64), which
+//                frees 36 VGPRs and lifts the occupancy of the VALU-bound kernel
+//   mo/argpo/nodeo -- only needed when the carried (sin,cos) pairs are re-seeded: re-read from the
+//                element table (L2-resident) on those steps
 struct Sgp4Lane {
-    double mo, mdot, argpo, argpdot, nodeo, nodedot, xnodcf;
-    double cc1, bc4, t2cof, ecco, a_base, no_unkozai;
+    double mdot, argpdot, nodedot, xnodcf;
     double aycof, xlcof, sinio, cosio;
     // J2 short-period factors, formed once per tile from con41 / x1mth2 / x7thm1 / sinio / cosio
     double k_mrt, k_c2u, k_su, k_node, k_inc, x1mth2, k_rv;
-    // higher-order drag (zeroed at load for isimp satellites, which disables every term)
-    double omgcof, eta, xmcof, delmo, bc5, sinmao, d2, d3, d4, t3cof, t4cof, t5cof;
 };
+enum Sgp4Cold {
+    C_cc1, C_bc4, C_t2cof, C_ecco, C_a_base, C_no_unkozai,
+    // higher-order drag (zeroed at load for isimp satellites, which disables every term)
+    C_omgcof, C_eta, C_xmcof, C_delmo, C_bc5, C_sinmao, C_d2, C_d3, C_d4, C_t3cof, C_t4cof, C_t5cof,
+    C_NUM
+};
+#ifndef AZ_COLD_STRIDE
+#define AZ_COLD_STRIDE 64
+#endif
 
 // (sin,cos) pairs carried from one time step to the next
 struct Sgp4Carry {
@@ -46,22 +58,23 @@ AZ_DEVICE void az_j2_factors(double con41, double x1mth2, double x7thm1, double 
 }
 
 AZ_DEVICE void az_load_sgp4(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags,
-                            Sgp4Lane &e)
+                            Sgp4Lane &e, double *cold)
 {
 #define L(f) el[(size_t)F_##f * n_pad + i]
-    e.mo = L(mo); e.mdot = L(mdot); e.argpo = L(argpo); e.argpdot = L(argpdot);
-    e.nodeo = L(nodeo); e.nodedot = L(nodedot); e.xnodcf = L(xnodcf);
-    e.cc1 = L(cc1); e.bc4 = L(bc4); e.t2cof = L(t2cof); e.ecco = L(ecco);
-    e.a_base = L(a_base); e.no_unkozai = L(no_unkozai);
+#define CS(k, val) cold[(k) * AZ_COLD_STRIDE] = (val)
+    e.mdot = L(mdot); e.argpdot = L(argpdot); e.nodedot = L(nodedot); e.xnodcf = L(xnodcf);
     e.aycof = L(aycof); e.xlcof = L(xlcof); e.sinio = L(sinio); e.cosio = L(cosio);
     az_j2_factors(L(con41), L(x1mth2), L(x7thm1), e.sinio, e.cosio, e.k_mrt, e.k_c2u, e.k_su, e.k_node, e.k_inc,
                   e.k_rv);
     e.x1mth2 = L(x1mth2);
+    CS(C_cc1, L(cc1)); CS(C_bc4, L(bc4)); CS(C_t2cof, L(t2cof)); CS(C_ecco, L(ecco));
+    CS(C_a_base, L(a_base)); CS(C_no_unkozai, L(no_unkozai));
     const bool ho = !(flags & AZ_FLAG_ISIMP);
-    e.omgcof = ho ? L(omgcof) : 0.0; e.eta = L(eta); e.xmcof = ho ? L(xmcof) : 0.0;
-    e.delmo = L(delmo); e.bc5 = ho ? L(bc5) : 0.0; e.sinmao = L(sinmao);
-    e.d2 = L(d2); e.d3 = L(d3); e.d4 = L(d4);
-    e.t3cof = L(t3cof); e.t4cof = L(t4cof); e.t5cof = L(t5cof);
+    CS(C_omgcof, ho ? L(omgcof) : 0.0); CS(C_eta, L(eta)); CS(C_xmcof, ho ? L(xmcof) : 0.0);
+    CS(C_delmo, L(delmo)); CS(C_bc5, ho ? L(bc5) : 0.0); CS(C_sinmao, L(sinmao));
+    CS(C_d2, L(d2)); CS(C_d3, L(d3)); CS(C_d4, L(d4));
+    CS(C_t3cof, L(t3cof)); CS(C_t4cof, L(t4cof)); CS(C_t5cof, L(t5cof));
+#undef CS
 #undef L
 }
 
@@ -161,10 +174,13 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
 
 // ------------------------------------------------------------------------------------------
 // one near-earth propagation.  `first` (wave-uniform) seeds the carried pairs with full sincos.
+// `el`/`n_pad`/`sat` locate the satellite's column of the element table for the re-seed loads.
 template <bool VEL>
-AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const AzGrav &g, double t, bool first, Sgp4Carry &st,
-                            double r[3], double v[3])
+AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const double *cold, const double *__restrict__ el, size_t n_pad,
+                            size_t sat, const AzGrav &g, double t, bool first, Sgp4Carry &st, double r[3],
+                            double v[3])
 {
+#define CL(k) cold[(k) * AZ_COLD_STRIDE]
     const double t2 = t * t;
     // slowly drifting angles: advance the carried (sin,cos) pairs
     {
@@ -173,9 +189,11 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const AzGrav &g, double t, bool f
         const double dO = dt * fma(e.xnodcf, t + st.t_prev, e.nodedot);
         const double dA = e.mdot * dt;
         if (first) {
-            az_sincos(fma(e.argpdot, t, e.argpo), st.sW, st.cW);
-            az_sincos(fma(e.xnodcf, t2, fma(e.nodedot, t, e.nodeo)), st.sO, st.cO);
-            az_sincos(fma(e.mdot, t, e.mo), st.sA, st.cA);
+            const double argpo = el[(size_t)F_argpo * n_pad + sat], nodeo = el[(size_t)F_nodeo * n_pad + sat];
+            const double mo = el[(size_t)F_mo * n_pad + sat];
+            az_sincos(fma(e.argpdot, t, argpo), st.sW, st.cW);
+            az_sincos(fma(e.xnodcf, t2, fma(e.nodedot, t, nodeo)), st.sO, st.cO);
+            az_sincos(fma(e.mdot, t, mo), st.sA, st.cA);
         } else if (!az_any(fmax(fabs(dW), fabs(dO)) > AZ_ROT_MILLI || fabs(dA) > AZ_ROT_MED)) {
             // a one-minute grid lands here: J2 rates are ~1e-4 rad/min, the mean motion < 0.08
             az_rotate_tiny(st.sW, st.cW, dW);
@@ -192,10 +210,10 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const AzGrav &g, double t, bool f
 
     // secular gravity + drag (Sgp4Batch.zig L121-154); isimp lanes carry zeros in the ho terms
     const double sA = st.sA, cA = st.cA; // (sin,cos) of xmdf = mo + mdot*t
-    const double dm = fma(e.eta, cA, 1.0);
-    const double th = fma(e.omgcof, t, e.xmcof * (dm * dm * dm - e.delmo)); // delomg + delm
+    const double dm = fma(CL(C_eta), cA, 1.0);
+    const double th = fma(CL(C_omgcof), t, CL(C_xmcof) * (dm * dm * dm - CL(C_delmo))); // delomg + delm
     const double t3 = t2 * t, t4 = t3 * t;
-    const double tempa = 1.0 - e.cc1 * t - e.d2 * t2 - e.d3 * t3 - e.d4 * t4;
+    const double tempa = 1.0 - CL(C_cc1) * t - CL(C_d2) * t2 - CL(C_d3) * t3 - CL(C_d4) * t4;
     // sin(mm), mm = xmdf + th, and (sin,cos)(argpm), argpm = argpdf - th: one (p,q) pair serves both
     double smm, sw = st.sW, cw = st.cW;
     if (!az_any(fabs(th) > AZ_ROT_SMALL)) {
@@ -210,11 +228,11 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const AzGrav &g, double t, bool f
         smm = sm;
         az_rotate(sw, cw, -th);
     }
-    const double tempe = fma(e.bc5, smm - e.sinmao, e.bc4 * t);
-    const double templ = fma(e.t2cof, t2, fma(e.t3cof, t3, t4 * fma(t, e.t5cof, e.t4cof)));
+    const double tempe = fma(CL(C_bc5), smm - CL(C_sinmao), CL(C_bc4) * t);
+    const double templ = fma(CL(C_t2cof), t2, fma(CL(C_t3cof), t3, t4 * fma(t, CL(C_t5cof), CL(C_t4cof))));
 
-    const double am = e.a_base * tempa * tempa;
-    const double em = fmax(e.ecco - tempe, 1.0e-6);
+    const double am = CL(C_a_base) * tempa * tempa;
+    const double em = fmax(CL(C_ecco) - tempe, 1.0e-6);
     const double ra = az_rsqrt(am);
     const double temp = ra * ra * az_rcp(fma(-em, em, 1.0));
 
@@ -223,10 +241,11 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const AzGrav &g, double t, bool f
     // u0 = mm + argpm + temp*xlcof*axnl = xmdf + argpdf + no*templ + temp*xlcof*axnl
     double su0, cu0;
     az_angle_add(sA, cA, st.sW, st.cW, su0, cu0);
-    az_rotate_le_small(su0, cu0, fma(e.no_unkozai, templ, temp * e.xlcof * axnl));
+    az_rotate_le_small(su0, cu0, fma(CL(C_no_unkozai), templ, temp * e.xlcof * axnl));
 
     const J2Factors k = {e.k_mrt, e.k_c2u, e.k_su, e.k_node, e.k_inc, e.x1mth2, e.k_rv};
     az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, st.sO, st.cO, e.sinio, e.cosio, k, r, v);
+#undef CL
 }
 
 // ------------------------------------------------------------------------------------------

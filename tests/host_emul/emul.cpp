@@ -6,6 +6,7 @@
 // wave votes degenerate to the lane's own predicate.  Never built into or loaded by the product.
 #define AZ_HOST_EMUL 1
 #define AZ_DEVICE static inline
+#define AZ_COLD_STRIDE 1
 #include <cstddef>
 #include <cstring>
 #include "../../astroz_amd/csrc/init_device.h"
@@ -41,12 +42,12 @@ void emul_propagate(const double* fields, unsigned flags, const double* grav6, c
             rc_out[i] = rc;
         }
     } else {
-        Sgp4Lane e; Sgp4Carry st;
-        az_load_sgp4(fields, 1, 0, flags, e);
+        Sgp4Lane e; Sgp4Carry st; double cold[C_NUM];
+        az_load_sgp4(fields, 1, 0, flags, e, cold);
         st.t_prev = 0; st.sW = st.cW = st.sO = st.cO = st.sA = st.cA = 0;
         for (int i = 0; i < n; ++i) {
             double r[3], v[3];
-            az_sgp4_step<true>(e, g, ts[i], (i == 0) || !incremental, st, r, v);
+            az_sgp4_step<true>(e, cold, fields, 1, 0, g, ts[i], (i == 0) || !incremental, st, r, v);
             memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
             rc_out[i] = 0;
         }

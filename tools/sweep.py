@@ -4,7 +4,7 @@ cross-compiles); `run` (on the GPU box) benches each variant x time-tile and pri
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VAR = os.path.join(ROOT, "tools", "variants")
-VARIANTS = {"b256w2": (256, 2, 0), "nostore": (256, 2, 1), "nocompute": (256, 2, 2)}
+VARIANTS = {"nt": (256, 1, 0), "nt_nocompute": (256, 1, 2)}
 
 def build():
     os.makedirs(VAR, exist_ok=True)
@@ -24,7 +24,7 @@ def build():
 
 def run(extra):
     rows = []
-    tiles = [0, 16]
+    tiles = [0]
     for name in VARIANTS:
         lib = os.path.join(VAR, "lib_%s.so" % name)
         if not os.path.exists(lib): continue
