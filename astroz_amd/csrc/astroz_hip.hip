@@ -96,7 +96,9 @@ struct azh_constellation {
     DevBuf<unsigned> d_list; // [near-earth | deep (by irez) | bad]
     unsigned n_sgp4 = 0, n_sdp4 = 0, n_bad = 0;
     // per-call scratch
-    DevBuf<double> d_times, d_offsets, d_sin, d_cos;
+    DevBuf<double> d_times, d_offsets, d_sin, d_cos, d_seeds;
+    bool seeds_valid = false; // resonance seeds match the staged times/offsets and tile
+    unsigned seeds_tile = 0;
     DevBuf<unsigned char> d_mask;
     bool have_offsets = false, have_mask = false;
     unsigned cached_n_times = 0;
@@ -122,6 +124,7 @@ void destroy(azh_constellation *c)
     c->d_offsets.release();
     c->d_sin.release();
     c->d_cos.release();
+    c->d_seeds.release();
     c->d_mask.release();
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -207,10 +210,22 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
                 return AZ_FLAG_ECLASS(c->h_flags[x]) < AZ_FLAG_ECLASS(c->h_flags[y]);
             });
         }
-        for (unsigned cls = 0; cls < 3; ++cls)
+        {
+            // deep space: order by (resonance class, near-equatorial [Lyddane branch], eccentricity
+            // class) so that the integrator branch, the Lyddane branch and the number of Kepler-Newton
+            // trips are as uniform as possible inside each wave
+            std::vector<unsigned> deep;
             for (size_t s = 0; s < n; ++s)
-                if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && (c->h_flags[s] & AZ_FLAG_DEEP) && AZ_FLAG_IREZ(c->h_flags[s]) == cls)
-                    list.push_back((unsigned)s);
+                if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && (c->h_flags[s] & AZ_FLAG_DEEP)) deep.push_back((unsigned)s);
+            const std::vector<double> &incl = cols[R_incl_deg];
+            auto key = [&](unsigned s) {
+                const unsigned f = c->h_flags[s];
+                const unsigned low = incl[s] < 12.5 ? 1u : 0u; // 0.2 rad = 11.46 deg, with margin for the periodics
+                return (AZ_FLAG_IREZ(f) << 4) | (low << 2) | AZ_FLAG_ECLASS(f);
+            };
+            std::stable_sort(deep.begin(), deep.end(), [&](unsigned x, unsigned y) { return key(x) < key(y); });
+            list.insert(list.end(), deep.begin(), deep.end());
+        }
         c->n_sdp4 = (unsigned)list.size() - c->n_sgp4;
         for (size_t s = 0; s < n; ++s)
             if (AZ_FLAG_ERR(c->h_flags[s]) != 0) list.push_back((unsigned)s);
@@ -316,6 +331,7 @@ int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, 
     }
     c->cached_n_times = (unsigned)n_times;
     c->cached_mode = mode;
+    c->seeds_valid = false; // new time grid / offsets
     return AZ_OK;
 }
 
@@ -356,6 +372,18 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         d.list = c->d_list.p + c->n_sgp4;
         d.n_list = c->n_sdp4;
         d.tile = auto_tile(c->n_sdp4, n_times, c->tile_sdp4, 8);
+        // resonance state at every tile start: computed once per (time grid, offsets, tile) and kept
+        // in the handle, like the reference keeps its carries (src/Constellation.zig L88, L294)
+        const unsigned n_tiles = (n_times + d.tile - 1) / d.tile;
+        if (!c->seeds_valid || c->seeds_tile != d.tile) {
+            if (c->d_seeds.ensure((size_t)n_tiles * 3 * c->n_sdp4) != AZ_OK) return AZ_ERR_HIP;
+            hipLaunchKernelGGL(k_deep_seed, dim3((c->n_sdp4 + 63) / 64), dim3(64), 0, c->s_deep, c->d_el, c->d_flags,
+                               c->n_pad, d.list, c->n_sdp4, d.times, n_times, d.offsets, d.tile, c->d_seeds.p);
+            HIP_TRY(hipGetLastError());
+            c->seeds_valid = true;
+            c->seeds_tile = d.tile;
+        }
+        d.seeds = c->d_seeds.p;
         launch_propagate(d, layout, d_vel != nullptr, true, c->s_deep);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_join, c->s_deep));

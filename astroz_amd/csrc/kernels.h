@@ -23,6 +23,9 @@
 #ifndef AZ_MIN_WAVES
 #define AZ_MIN_WAVES 1 /* __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow */
 #endif
+#ifndef AZ_DEEP_WAVES
+#define AZ_DEEP_WAVES 2
+#endif
 #define AZ_RESEED 256 /* re-seed carried (sin,cos) pairs with a full sincos every 256 steps */
 #define AZ_SM_CHUNK 4 /* time steps staged in LDS per flush in the satellite-major store path */
 
@@ -41,6 +44,7 @@ struct PropArgs {
     unsigned char *err;          // n_sats x n_times, may be null (pre-zeroed)
     size_t stride_sats;          // time-major row length
     unsigned tile;               // time steps per workgroup
+    const double *seeds;         // deep space: resonance state at each tile start, [tile][3][n_list]; may be null
     int mode;
     AzGrav g;
 };
@@ -102,11 +106,13 @@ __device__ __forceinline__ void az_wave_lds_fence()
 // FRAME = false: TEME output, no epilogue code at all (keeps its registers and SGPRs out of the
 // hot kernel); FRAME = true: ECEF / geodetic chosen at run time by p.mode.
 template <int LAYOUT, bool VEL, bool DEEP, bool FRAME>
-__global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : ((DEEP || FRAME) ? 1 : 2))) k_propagate(PropArgs p)
+__global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (FRAME ? 1 : (DEEP ? AZ_DEEP_WAVES : 2)))) k_propagate(PropArgs p)
 {
     constexpr int WAVES = AZ_BLOCK / 64;
-    constexpr int SLICE = (LAYOUT == 1) ? AZ_TM_ROW : 64 * AZ_SM_ROW;
-    constexpr int COLD = DEEP ? 0 : C_NUM * 64; // near-earth once-per-step constants, one column per lane
+    // deep-space lists are never runs of consecutive rows: no time-major staging (LDS is needed for
+    // the 37 cold coefficients; 18.9 KB/wave lets two workgroups share a CU)
+    constexpr int SLICE = (LAYOUT == 1) ? (DEEP ? 0 : AZ_TM_ROW) : 64 * AZ_SM_ROW;
+    constexpr int COLD = (DEEP ? (int)D_NUM : (int)C_NUM) * 64; // once-per-step constants, one column per lane
     __shared__ __attribute__((aligned(16))) double lds[WAVES * ((VEL ? 2 : 1) * SLICE + COLD)];
 
     const unsigned lane = threadIdx.x & 63u;
@@ -131,19 +137,28 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
 
     // time-major fast path: this wave's 64 satellites are consecutive catalog rows
     const unsigned s_first = p.list[li0];
-    const bool dense = (LAYOUT == 1) && (li0 + 63 < p.n_list) && (p.list[min(li0 + 63, p.n_list - 1)] - s_first == 63u) &&
+    const bool dense = (LAYOUT == 1) && !DEEP && (li0 + 63 < p.n_list) && (p.list[min(li0 + 63, p.n_list - 1)] - s_first == 63u) &&
                        (p.mask == nullptr);
 
     Sgp4Lane e4;
     Sgp4Carry c4;
     Sdp4Lane e8;
-    Sdp4Res q8;
     Sdp4Carry c8;
     if (DEEP) {
-        az_load_sdp4(p.el, p.n_pad, s, fl, e8, q8);
-        c8.atime = 0.0;
-        c8.xli = e8.xlamo;
-        c8.xni = e8.no_unkozai;
+        az_load_sdp4(p.el, p.n_pad, s, fl, e8, cold);
+        if (p.seeds) {
+            // resonance state at this tile's first time, prepared once by k_deep_seed: a tile never
+            // re-integrates from epoch (a 300-day-old resonant element set would cost 600+ integrator
+            // steps per tile otherwise)
+            const double *sd = p.seeds + (size_t)blockIdx.y * 3 * p.n_list + (in_range ? li : p.n_list - 1);
+            c8.atime = sd[0];
+            c8.xli = sd[p.n_list];
+            c8.xni = sd[2 * (size_t)p.n_list];
+        } else {
+            c8.atime = 0.0;
+            c8.xli = e8.xlamo;
+            c8.xni = e8.no_unkozai;
+        }
     } else {
         az_load_sgp4(p.el, p.n_pad, s, fl, e4, cold);
         c4.t_prev = 0.0;
@@ -167,7 +182,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
         r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
 #else
         if (DEEP) {
-            rc = az_sdp4_step<VEL>(e8, q8, p.g, t, c8, r, v);
+            rc = az_sdp4_step<VEL>(e8, cold, p.g, t, c8, r, v);
         } else {
             const bool first = ((i - t0) % AZ_RESEED) == 0;
             az_sgp4_step<VEL>(e4, cold, p.el, p.n_pad, s, p.g, t, first, c4, r, v);
@@ -264,6 +279,41 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
     }
 }
 
+// Deep space: walk the resonance integrator ONCE per satellite through the tile start times and
+// record (atime, xli, xni) for every tile.  Lane = deep-space list slot; sequential in time like the
+// reference's carry (src/Constellation.zig L448-476), but only the integrator -- a few dozen
+// instructions per 720 minutes of elapsed time -- so the serial chain is short.
+__global__ void __launch_bounds__(64) k_deep_seed(const double *el, const unsigned *flags, size_t n_pad,
+                                                  const unsigned *list, unsigned n_list, const double *times,
+                                                  unsigned n_times, const double *offsets, unsigned tile,
+                                                  double *seeds)
+{
+    __shared__ double cold_lds[D_NUM * 64];
+    const unsigned li = blockIdx.x * 64 + threadIdx.x;
+    const bool in_range = li < n_list;
+    const unsigned s = list[in_range ? li : n_list - 1];
+    const unsigned fl = flags[s];
+    Sdp4Lane e;
+    double *cold = cold_lds + threadIdx.x;
+    az_load_sdp4(el, n_pad, s, fl, e, cold);
+    Sdp4Carry cy;
+    cy.atime = 0.0;
+    cy.xli = e.xlamo;
+    cy.xni = e.no_unkozai;
+    const double off = offsets ? offsets[s] : 0.0;
+    const unsigned n_tiles = (n_times + tile - 1) / tile;
+    for (unsigned k = 0; k < n_tiles; ++k) {
+        const double t = times[k * tile] + off;
+        if (az_any(e.irez != 0)) az_resonance_advance(e, cold, t, cy);
+        if (in_range) {
+            double *sd = seeds + (size_t)k * 3 * n_list + li;
+            sd[0] = cy.atime;
+            sd[n_list] = cy.xli;
+            sd[2 * (size_t)n_list] = cy.xni;
+        }
+    }
+}
+
 // one satellite x many times: lane = time, the satellite's constants are wave-uniform.  Every
 // evaluation is a 'first' step (full sincos seeds); deep-space lanes integrate the resonance from
 // epoch themselves, like the reference's sdp4Times8 (src/Sdp4.zig L1105-1128).
@@ -280,13 +330,14 @@ __global__ void __launch_bounds__(64) k_one_satellite(const double *el, const un
     if (rc == 0) {
         if (fl & AZ_FLAG_DEEP) {
             Sdp4Lane e;
-            Sdp4Res q;
             Sdp4Carry c;
-            az_load_sdp4(el, n_pad, sat, fl, e, q);
+            __shared__ double cold_deep[D_NUM * 64];
+            double *cold = cold_deep + threadIdx.x;
+            az_load_sdp4(el, n_pad, sat, fl, e, cold);
             c.atime = 0.0;
             c.xli = e.xlamo;
             c.xni = e.no_unkozai;
-            rc = az_sdp4_step<true>(e, q, g, t, c, r, v);
+            rc = az_sdp4_step<true>(e, cold, g, t, c, r, v);
         } else {
             Sgp4Lane e;
             Sgp4Carry c;

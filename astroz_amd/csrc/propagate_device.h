@@ -250,44 +250,46 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const double *cold, const double 
 
 // ------------------------------------------------------------------------------------------
 // deep space
+// Deep-space constants of one satellite, split like the near-earth ones:
+//   Sdp4Lane -- secular rates, epoch angles, resonance start values: VGPR resident (25 doubles)
+//   cold[]   -- the 24 lunar/solar periodic coefficients (one use per step in dpper) and the 13
+//               resonance coefficients (one use per integrator evaluation): LDS, one column per lane
 struct Sdp4Lane {
     double mo, mdot, argpo, argpdot, nodeo, nodedot, xnodcf;
-    double cc1, bc4, t2cof, ecco, inclo, no_unkozai;
-    double se2, se3, si2, si3, sl2, sl3, sl4, sgh2, sgh3, sgh4, sh2, sh3;
-    double ee2, e3, xi2, xi3, xl2, xl3, xl4, xgh2, xgh3, xgh4, xh2, xh3;
+    double cc1, bc4, t2cof, ecco, inclo, no_unkozai, a_base;
     double zmol, zmos, dedt, didt, dmdt, domdt, dnodt;
     double xlamo, xfact, gsto;
     int irez;
 };
-// resonance coefficients live in their own struct so non-resonant waves never load them
-struct Sdp4Res {
-    double d2201, d2211, d3210, d3222, d4410, d4422, d5220, d5232, d5421, d5433;
-    double del1, del2, del3;
+enum Sdp4Cold {
+    D_se2, D_se3, D_si2, D_si3, D_sl2, D_sl3, D_sl4, D_sgh2, D_sgh3, D_sgh4, D_sh2, D_sh3,
+    D_ee2, D_e3, D_xi2, D_xi3, D_xl2, D_xl3, D_xl4, D_xgh2, D_xgh3, D_xgh4, D_xh2, D_xh3,
+    D_d2201, D_d2211, D_d3210, D_d3222, D_d4410, D_d4422, D_d5220, D_d5232, D_d5421, D_d5433,
+    D_del1, D_del2, D_del3,
+    D_NUM
 };
 struct Sdp4Carry {
     double atime, xli, xni;
 };
 
 AZ_DEVICE void az_load_sdp4(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags,
-                            Sdp4Lane &e, Sdp4Res &q)
+                            Sdp4Lane &e, double *cold)
 {
 #define L(f) el[(size_t)F_##f * n_pad + i]
+#define CS(f) cold[D_##f * AZ_COLD_STRIDE] = L(f)
     e.mo = L(mo); e.mdot = L(mdot); e.argpo = L(argpo); e.argpdot = L(argpdot);
     e.nodeo = L(nodeo); e.nodedot = L(nodedot); e.xnodcf = L(xnodcf);
     e.cc1 = L(cc1); e.bc4 = L(bc4); e.t2cof = L(t2cof); e.ecco = L(ecco); e.inclo = L(inclo);
-    e.no_unkozai = L(no_unkozai);
-    e.se2 = L(se2); e.se3 = L(se3); e.si2 = L(si2); e.si3 = L(si3); e.sl2 = L(sl2); e.sl3 = L(sl3);
-    e.sl4 = L(sl4); e.sgh2 = L(sgh2); e.sgh3 = L(sgh3); e.sgh4 = L(sgh4); e.sh2 = L(sh2); e.sh3 = L(sh3);
-    e.ee2 = L(ee2); e.e3 = L(e3); e.xi2 = L(xi2); e.xi3 = L(xi3); e.xl2 = L(xl2); e.xl3 = L(xl3);
-    e.xl4 = L(xl4); e.xgh2 = L(xgh2); e.xgh3 = L(xgh3); e.xgh4 = L(xgh4); e.xh2 = L(xh2); e.xh3 = L(xh3);
+    e.no_unkozai = L(no_unkozai); e.a_base = L(a_base);
     e.zmol = L(zmol); e.zmos = L(zmos); e.dedt = L(dedt); e.didt = L(didt); e.dmdt = L(dmdt);
     e.domdt = L(domdt); e.dnodt = L(dnodt);
     e.xlamo = L(xlamo); e.xfact = L(xfact); e.gsto = L(gsto);
     e.irez = (int)AZ_FLAG_IREZ(flags);
-    q.d2201 = L(d2201); q.d2211 = L(d2211); q.d3210 = L(d3210); q.d3222 = L(d3222);
-    q.d4410 = L(d4410); q.d4422 = L(d4422); q.d5220 = L(d5220); q.d5232 = L(d5232);
-    q.d5421 = L(d5421); q.d5433 = L(d5433);
-    q.del1 = L(del1); q.del2 = L(del2); q.del3 = L(del3);
+    CS(se2); CS(se3); CS(si2); CS(si3); CS(sl2); CS(sl3); CS(sl4); CS(sgh2); CS(sgh3); CS(sgh4); CS(sh2); CS(sh3);
+    CS(ee2); CS(e3); CS(xi2); CS(xi3); CS(xl2); CS(xl3); CS(xl4); CS(xgh2); CS(xgh3); CS(xgh4); CS(xh2); CS(xh3);
+    CS(d2201); CS(d2211); CS(d3210); CS(d3222); CS(d4410); CS(d4422); CS(d5220); CS(d5232); CS(d5421); CS(d5433);
+    CS(del1); CS(del2); CS(del3);
+#undef CS
 #undef L
 }
 
@@ -309,10 +311,11 @@ AZ_DEVICE void az_load_sdp4(const double *__restrict__ el, size_t n_pad, size_t 
 #define AZ_STEP2 259200.0
 
 // resonance accelerations (Sdp4.computeResonanceAccel, src/Sdp4.zig L824-866).  Unlike the
-// reference batch kernel (Sdp4Batch.zig L347-425: both branches for every lane) the half-day
-// branch is only entered by waves that hold a half-day satellite; the host orders the deep-space
-// index list by resonance class so that waves are uniform.
-AZ_DEVICE void az_resonance_accel(const Sdp4Lane &e, const Sdp4Res &q, double xli, double xni,
+// reference batch kernel (Sdp4Batch.zig L347-425: both branches for every lane) each branch is
+// only entered by waves that hold such a satellite; the host orders the deep-space index list by
+// resonance class so that waves are uniform.
+#define DL(f) cold[D_##f * AZ_COLD_STRIDE]
+AZ_DEVICE void az_resonance_accel(const Sdp4Lane &e, const double *cold, double xli, double xni,
                                   double atime, double &xndt, double &xnddt, double &xldot)
 {
     xldot = xni + e.xfact;
@@ -320,22 +323,30 @@ AZ_DEVICE void az_resonance_accel(const Sdp4Lane &e, const Sdp4Res &q, double xl
     if (az_any(e.irez == 2)) {
         const double xomi = fma(e.argpdot, atime, e.argpo);
         const double x2omi = xomi + xomi, x2li = xli + xli;
-        double s1, c1, s2, c2, s3, c3, s4, c4, s5, c5, s6, c6, s7, c7, s8, c8, s9, c9, s10, c10;
-        az_sincos(x2omi + xli - AZ_G22, s1, c1);
-        az_sincos(xli - AZ_G22, s2, c2);
-        az_sincos(xomi + xli - AZ_G32, s3, c3);
-        az_sincos(-xomi + xli - AZ_G32, s4, c4);
-        az_sincos(x2omi + x2li - AZ_G44, s5, c5);
-        az_sincos(x2li - AZ_G44, s6, c6);
-        az_sincos(xomi + xli - AZ_G52, s7, c7);
-        az_sincos(-xomi + xli - AZ_G52, s8, c8);
-        az_sincos(xomi + x2li - AZ_G54, s9, c9);
-        az_sincos(-xomi + x2li - AZ_G54, s10, c10);
-        xndt_h = q.d2201 * s1 + q.d2211 * s2 + q.d3210 * s3 + q.d3222 * s4 + q.d4410 * s5 +
-                 q.d4422 * s6 + q.d5220 * s7 + q.d5232 * s8 + q.d5421 * s9 + q.d5433 * s10;
-        xnddt_h = (q.d2201 * c1 + q.d2211 * c2 + q.d3210 * c3 + q.d3222 * c4 + q.d5220 * c7 +
-                   q.d5232 * c8 + 2.0 * (q.d4410 * c5 + q.d4422 * c6 + q.d5421 * c9 + q.d5433 * c10)) *
-                  xldot;
+        // ten phases, accumulated one at a time (short live ranges: the kernel is register-bound)
+        double sn, cs, acc_s = 0.0, acc_c = 0.0, acc_c2 = 0.0;
+        az_sincos(x2omi + xli - AZ_G22, sn, cs);
+        acc_s = DL(d2201) * sn; acc_c = DL(d2201) * cs;
+        az_sincos(xli - AZ_G22, sn, cs);
+        acc_s = fma(DL(d2211), sn, acc_s); acc_c = fma(DL(d2211), cs, acc_c);
+        az_sincos(xomi + xli - AZ_G32, sn, cs);
+        acc_s = fma(DL(d3210), sn, acc_s); acc_c = fma(DL(d3210), cs, acc_c);
+        az_sincos(-xomi + xli - AZ_G32, sn, cs);
+        acc_s = fma(DL(d3222), sn, acc_s); acc_c = fma(DL(d3222), cs, acc_c);
+        az_sincos(xomi + xli - AZ_G52, sn, cs);
+        acc_s = fma(DL(d5220), sn, acc_s); acc_c = fma(DL(d5220), cs, acc_c);
+        az_sincos(-xomi + xli - AZ_G52, sn, cs);
+        acc_s = fma(DL(d5232), sn, acc_s); acc_c = fma(DL(d5232), cs, acc_c);
+        az_sincos(x2omi + x2li - AZ_G44, sn, cs);
+        acc_s = fma(DL(d4410), sn, acc_s); acc_c2 = DL(d4410) * cs;
+        az_sincos(x2li - AZ_G44, sn, cs);
+        acc_s = fma(DL(d4422), sn, acc_s); acc_c2 = fma(DL(d4422), cs, acc_c2);
+        az_sincos(xomi + x2li - AZ_G54, sn, cs);
+        acc_s = fma(DL(d5421), sn, acc_s); acc_c2 = fma(DL(d5421), cs, acc_c2);
+        az_sincos(-xomi + x2li - AZ_G54, sn, cs);
+        acc_s = fma(DL(d5433), sn, acc_s); acc_c2 = fma(DL(d5433), cs, acc_c2);
+        xndt_h = acc_s;
+        xnddt_h = fma(2.0, acc_c2, acc_c) * xldot;
     }
     double xndt_g = 0.0, xnddt_g = 0.0;
     if (az_any(e.irez == 1)) {
@@ -344,17 +355,42 @@ AZ_DEVICE void az_resonance_accel(const Sdp4Lane &e, const Sdp4Res &q, double xl
         az_sincos(xli - AZ_FASX2, s1, c1);
         az_sincos(2.0 * (xli - AZ_FASX4), s2, c2);
         az_sincos(3.0 * (xli - AZ_FASX6), s3, c3);
-        xndt_g = q.del1 * s1 + q.del2 * s2 + q.del3 * s3;
-        xnddt_g = (q.del1 * c1 + 2.0 * q.del2 * c2 + 3.0 * q.del3 * c3) * xldot;
+        const double del1 = DL(del1), del2 = DL(del2), del3 = DL(del3);
+        xndt_g = del1 * s1 + del2 * s2 + del3 * s3;
+        xnddt_g = (del1 * c1 + 2.0 * del2 * c2 + 3.0 * del3 * c3) * xldot;
     }
     xndt = (e.irez == 2) ? xndt_h : xndt_g;
     xnddt = (e.irez == 2) ? xnddt_h : xnddt_g;
 }
 
+// Advance the resonance state (atime, xli, xni) to the last 720-minute boundary before t, with the
+// reference's restart rule (src/Sdp4.zig L786-801, src/Sdp4Batch.zig L241-267).  The state reached
+// after k steps of +-720 min is a pure function of k, so carrying it, restarting from epoch, or
+// loading it from the per-tile seed table (k_deep_seed) are all equivalent.
+AZ_DEVICE void az_resonance_advance(const Sdp4Lane &e, const double *cold, double t, Sdp4Carry &cy)
+{
+    const bool res = e.irez != 0;
+    if (res && (cy.atime == 0.0 || t * cy.atime <= 0.0 || fabs(t) < fabs(cy.atime))) {
+        cy.atime = 0.0;
+        cy.xni = e.no_unkozai;
+        cy.xli = e.xlamo;
+    }
+    const double delt = (t > 0.0) ? AZ_STEPP : -AZ_STEPP;
+    while (az_any(res && fabs(t - cy.atime) >= AZ_STEPP)) {
+        double xndt, xnddt, xldot;
+        az_resonance_accel(e, cold, cy.xli, cy.xni, cy.atime, xndt, xnddt, xldot);
+        if (res && fabs(t - cy.atime) >= AZ_STEPP) {
+            cy.xli += xldot * delt + xndt * AZ_STEP2;
+            cy.xni += xndt * delt + xnddt * AZ_STEP2;
+            cy.atime += delt;
+        }
+    }
+}
+
 // one deep-space propagation; returns 0 / 1 (eccentricity) / 6 (decayed) per the scalar
 // reference path (src/Sdp4.zig L914-921, L937-938, L967).
 template <bool VEL>
-AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const Sdp4Res &q, const AzGrav &g, double t, Sdp4Carry &cy,
+AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const double *cold, const AzGrav &g, double t, Sdp4Carry &cy,
                            double r[3], double v[3])
 {
     const double t2 = t * t;
@@ -370,49 +406,44 @@ AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const Sdp4Res &q, const AzGrav &g,
     double nm = e.no_unkozai;
     int rc = 0;
 
-    // resonance integrator (dspace, src/Sdp4.zig L784-819): the state reached after k steps of
-    // +-720 min is a pure function of k, so carrying it and restarting from epoch are equivalent.
+    // resonance integrator (dspace, src/Sdp4.zig L784-819)
+    double a23 = e.a_base; // (xke/nm)^(2/3)
     if (az_any(e.irez != 0)) {
         const bool res = e.irez != 0;
-        if (res && (cy.atime == 0.0 || t * cy.atime <= 0.0 || fabs(t) < fabs(cy.atime))) {
-            cy.atime = 0.0;
-            cy.xni = e.no_unkozai;
-            cy.xli = e.xlamo;
-        }
-        const double delt = (t > 0.0) ? AZ_STEPP : -AZ_STEPP;
+        az_resonance_advance(e, cold, t, cy);
         double xndt, xnddt, xldot;
-        while (az_any(res && fabs(t - cy.atime) >= AZ_STEPP)) {
-            az_resonance_accel(e, q, cy.xli, cy.xni, cy.atime, xndt, xnddt, xldot);
-            if (res && fabs(t - cy.atime) >= AZ_STEPP) {
-                cy.xli += xldot * delt + xndt * AZ_STEP2;
-                cy.xni += xndt * delt + xnddt * AZ_STEP2;
-                cy.atime += delt;
-            }
-        }
-        az_resonance_accel(e, q, cy.xli, cy.xni, cy.atime, xndt, xnddt, xldot);
+        az_resonance_accel(e, cold, cy.xli, cy.xni, cy.atime, xndt, xnddt, xldot);
         if (res) {
             const double ft = t - cy.atime;
             nm = cy.xni + xndt * ft + xnddt * ft * ft * 0.5;
             const double xl = cy.xli + xldot * ft + xndt * ft * ft * 0.5;
-            const double theta = az_mod2pi(fma(t, AZ_RPTIM, e.gsto));
+            const double theta = fma(t, AZ_RPTIM, e.gsto); // only ever used through sin/cos: no modulo
             mm = (e.irez != 2) ? xl - nodem - argpm + theta : xl - 2.0 * nodem + 2.0 * theta;
             nm = e.no_unkozai + (nm - e.no_unkozai);
         }
+        if (nm <= 0.0) { rc = 6; nm = e.no_unkozai; }
+        // (xke/nm)^(2/3) = a_base (1+x)^(-2/3), x = nm/no - 1 (|x| ~ 1e-5 for real resonant orbits):
+        // binomial series to x^5 (next term 0.4 x^6 < 3e-17 for |x| <= 2e-3), cbrt only beyond that
+        const double x = (nm - e.no_unkozai) * az_rcp(e.no_unkozai);
+        if (!az_any(fabs(x) > 2.0e-3)) {
+            double f = fma(x, -308.0 / 729.0, 110.0 / 243.0);
+            f = fma(x, f, -40.0 / 81.0);
+            f = fma(x, f, 5.0 / 9.0);
+            f = fma(x, f, -2.0 / 3.0);
+            a23 = e.a_base * fma(x, f, 1.0);
+        } else {
+            const double q = g.xke / nm;
+            a23 = cbrt(q * q);
+        }
     }
 
-    if (nm <= 0.0) { rc = 6; nm = e.no_unkozai; }
-    // am = (xke/nm)^(2/3) * tempa^2
-    const double am = cbrt((g.xke / nm) * (g.xke / nm)) * tempa * tempa;
+    const double am = a23 * tempa * tempa;
     em -= tempe;
     if (rc == 0 && (em >= 1.0 || em < -0.001)) rc = 1;
     if (em < 1.0e-6) em = 1.0e-6;
     if (rc == 0 && am < 0.95) rc = 6;
-
     mm += e.no_unkozai * templ;
-    const double xlm = mm + argpm + nodem;
-    nodem = az_mod2pi(nodem);
-    argpm = az_mod2pi(argpm);
-    mm = az_mod2pi(xlm - argpm - nodem);
+    // (no mod 2pi: the angles are only consumed by sin/cos, except inside the Lyddane branch)
 
     // lunar-solar periodics (dpper, src/Sdp4.zig L681-759)
     double sI, cI; // sin/cos of the perturbed inclination
@@ -420,23 +451,25 @@ AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const Sdp4Res &q, const AzGrav &g,
         double zm = fma(AZ_ZNS, t, e.zmos);
         double szm, czm, sinzf, coszf;
         az_sincos(zm, szm, czm);
-        az_sincos(fma(2.0 * AZ_ZES, szm, zm), sinzf, coszf);
+        sinzf = szm; coszf = czm;
+        az_rotate_med(sinzf, coszf, 2.0 * AZ_ZES * szm); // zf = zm + 2 zes sin zm  (|.| <= 0.0335)
         double f2 = fma(0.5 * sinzf, sinzf, -0.25), f3 = -0.5 * sinzf * coszf;
-        const double ses = e.se2 * f2 + e.se3 * f3;
-        const double sis = e.si2 * f2 + e.si3 * f3;
-        const double sls = e.sl2 * f2 + e.sl3 * f3 + e.sl4 * sinzf;
-        const double sghs = e.sgh2 * f2 + e.sgh3 * f3 + e.sgh4 * sinzf;
-        const double shs = e.sh2 * f2 + e.sh3 * f3;
+        const double ses = DL(se2) * f2 + DL(se3) * f3;
+        const double sis = DL(si2) * f2 + DL(si3) * f3;
+        const double sls = DL(sl2) * f2 + DL(sl3) * f3 + DL(sl4) * sinzf;
+        const double sghs = DL(sgh2) * f2 + DL(sgh3) * f3 + DL(sgh4) * sinzf;
+        const double shs = DL(sh2) * f2 + DL(sh3) * f3;
         zm = fma(AZ_ZNL, t, e.zmol);
         az_sincos(zm, szm, czm);
-        az_sincos(fma(2.0 * AZ_ZEL, szm, zm), sinzf, coszf);
+        sinzf = szm; coszf = czm;
+        az_rotate_med(sinzf, coszf, 2.0 * AZ_ZEL * szm); // |.| <= 0.1098
         f2 = fma(0.5 * sinzf, sinzf, -0.25);
         f3 = -0.5 * sinzf * coszf;
-        const double sel = e.ee2 * f2 + e.e3 * f3;
-        const double sil = e.xi2 * f2 + e.xi3 * f3;
-        const double sll = e.xl2 * f2 + e.xl3 * f3 + e.xl4 * sinzf;
-        const double sghl = e.xgh2 * f2 + e.xgh3 * f3 + e.xgh4 * sinzf;
-        const double shl = e.xh2 * f2 + e.xh3 * f3;
+        const double sel = DL(ee2) * f2 + DL(e3) * f3;
+        const double sil = DL(xi2) * f2 + DL(xi3) * f3;
+        const double sll = DL(xl2) * f2 + DL(xl3) * f3 + DL(xl4) * sinzf;
+        const double sghl = DL(xgh2) * f2 + DL(xgh3) * f3 + DL(xgh4) * sinzf;
+        const double shl = DL(xh2) * f2 + DL(xh3) * f3;
         const double pe = ses + sel, pinc = sis + sil, pl = sls + sll;
         double pgh = sghs + sghl, ph = shs + shl;
 
@@ -446,7 +479,8 @@ AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const Sdp4Res &q, const AzGrav &g,
         const double sinip = sI, cosip = cI;
         const bool lyd = inclm < 0.2;
         if (az_any(lyd)) {
-            // Lyddane modification for near-equatorial orbits (rare: own branch)
+            // Lyddane modification for near-equatorial orbits (own branch; the host groups such
+            // members so that most waves skip it)
             if (lyd) {
                 double sinop, cosop;
                 az_sincos(nodem, sinop, cosop);
@@ -504,6 +538,7 @@ AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const Sdp4Res &q, const AzGrav &g,
     if (rc == 0 && mrt < 1.0) rc = 6;
     return rc;
 }
+#undef DL
 
 // ------------------------------------------------------------------------------------------
 // output frames (Constellation.zig L54-56, L489-506; WorldCoordinateSystem.zig L98-121)
