@@ -5,6 +5,8 @@ download, benchmarks/sgp4_compat_test.py L79-97) and there is no network here, s
 and catalog-scale tests use a seeded generator that renders 69-column TLE text with valid
 checksums; the text is then parsed by the library's own parser like any other input.
 """
+import os
+
 import numpy as np
 
 START_JD = 2460800.5      # 2025-05-05 00:00 UTC
@@ -70,6 +72,8 @@ def near_earth_elements(n, seed=20260926, start_jd=START_JD):
     """Config-2 shell mix.  Returns dict of arrays (TLE units)."""
     rng = np.random.default_rng(seed)
     kind = rng.choice(6, size=n, p=[0.62, 0.05, 0.20, 0.08, 0.04, 0.01])
+    if os.environ.get("AZ_SYNTH_NO_ECC"):  # tuning experiment only: no eccentric members
+        kind[kind == 4] = 0
     incl = np.empty(n)
     alt = np.empty(n)
     ecc = np.exp(rng.uniform(np.log(1e-5), np.log(3e-3), n))

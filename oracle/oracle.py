@@ -136,16 +136,21 @@ class Catalog:
         return rc, np.array(r[:]), np.array(v[:])
 
     def propagate(self, times_min, offsets_min=None, *, velocities=True, mode=TEME,
-                  reference_jd=0.0, mask=None, layout=SAT_MAJOR, stride=0, threads=1):
-        """Returns (err (n_sats,n_times) u8, pos, vel-or-None); pos/vel shaped per layout."""
+                  reference_jd=0.0, mask=None, layout=SAT_MAJOR, stride=0, threads=1, out=None):
+        """Returns (err (n_sats,n_times) u8, pos, vel-or-None); pos/vel shaped per layout.
+        `out` = (err, pos, vel) from a previous call re-uses those buffers (timing loops)."""
         times = np.ascontiguousarray(times_min, dtype=np.float64)
         nt = len(times)
         ns = self.n
         st = stride or ns
         shape = (ns, nt, 3) if layout == SAT_MAJOR else (nt, st, 3)
-        pos = np.zeros(shape, dtype=np.float64)
-        vel = np.zeros(shape, dtype=np.float64) if velocities else None
-        err = np.zeros((ns, nt), dtype=np.uint8)
+        if out is not None:
+            err, pos, vel = out
+            assert pos.shape == shape and err.shape == (ns, nt)
+        else:
+            pos = np.zeros(shape, dtype=np.float64)
+            vel = np.zeros(shape, dtype=np.float64) if velocities else None
+            err = np.zeros((ns, nt), dtype=np.uint8)
         off = None if offsets_min is None else np.ascontiguousarray(offsets_min, dtype=np.float64)
         if off is not None:
             assert len(off) >= ns
