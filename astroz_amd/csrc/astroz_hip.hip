@@ -297,6 +297,24 @@ void launch_propagate2(const PropArgs &a, int layout, bool vel, hipStream_t st)
 void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStream_t st)
 {
     const bool frame = a.mode != AZ_OUT_TEME;
+    if (!deep && layout == AZ_LAYOUT_SAT_MAJOR && a.n_times >= 32) {
+        // satellite-major near-earth rows: one wave per satellite, lane = time (k_rows)
+        // time segments: enough waves for ~4 rounds of 4 waves/SIMD, segments of >= 256 grid points
+        PropArgs b = a;
+        unsigned segs = std::max(1u, std::min((16384u + a.n_list - 1) / a.n_list, (a.n_times + 255) / 256));
+        if (a.tile_forced) segs = std::max(1u, (a.n_times + a.tile_forced - 1) / a.tile_forced);
+        b.tile = ((a.n_times + segs - 1) / segs + 63) / 64 * 64;
+        dim3 grid(a.n_list, (a.n_times + b.tile - 1) / b.tile), block(64);
+        const PropArgs &a = b;
+        if (frame) {
+            if (vel) hipLaunchKernelGGL((k_rows<true, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_rows<false, true>), grid, block, 0, st, a);
+        } else {
+            if (vel) hipLaunchKernelGGL((k_rows<true, false>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_rows<false, false>), grid, block, 0, st, a);
+        }
+        return;
+    }
     if (deep) {
         if (frame) launch_propagate2<true, true>(a, layout, vel, st);
         else launch_propagate2<true, false>(a, layout, vel, st);
@@ -392,6 +410,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         a.list = c->d_list.p;
         a.n_list = c->n_sgp4;
         a.tile = auto_tile(c->n_sgp4, n_times, c->tile_sgp4, 8);
+        a.tile_forced = c->tile_sgp4;
         launch_propagate(a, layout, d_vel != nullptr, false, st);
         HIP_TRY(hipGetLastError());
     }

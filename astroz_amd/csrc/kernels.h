@@ -27,7 +27,9 @@
 #define AZ_DEEP_WAVES 2
 #endif
 #define AZ_RESEED 256 /* re-seed carried (sin,cos) pairs with a full sincos every 256 steps */
-#define AZ_SM_CHUNK 4 /* time steps staged in LDS per flush in the satellite-major store path */
+#ifndef AZ_SM_CHUNK
+#define AZ_SM_CHUNK 4 /* time steps staged in LDS per flush in the satellite-major store path; 0 = direct */
+#endif
 
 struct PropArgs {
     const double *el;
@@ -44,6 +46,7 @@ struct PropArgs {
     unsigned char *err;          // n_sats x n_times, may be null (pre-zeroed)
     size_t stride_sats;          // time-major row length
     unsigned tile;               // time steps per workgroup
+    unsigned tile_forced;        // user override (0 = automatic)
     const double *seeds;         // deep space: resonance state at each tile start, [tile][3][n_list]; may be null
     int mode;
     AzGrav g;
@@ -111,7 +114,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
     constexpr int WAVES = AZ_BLOCK / 64;
     // deep-space lists are never runs of consecutive rows: no time-major staging (LDS is needed for
     // the 37 cold coefficients; 18.9 KB/wave lets two workgroups share a CU)
-    constexpr int SLICE = (LAYOUT == 1) ? (DEEP ? 0 : AZ_TM_ROW) : 64 * AZ_SM_ROW;
+    constexpr int SLICE = (LAYOUT == 1) ? (DEEP ? 0 : AZ_TM_ROW) : (AZ_SM_CHUNK > 0 ? 64 * AZ_SM_ROW : 0);
     constexpr int COLD = (DEEP ? (int)D_NUM : (int)C_NUM) * 64; // once-per-step constants, one column per lane
     __shared__ __attribute__((aligned(16))) double lds[WAVES * ((VEL ? 2 : 1) * SLICE + COLD)];
 
@@ -121,6 +124,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
     double *lds_p = lds_w;
     double *lds_v = lds_w + SLICE;
     double *cold = lds_w + (VEL ? 2 : 1) * SLICE + lane;
+    ColdLds cold4{cold};
 
     const unsigned li0 = blockIdx.x * AZ_BLOCK + wave * 64; // first list slot of this wave
     if (li0 >= p.n_list) return;                            // whole wave beyond the list (AZ_BLOCK > 64 only)
@@ -160,7 +164,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
             c8.xni = e8.no_unkozai;
         }
     } else {
-        az_load_sgp4(p.el, p.n_pad, s, fl, e4, cold);
+        az_load_sgp4(p.el, p.n_pad, s, fl, e4, cold4);
         c4.t_prev = 0.0;
         c4.sW = c4.sO = c4.sA = 0.0;
         c4.cW = c4.cO = c4.cA = 1.0;
@@ -185,7 +189,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
             rc = az_sdp4_step<VEL>(e8, cold, p.g, t, c8, r, v);
         } else {
             const bool first = ((i - t0) % AZ_RESEED) == 0;
-            az_sgp4_step<VEL>(e4, cold, p.el, p.n_pad, s, p.g, t, first, c4, r, v);
+            az_sgp4_step<VEL>(e4, cold4, p.el, p.n_pad, s, p.g, t, first, c4, r, v);
         }
 #endif
         if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, i);
@@ -242,8 +246,24 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
                     AZ_ST1(p.vel + ob + 2, v[2]);
                 }
             }
+        } else if (AZ_SM_CHUNK == 0) {
+            // satellite-major, direct: every lane appends 24 B to its own row each step.  One store
+            // instruction touches 64 cache lines, but a lane's consecutive steps are adjacent in
+            // memory, so the pieces combine in L2 before they reach HBM -- and no LDS is spent on
+            // staging, which keeps the occupancy of the time-major kernel.
+            if (wr) {
+                const size_t ob = ((size_t)s * p.n_times + i) * 3;
+                AZ_ST1(p.pos + ob, r[0]);
+                AZ_ST1(p.pos + ob + 1, r[1]);
+                AZ_ST1(p.pos + ob + 2, r[2]);
+                if (VEL) {
+                    AZ_ST1(p.vel + ob, v[0]);
+                    AZ_ST1(p.vel + ob + 1, v[1]);
+                    AZ_ST1(p.vel + ob + 2, v[2]);
+                }
+            }
         } else {
-            const unsigned k = (i - t0) % AZ_SM_CHUNK;
+            const unsigned k = (i - t0) % (AZ_SM_CHUNK > 0 ? AZ_SM_CHUNK : 1);
             double *row = lds_p + lane * AZ_SM_ROW + k * 3;
             row[0] = r[0];
             row[1] = r[1];
@@ -341,8 +361,7 @@ __global__ void __launch_bounds__(64) k_one_satellite(const double *el, const un
         } else {
             Sgp4Lane e;
             Sgp4Carry c;
-            __shared__ double cold_lds[C_NUM * 64];
-            double *cold = cold_lds + threadIdx.x;
+            ColdRegs cold;
             az_load_sgp4(el, n_pad, sat, fl, e, cold);
             c.t_prev = 0.0;
             az_sgp4_step<true>(e, cold, el, n_pad, sat, g, t, true, c, r, v);
@@ -361,6 +380,74 @@ __global__ void __launch_bounds__(64) k_one_satellite(const double *el, const un
             if (vel) { vel[(size_t)i * 3] = v[0]; vel[(size_t)i * 3 + 1] = v[1]; vel[(size_t)i * 3 + 2] = v[2]; }
         }
         if (err) err[i] = (unsigned char)rc;
+    }
+}
+
+// Satellite-major output, near-earth: ONE WAVE PER SATELLITE ROW, lane = time.
+// The row (s, :, :) is contiguous in memory, so with lane = time a wave's 64 results of one
+// iteration are 1,536 contiguous bytes per array -- perfectly coalesced without any staging.  All
+// per-satellite constants are wave-uniform (forced into SGPRs with v_readfirstlane): no LDS, ~100
+// VGPRs less than the lane = satellite kernel, and the Kepler-Newton trip count and every rotation
+// tier are uniform by construction (one orbit per wave).  Each lane carries its own (sin,cos) pairs
+// of the slow angles across iterations (64 steps apart: small tier); only the mean anomaly, which
+// moves ~4.5 rad per 64 minutes, takes a full sincos.
+AZ_DEVICE double az_uniform(double x)
+{
+#ifdef AZ_HOST_EMUL
+    return x;
+#else
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(x)));
+#endif
+}
+struct ColdUniform {
+    double c[C_NUM_MAX];
+    __device__ __forceinline__ double operator()(int k) const { return c[k]; }
+    __device__ __forceinline__ void set(int k, double v) { c[k] = az_uniform(v); }
+};
+
+template <bool VEL, bool FRAME>
+__global__ void __launch_bounds__(64) k_rows(PropArgs p)
+{
+    const unsigned lane = threadIdx.x;
+    const unsigned s = p.list[blockIdx.x]; // wave-uniform
+    const unsigned fl = p.flags[s];
+    if (p.mask != nullptr && p.mask[s] == 0) return;
+    // blockIdx.y: time segment of p.tile grid points (a multiple of 64) -- splits long rows so that
+    // the grid has enough waves to fill the chip several times over
+    const unsigned t_lo = blockIdx.y * p.tile;
+    const unsigned t_hi = min(t_lo + p.tile, p.n_times);
+    Sgp4Lane e;
+    ColdUniform cold;
+    az_load_sgp4(p.el, p.n_pad, s, fl, e, cold);
+    e.mdot = az_uniform(e.mdot); e.argpdot = az_uniform(e.argpdot); e.nodedot = az_uniform(e.nodedot);
+    e.xnodcf = az_uniform(e.xnodcf); e.aycof = az_uniform(e.aycof); e.xlcof = az_uniform(e.xlcof);
+    e.sinio = az_uniform(e.sinio); e.cosio = az_uniform(e.cosio); e.k_mrt = az_uniform(e.k_mrt);
+    e.k_c2u = az_uniform(e.k_c2u); e.k_su = az_uniform(e.k_su); e.k_node = az_uniform(e.k_node);
+    e.k_inc = az_uniform(e.k_inc); e.x1mth2 = az_uniform(e.x1mth2); e.k_rv = az_uniform(e.k_rv);
+    const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
+    Sgp4Carry c;
+    c.t_prev = 0.0;
+    c.sW = c.sO = c.sA = 0.0;
+    c.cW = c.cO = c.cA = 1.0;
+    double *prow = p.pos + (size_t)s * p.n_times * 3;
+    double *vrow = VEL ? p.vel + (size_t)s * p.n_times * 3 : nullptr;
+#pragma unroll 1
+    for (unsigned base = t_lo; base < t_hi; base += 64) {
+        const unsigned i = base + lane;
+        const bool live = i < t_hi;
+        const double t = p.times[live ? i : t_hi - 1] + off;
+        double r[3], v[3];
+        az_sgp4_step<VEL, ColdUniform, true>(e, cold, p.el, p.n_pad, s, p.g, t, base == t_lo, c, r, v);
+        if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
+        if (live) {
+            double *o = prow + (size_t)i * 3;
+            o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
+            if (VEL) {
+                double *w = vrow + (size_t)i * 3;
+                w[0] = v[0]; w[1] = v[1]; w[2] = v[2];
+            }
+        }
     }
 }
 

@@ -36,6 +36,7 @@ enum Sgp4Cold {
 #ifndef AZ_COLD_STRIDE
 #define AZ_COLD_STRIDE 64
 #endif
+#define C_NUM_MAX 18
 
 // (sin,cos) pairs carried from one time step to the next
 struct Sgp4Carry {
@@ -57,11 +58,30 @@ AZ_DEVICE void az_j2_factors(double con41, double x1mth2, double x7thm1, double 
     k_rv = 1.5 * con41;       // rvdot = rvdotl + nx temp1 (x1mth2 cos2u + k_rv)
 }
 
+// where the once-per-step constants live: an LDS column (lane = satellite kernels) ...
+#ifdef AZ_HOST_EMUL
+#define AZ_MEMBER inline
+#else
+#define AZ_MEMBER __device__ __forceinline__
+#endif
+struct ColdLds {
+    double *p;
+    AZ_MEMBER double operator()(int k) const { return p[k * AZ_COLD_STRIDE]; }
+    AZ_MEMBER void set(int k, double v) const { p[k * AZ_COLD_STRIDE] = v; }
+};
+// ... or plain (wave-uniform) values when one wave works on a single satellite (lane = time kernels)
+struct ColdRegs {
+    double c[C_NUM_MAX];
+    AZ_MEMBER double operator()(int k) const { return c[k]; }
+    AZ_MEMBER void set(int k, double v) { c[k] = v; }
+};
+
+template <class Cold>
 AZ_DEVICE void az_load_sgp4(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags,
-                            Sgp4Lane &e, double *cold)
+                            Sgp4Lane &e, Cold &cold)
 {
 #define L(f) el[(size_t)F_##f * n_pad + i]
-#define CS(k, val) cold[(k) * AZ_COLD_STRIDE] = (val)
+#define CS(k, val) cold.set((k), (val))
     e.mdot = L(mdot); e.argpdot = L(argpdot); e.nodedot = L(nodedot); e.xnodcf = L(xnodcf);
     e.aycof = L(aycof); e.xlcof = L(xlcof); e.sinio = L(sinio); e.cosio = L(cosio);
     az_j2_factors(L(con41), L(x1mth2), L(x7thm1), e.sinio, e.cosio, e.k_mrt, e.k_c2u, e.k_su, e.k_node, e.k_inc,
@@ -175,12 +195,16 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
 // ------------------------------------------------------------------------------------------
 // one near-earth propagation.  `first` (wave-uniform) seeds the carried pairs with full sincos.
 // `el`/`n_pad`/`sat` locate the satellite's column of the element table for the re-seed loads.
-template <bool VEL>
-AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const double *cold, const double *__restrict__ el, size_t n_pad,
+// STRIDE64 = false: consecutive steps of one lane are consecutive grid times (lane = satellite);
+// STRIDE64 = true : a lane's consecutive steps are 64 grid times apart (lane = time, k_rows): the
+//                   mean anomaly moves by radians between them and is simply re-evaluated, the J2
+//                   angles still move by < 2^-7 rad and keep their carried pairs.
+template <bool VEL, class Cold, bool STRIDE64 = false>
+AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const Cold &cold, const double *__restrict__ el, size_t n_pad,
                             size_t sat, const AzGrav &g, double t, bool first, Sgp4Carry &st, double r[3],
                             double v[3])
 {
-#define CL(k) cold[(k) * AZ_COLD_STRIDE]
+#define CL(k) cold(k)
     const double t2 = t * t;
     // slowly drifting angles: advance the carried (sin,cos) pairs
     {
@@ -194,6 +218,10 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const double *cold, const double 
             az_sincos(fma(e.argpdot, t, argpo), st.sW, st.cW);
             az_sincos(fma(e.xnodcf, t2, fma(e.nodedot, t, nodeo)), st.sO, st.cO);
             az_sincos(fma(e.mdot, t, mo), st.sA, st.cA);
+        } else if (STRIDE64) {
+            az_rotate_le_small(st.sW, st.cW, dW);
+            az_rotate_le_small(st.sO, st.cO, dO);
+            az_sincos(fma(e.mdot, t, el[(size_t)F_mo * n_pad + sat]), st.sA, st.cA);
         } else if (!az_any(fmax(fabs(dW), fabs(dO)) > AZ_ROT_MILLI || fabs(dA) > AZ_ROT_MED)) {
             // a one-minute grid lands here: J2 rates are ~1e-4 rad/min, the mean motion < 0.08
             az_rotate_tiny(st.sW, st.cW, dW);

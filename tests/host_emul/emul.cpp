@@ -42,7 +42,7 @@ void emul_propagate(const double* fields, unsigned flags, const double* grav6, c
             rc_out[i] = rc;
         }
     } else {
-        Sgp4Lane e; Sgp4Carry st; double cold[C_NUM];
+        Sgp4Lane e; Sgp4Carry st; ColdRegs cold;
         az_load_sgp4(fields, 1, 0, flags, e, cold);
         st.t_prev = 0; st.sW = st.cW = st.sO = st.cO = st.sA = st.cA = 0;
         for (int i = 0; i < n; ++i) {
