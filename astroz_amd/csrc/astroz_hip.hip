@@ -106,6 +106,7 @@ struct azh_constellation {
     hipStream_t s_main = nullptr, s_deep = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     bool timed = false;
+    bool timing = true; // record the ev_t0/ev_t1 pair around every launch set (azh_set_timing)
     unsigned tile_sgp4 = 0, tile_sdp4 = 0;
 };
 
@@ -379,7 +380,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     a.mode = c->cached_mode;
     a.g = c->g;
 
-    HIP_TRY(hipEventRecord(c->ev_t0, st));
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
     if (d_err) HIP_TRY(hipMemsetAsync(d_err, 0, c->n * (size_t)n_times, st));
     const bool fork = c->n_sdp4 > 0;
     if (fork) {
@@ -421,8 +422,10 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         HIP_TRY(hipGetLastError());
     }
     if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
-    HIP_TRY(hipEventRecord(c->ev_t1, st));
-    c->timed = true;
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev_t1, st));
+        c->timed = true;
+    }
     return AZ_OK;
 }
 
@@ -528,6 +531,14 @@ int32_t azh_get_field(const azh_constellation *c, const char *name, double *out)
         }
     }
     return AZ_ERR_VALUE;
+}
+
+int32_t azh_set_timing(azh_constellation *c, int32_t enabled)
+{
+    if (!c) return AZ_ERR_NULL_POINTER;
+    c->timing = enabled != 0;
+    if (!c->timing) c->timed = false;
+    return AZ_OK;
 }
 
 int32_t azh_set_time_tile(azh_constellation *c, uint32_t sgp4_tile, uint32_t sdp4_tile)

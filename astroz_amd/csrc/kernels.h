@@ -430,6 +430,9 @@ __global__ void __launch_bounds__(64) k_rows(PropArgs p)
     c.t_prev = 0.0;
     c.sW = c.sO = c.sA = 0.0;
     c.cW = c.cO = c.cA = 1.0;
+    c.dt_c = -1.0e300;
+    c.sdA = c.pW = c.qW = 0.0;
+    c.cdA = 1.0;
     double *prow = p.pos + (size_t)s * p.n_times * 3;
     double *vrow = VEL ? p.vel + (size_t)s * p.n_times * 3 : nullptr;
 #pragma unroll 1
@@ -438,7 +441,9 @@ __global__ void __launch_bounds__(64) k_rows(PropArgs p)
         const bool live = i < t_hi;
         const double t = p.times[live ? i : t_hi - 1] + off;
         double r[3], v[3];
-        az_sgp4_step<VEL, ColdUniform, true>(e, cold, p.el, p.n_pad, s, p.g, t, base == t_lo, c, r, v);
+        // full re-seed of the carried pairs at the start and every 64 iterations (4,096 grid points)
+        const bool first = ((base - t_lo) & (64u * 64u - 1u)) == 0;
+        az_sgp4_step<VEL, ColdUniform, true>(e, cold, p.el, p.n_pad, s, p.g, t, first, c, r, v);
         if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
         if (live) {
             double *o = prow + (size_t)i * 3;

@@ -44,6 +44,10 @@ struct Sgp4Carry {
     double sW, cW; // argpo + argpdot*t
     double sO, cO; // nodeo + nodedot*t + xnodcf*t^2
     double sA, cA; // mo + mdot*t
+    // lane = time kernels only: a lane's successive steps are a constant dt apart on a uniform grid,
+    // so the rotation of the mean anomaly (radians per step) and of the argument of perigee are the
+    // SAME every step -- cached as (sin,cos)(mdot dt) and the (p,q) pair of argpdot dt
+    double dt_c, sdA, cdA, pW, qW;
 };
 
 // products of the inclination-dependent constants that the short-period step uses
@@ -219,9 +223,22 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const Cold &cold, const double *_
             az_sincos(fma(e.xnodcf, t2, fma(e.nodedot, t, nodeo)), st.sO, st.cO);
             az_sincos(fma(e.mdot, t, mo), st.sA, st.cA);
         } else if (STRIDE64) {
-            az_rotate_le_small(st.sW, st.cW, dW);
             az_rotate_le_small(st.sO, st.cO, dO);
-            az_sincos(fma(e.mdot, t, el[(size_t)F_mo * n_pad + sat]), st.sA, st.cA);
+            if (az_any(dt != st.dt_c || fabs(dW) > AZ_ROT_SMALL)) {
+                // (re)build the cached increments; also the path of any non-uniform grid
+                st.dt_c = (fabs(dW) > AZ_ROT_SMALL) ? -1.0e300 : dt;
+                az_sincos(dA, st.sdA, st.cdA);
+                const double d2 = dW * dW;
+                st.qW = d2 * fma(d2, fma(d2, -1.0 / 720.0, 1.0 / 24.0), -0.5);
+                st.pW = dW * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+                az_rotate(st.sW, st.cW, dW);
+                az_sincos(fma(e.mdot, t, el[(size_t)F_mo * n_pad + sat]), st.sA, st.cA);
+            } else {
+                az_rot_apply(st.sW, st.cW, st.pW, st.qW);
+                const double ns = fma(st.sA, st.cdA, st.cA * st.sdA);
+                st.cA = fma(st.cA, st.cdA, -(st.sA * st.sdA));
+                st.sA = ns;
+            }
         } else if (!az_any(fmax(fabs(dW), fabs(dO)) > AZ_ROT_MILLI || fabs(dA) > AZ_ROT_MED)) {
             // a one-minute grid lands here: J2 rates are ~1e-4 rad/min, the mean motion < 0.08
             az_rotate_tiny(st.sW, st.cW, dW);

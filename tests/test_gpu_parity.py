@@ -127,6 +127,26 @@ def test_mixed_catalog_vs_oracle(native, orc, synth, layout, velocities):
         assert np.abs(vel - v0).max() < TOL_V
 
 
+@pytest.mark.parametrize("layout", ["time_major", "sat_major"])
+def test_long_uniform_grid(native, orc, synth, layout):
+    """10,000 one-minute steps (a week): exercises the carried-rotation paths over many steps, the
+    periodic re-seeding, and -- satellite-major -- the cached constant rotations of the row kernel."""
+    pairs = synth.synth_catalog(n_near=90, n_deep=10, seed=77)
+    dev, cat = _dev_and_oracle(native, orc, pairs)
+    times = np.arange(10000, dtype=np.float64)
+    off = (synth.START_JD - dev.epochs) * 1440.0
+    lay = native.TIME_MAJOR if layout == "time_major" else native.SAT_MAJOR
+    shape = (len(times), dev.n, 3) if lay == native.TIME_MAJOR else (dev.n, len(times), 3)
+    pos = np.empty(shape)
+    vel = np.empty(shape)
+    err = np.zeros((dev.n, len(times)), dtype=np.uint8)
+    dev.propagate_host(times, off, pos=pos, vel=vel, layout=lay, err=err)
+    e0, p0, v0 = cat.propagate(times, off, layout=lay, threads=8)
+    assert np.array_equal(err, e0)
+    assert np.abs(pos - p0).max() < 5e-6      # |t| up to 1.7e4 min: ulp(mean anomaly) limits agreement
+    assert np.abs(vel - v0).max() < 5e-9
+
+
 def test_long_span_and_negative_times(native, orc, synth):
     """+-2 weeks, non-uniform and non-monotonic time grid (forces the full-sincos re-seed path and
     resonance-integrator restarts)."""

@@ -7,9 +7,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-BENCH="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline $BENCH_EXTRA"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
-PM="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+PM="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_EXTRA"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o pmc -- $PM > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_TRANS_F64 -d $OUT/pmc_sq2 -o pmc -- $PM > $OUT/pmc_sq2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $PM > $OUT/pmc_fetch.log 2>&1
@@ -30,5 +30,5 @@ for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_grbm"):
             agg[k][0] += float(row.get("Counter_Value", 0)); agg[k][1] += 1
         print("==", d)
         for (kn, cn), (v, n) in sorted(agg.items()):
-            if "k_propagate" in kn: print("%-60s %-28s sum=%.6g dispatches=%d per_dispatch=%.6g" % (kn, cn, v, n, v / max(n, 1)))
+            if "k_propagate" in kn or "k_rows" in kn: print("%-60s %-28s sum=%.6g dispatches=%d per_dispatch=%.6g" % (kn, cn, v, n, v / max(n, 1)))
 PY

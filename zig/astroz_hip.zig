@@ -37,4 +37,5 @@ pub extern "c" fn azh_propagate_jd_host(h: ?*Handle, jd: [*]const f64, fr: [*]co
 pub extern "c" fn azh_propagate_one_host(h: ?*Handle, sat_index: usize, tsince_min: [*]const f64, n: usize, pos: [*]f64, vel: ?[*]f64, err: ?[*]u8) i32;
 pub extern "c" fn azh_synchronize(h: ?*Handle) i32;
 pub extern "c" fn azh_set_time_tile(h: ?*Handle, sgp4_tile: u32, sdp4_tile: u32) i32;
+pub extern "c" fn azh_set_timing(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_last_kernel_ms(h: ?*Handle) f64;
