@@ -89,6 +89,32 @@ AZ_DEVICE void az_sincos(double x, double &s, double &c)
     c = ((k + 1) & 2) ? -cc : cc;
 }
 
+// ---------------------------------------------------------------- register-resident constants
+// v_fma_f64 accepts at most ONE scalar/literal source and no 64-bit literal at all, so a Horner
+// step fma(d2, C1, C2) with two fp64 constants costs an extra v_mov_b64 every time the compiler
+// re-materialises a constant instead of keeping it live.  The four Taylor coefficients of the two
+// rotation tiers on the hot path are therefore parked in VGPRs once per kernel; the empty asm makes
+// the value opaque so that it cannot be folded back into an immediate.
+AZ_DEVICE double az_opaque(double x)
+{
+#ifndef AZ_HOST_EMUL
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+struct RotK {
+    double n6, p24, p120, n720; // -1/6, 1/24, 1/120, -1/720
+};
+AZ_DEVICE RotK az_rotk()
+{
+    RotK k;
+    k.n6 = az_opaque(-1.0 / 6.0);
+    k.p24 = az_opaque(1.0 / 24.0);
+    k.p120 = az_opaque(1.0 / 120.0);
+    k.n720 = az_opaque(-1.0 / 720.0);
+    return k;
+}
+
 // ---------------------------------------------------------------- small rotations
 // (s,c) <- (sin,cos)(angle + d).  Written as s += (s*q + c*p), q = cos d - 1, p = sin d, so the
 // rounding error is that of one addition to s (c), not of a product.
@@ -118,20 +144,26 @@ AZ_DEVICE void az_rotate_med(double &s, double &c, double d)
     p = d * fma(d2, p, 1.0);
     az_rot_apply(s, c, p, q);
 }
-// |d| <= 2^-7
-AZ_DEVICE void az_rotate_small(double &s, double &c, double d)
+// (p,q) = (sin d, cos d - 1) of the 2^-7 tier
+AZ_DEVICE void az_pq_small(double d, const RotK &k, double &p, double &q)
 {
     const double d2 = d * d;
-    const double q = d2 * fma(d2, fma(d2, -1.0 / 720.0, 1.0 / 24.0), -0.5);
-    const double p = d * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+    q = d2 * fma(d2, fma(d2, k.n720, k.p24), -0.5);
+    p = d * fma(d2, fma(d2, k.p120, k.n6), 1.0);
+}
+// |d| <= 2^-7
+AZ_DEVICE void az_rotate_small(double &s, double &c, double d, const RotK &k)
+{
+    double p, q;
+    az_pq_small(d, k, p, q);
     az_rot_apply(s, c, p, q);
 }
 // |d| <= 2^-10
-AZ_DEVICE void az_rotate_tiny(double &s, double &c, double d)
+AZ_DEVICE void az_rotate_tiny(double &s, double &c, double d, const RotK &k)
 {
     const double d2 = d * d;
-    const double q = d2 * fma(d2, 1.0 / 24.0, -0.5);
-    const double p = d * fma(d2, -1.0 / 6.0, 1.0);
+    const double q = d2 * fma(d2, k.p24, -0.5);
+    const double p = d * fma(d2, k.n6, 1.0);
     az_rot_apply(s, c, p, q);
 }
 // sincos(d) + angle addition, any d
@@ -168,14 +200,14 @@ AZ_DEVICE void az_rotate_large(double &s, double &c, double d)
 }
 // any d: wave-uniform choice of the cheapest valid tier (up to four votes: use the az_rotate_le_*
 // forms below where the usual magnitude is known)
-AZ_DEVICE void az_rotate(double &s, double &c, double d)
+AZ_DEVICE void az_rotate(double &s, double &c, double d, const RotK &k)
 {
     const double ad = fabs(d);
     if (!az_any(ad > AZ_ROT_SMALL)) {
         if (!az_any(ad > AZ_ROT_MILLI))
-            az_rotate_tiny(s, c, d);
+            az_rotate_tiny(s, c, d, k);
         else
-            az_rotate_small(s, c, d);
+            az_rotate_small(s, c, d, k);
     } else if (!az_any(ad > AZ_ROT_MED)) {
         az_rotate_med(s, c, d);
     } else if (!az_any(ad > 0.5)) {
@@ -185,19 +217,19 @@ AZ_DEVICE void az_rotate(double &s, double &c, double d)
     }
 }
 // one vote for the expected tier, generic fallback otherwise
-AZ_DEVICE void az_rotate_le_tiny(double &s, double &c, double d)
+AZ_DEVICE void az_rotate_le_tiny(double &s, double &c, double d, const RotK &k)
 {
     if (!az_any(fabs(d) > AZ_ROT_MILLI))
-        az_rotate_tiny(s, c, d);
+        az_rotate_tiny(s, c, d, k);
     else
-        az_rotate(s, c, d);
+        az_rotate(s, c, d, k);
 }
-AZ_DEVICE void az_rotate_le_small(double &s, double &c, double d)
+AZ_DEVICE void az_rotate_le_small(double &s, double &c, double d, const RotK &k)
 {
     if (!az_any(fabs(d) > AZ_ROT_SMALL))
-        az_rotate_small(s, c, d);
+        az_rotate_small(s, c, d, k);
     else
-        az_rotate(s, c, d);
+        az_rotate(s, c, d, k);
 }
 // (s,c) of a+b from (sa,ca),(sb,cb)
 AZ_DEVICE void az_angle_add(double sa, double ca, double sb, double cb, double &s, double &c)

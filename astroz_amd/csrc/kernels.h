@@ -23,6 +23,9 @@
 #ifndef AZ_MIN_WAVES
 #define AZ_MIN_WAVES 1 /* __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow */
 #endif
+#ifndef AZ_ROWS_WAVES
+#define AZ_ROWS_WAVES 4
+#endif
 #ifndef AZ_DEEP_WAVES
 #define AZ_DEEP_WAVES 2
 #endif
@@ -109,7 +112,7 @@ __device__ __forceinline__ void az_wave_lds_fence()
 // FRAME = false: TEME output, no epilogue code at all (keeps its registers and SGPRs out of the
 // hot kernel); FRAME = true: ECEF / geodetic chosen at run time by p.mode.
 template <int LAYOUT, bool VEL, bool DEEP, bool FRAME>
-__global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (FRAME ? 1 : (DEEP ? AZ_DEEP_WAVES : 2)))) k_propagate(PropArgs p)
+__global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (FRAME ? 1 : (DEEP ? AZ_DEEP_WAVES : 3)))) k_propagate(PropArgs p)
 {
     constexpr int WAVES = AZ_BLOCK / 64;
     // deep-space lists are never runs of consecutive rows: no time-major staging (LDS is needed for
@@ -171,6 +174,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
     }
 
     double tcache = 0.0;
+    const RotK rk = az_rotk();
 #pragma unroll 1
     for (unsigned i = t0; i < t1; ++i) {
         // Time values: one coalesced 512-B vector load per 64 steps parks 64 of them in a VGPR (one
@@ -186,10 +190,10 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
         r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
 #else
         if (DEEP) {
-            rc = az_sdp4_step<VEL>(e8, cold, p.g, t, c8, r, v);
+            rc = az_sdp4_step<VEL>(e8, cold, p.g, rk, t, c8, r, v);
         } else {
             const bool first = ((i - t0) % AZ_RESEED) == 0;
-            az_sgp4_step<VEL>(e4, cold4, p.el, p.n_pad, s, p.g, t, first, c4, r, v);
+            az_sgp4_step<VEL>(e4, cold4, p.el, p.n_pad, s, p.g, rk, t, first, c4, r, v);
         }
 #endif
         if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, i);
@@ -357,14 +361,14 @@ __global__ void __launch_bounds__(64) k_one_satellite(const double *el, const un
             c.atime = 0.0;
             c.xli = e.xlamo;
             c.xni = e.no_unkozai;
-            rc = az_sdp4_step<true>(e, cold, g, t, c, r, v);
+            rc = az_sdp4_step<true>(e, cold, g, az_rotk(), t, c, r, v);
         } else {
             Sgp4Lane e;
             Sgp4Carry c;
             ColdRegs cold;
             az_load_sgp4(el, n_pad, sat, fl, e, cold);
             c.t_prev = 0.0;
-            az_sgp4_step<true>(e, cold, el, n_pad, sat, g, t, true, c, r, v);
+            az_sgp4_step<true>(e, cold, el, n_pad, sat, g, az_rotk(), t, true, c, r, v);
         }
     }
     if (rc != 0) {
@@ -407,7 +411,7 @@ struct ColdUniform {
 };
 
 template <bool VEL, bool FRAME>
-__global__ void __launch_bounds__(64) k_rows(PropArgs p)
+__global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
 {
     const unsigned lane = threadIdx.x;
     const unsigned s = p.list[blockIdx.x]; // wave-uniform
@@ -433,6 +437,7 @@ __global__ void __launch_bounds__(64) k_rows(PropArgs p)
     c.dt_c = -1.0e300;
     c.sdA = c.pW = c.qW = 0.0;
     c.cdA = 1.0;
+    const RotK rk = az_rotk();
     double *prow = p.pos + (size_t)s * p.n_times * 3;
     double *vrow = VEL ? p.vel + (size_t)s * p.n_times * 3 : nullptr;
 #pragma unroll 1
@@ -443,7 +448,7 @@ __global__ void __launch_bounds__(64) k_rows(PropArgs p)
         double r[3], v[3];
         // full re-seed of the carried pairs at the start and every 64 iterations (4,096 grid points)
         const bool first = ((base - t_lo) & (64u * 64u - 1u)) == 0;
-        az_sgp4_step<VEL, ColdUniform, true>(e, cold, p.el, p.n_pad, s, p.g, t, first, c, r, v);
+        az_sgp4_step<VEL, ColdUniform, true>(e, cold, p.el, p.n_pad, s, p.g, rk, t, first, c, r, v);
         if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
         if (live) {
             double *o = prow + (size_t)i * 3;

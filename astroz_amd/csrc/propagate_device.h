@@ -117,7 +117,7 @@ struct J2Factors {
 template <bool VEL>
 AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double axnl, double aynl,
                                   double su0, double cu0, double sO, double cO, double sI, double cI,
-                                  const J2Factors &k, double r[3], double v[3])
+                                  const J2Factors &k, const RotK &rk, double r[3], double v[3])
 {
     // Newton on  E - aynl*cosE + axnl*sinE = u  with eps = E - u carried instead of E.
     // Exit test: the step after d would be ~ (el/2) d^2, so stop once el2 * d^4 < (2e-13)^2.
@@ -131,9 +131,9 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
         d = fmin(fmax(d, -0.95), 0.95);
         eps += d;
         if (it == 0)
-            az_rotate_le_small(s, c, d);
+            az_rotate_le_small(s, c, d, rk);
         else
-            az_rotate_le_tiny(s, c, d);
+            az_rotate_le_tiny(s, c, d, rk);
         const double d2 = d * d;
         if (!az_any(el2 * d2 * d2 >= 4.0e-26)) break;
     }
@@ -162,13 +162,13 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
     double ssu = sinu, csu = cosu, sn = sO, cn = cO, si = sI, ci = cI;
     // the three corrections are bounded by 1.5*temp2 = 0.75 J2 / pl^2 (8e-4 for pl = 1): one vote
     if (!az_any(temp2 > 6.0e-4)) {
-        az_rotate_tiny(ssu, csu, k.k_su * t2s);
-        az_rotate_tiny(sn, cn, k.k_node * t2s);
-        az_rotate_tiny(si, ci, k.k_inc * temp2 * cos2u);
+        az_rotate_tiny(ssu, csu, k.k_su * t2s, rk);
+        az_rotate_tiny(sn, cn, k.k_node * t2s, rk);
+        az_rotate_tiny(si, ci, k.k_inc * temp2 * cos2u, rk);
     } else {
-        az_rotate(ssu, csu, k.k_su * t2s);
-        az_rotate(sn, cn, k.k_node * t2s);
-        az_rotate(si, ci, k.k_inc * temp2 * cos2u);
+        az_rotate(ssu, csu, k.k_su * t2s, rk);
+        az_rotate(sn, cn, k.k_node * t2s, rk);
+        az_rotate(si, ci, k.k_inc * temp2 * cos2u, rk);
     }
 
     const double xmx = -sn * ci, xmy = cn * ci;
@@ -205,8 +205,8 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
 //                   angles still move by < 2^-7 rad and keep their carried pairs.
 template <bool VEL, class Cold, bool STRIDE64 = false>
 AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const Cold &cold, const double *__restrict__ el, size_t n_pad,
-                            size_t sat, const AzGrav &g, double t, bool first, Sgp4Carry &st, double r[3],
-                            double v[3])
+                            size_t sat, const AzGrav &g, const RotK &rk, double t, bool first, Sgp4Carry &st,
+                            double r[3], double v[3])
 {
 #define CL(k) cold(k)
     const double t2 = t * t;
@@ -223,15 +223,13 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const Cold &cold, const double *_
             az_sincos(fma(e.xnodcf, t2, fma(e.nodedot, t, nodeo)), st.sO, st.cO);
             az_sincos(fma(e.mdot, t, mo), st.sA, st.cA);
         } else if (STRIDE64) {
-            az_rotate_le_small(st.sO, st.cO, dO);
+            az_rotate_le_small(st.sO, st.cO, dO, rk);
             if (az_any(dt != st.dt_c || fabs(dW) > AZ_ROT_SMALL)) {
                 // (re)build the cached increments; also the path of any non-uniform grid
                 st.dt_c = (fabs(dW) > AZ_ROT_SMALL) ? -1.0e300 : dt;
                 az_sincos(dA, st.sdA, st.cdA);
-                const double d2 = dW * dW;
-                st.qW = d2 * fma(d2, fma(d2, -1.0 / 720.0, 1.0 / 24.0), -0.5);
-                st.pW = dW * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
-                az_rotate(st.sW, st.cW, dW);
+                az_pq_small(dW, rk, st.pW, st.qW);
+                az_rotate(st.sW, st.cW, dW, rk);
                 az_sincos(fma(e.mdot, t, el[(size_t)F_mo * n_pad + sat]), st.sA, st.cA);
             } else {
                 az_rot_apply(st.sW, st.cW, st.pW, st.qW);
@@ -241,14 +239,14 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const Cold &cold, const double *_
             }
         } else if (!az_any(fmax(fabs(dW), fabs(dO)) > AZ_ROT_MILLI || fabs(dA) > AZ_ROT_MED)) {
             // a one-minute grid lands here: J2 rates are ~1e-4 rad/min, the mean motion < 0.08
-            az_rotate_tiny(st.sW, st.cW, dW);
-            az_rotate_tiny(st.sO, st.cO, dO);
+            az_rotate_tiny(st.sW, st.cW, dW, rk);
+            az_rotate_tiny(st.sO, st.cO, dO, rk);
             az_rotate_med(st.sA, st.cA, dA);
         } else {
             // any other grid: per-angle tier votes (increments formed from dt: no cancellation)
-            az_rotate(st.sW, st.cW, dW);
-            az_rotate(st.sO, st.cO, dO);
-            az_rotate(st.sA, st.cA, dA);
+            az_rotate(st.sW, st.cW, dW, rk);
+            az_rotate(st.sO, st.cO, dO, rk);
+            az_rotate(st.sA, st.cA, dA, rk);
         }
         st.t_prev = t;
     }
@@ -262,16 +260,15 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const Cold &cold, const double *_
     // sin(mm), mm = xmdf + th, and (sin,cos)(argpm), argpm = argpdf - th: one (p,q) pair serves both
     double smm, sw = st.sW, cw = st.cW;
     if (!az_any(fabs(th) > AZ_ROT_SMALL)) {
-        const double d2 = th * th;
-        const double q = d2 * fma(d2, fma(d2, -1.0 / 720.0, 1.0 / 24.0), -0.5);
-        const double p = th * fma(d2, fma(d2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+        double p, q;
+        az_pq_small(th, rk, p, q);
         smm = sA + fma(sA, q, cA * p);
         az_rot_apply(sw, cw, -p, q);
     } else {
         double sm = sA, cm = cA;
-        az_rotate(sm, cm, th);
+        az_rotate(sm, cm, th, rk);
         smm = sm;
-        az_rotate(sw, cw, -th);
+        az_rotate(sw, cw, -th, rk);
     }
     const double tempe = fma(CL(C_bc5), smm - CL(C_sinmao), CL(C_bc4) * t);
     const double templ = fma(CL(C_t2cof), t2, fma(CL(C_t3cof), t3, t4 * fma(t, CL(C_t5cof), CL(C_t4cof))));
@@ -286,10 +283,10 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const Cold &cold, const double *_
     // u0 = mm + argpm + temp*xlcof*axnl = xmdf + argpdf + no*templ + temp*xlcof*axnl
     double su0, cu0;
     az_angle_add(sA, cA, st.sW, st.cW, su0, cu0);
-    az_rotate_le_small(su0, cu0, fma(CL(C_no_unkozai), templ, temp * e.xlcof * axnl));
+    az_rotate_le_small(su0, cu0, fma(CL(C_no_unkozai), templ, temp * e.xlcof * axnl), rk);
 
     const J2Factors k = {e.k_mrt, e.k_c2u, e.k_su, e.k_node, e.k_inc, e.x1mth2, e.k_rv};
-    az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, st.sO, st.cO, e.sinio, e.cosio, k, r, v);
+    az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, st.sO, st.cO, e.sinio, e.cosio, k, rk, r, v);
 #undef CL
 }
 
@@ -435,8 +432,8 @@ AZ_DEVICE void az_resonance_advance(const Sdp4Lane &e, const double *cold, doubl
 // one deep-space propagation; returns 0 / 1 (eccentricity) / 6 (decayed) per the scalar
 // reference path (src/Sdp4.zig L914-921, L937-938, L967).
 template <bool VEL>
-AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const double *cold, const AzGrav &g, double t, Sdp4Carry &cy,
-                           double r[3], double v[3])
+AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const double *cold, const AzGrav &g, const RotK &rk, double t,
+                           Sdp4Carry &cy, double r[3], double v[3])
 {
     const double t2 = t * t;
     const double tempa = 1.0 - e.cc1 * t;
@@ -579,7 +576,7 @@ AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const double *cold, const AzGrav &
     const double aynl = fma(em, sw, temp * aycof);
     az_sincos(mm + argpm + temp * xlcof * axnl, su0, cu0);
 
-    const double mrt = az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, sO, cO, sI, cI, k, r, v);
+    const double mrt = az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, sO, cO, sI, cI, k, rk, r, v);
     if (rc == 0 && mrt < 1.0) rc = 6;
     return rc;
 }

@@ -36,7 +36,7 @@ void emul_propagate(const double* fields, unsigned flags, const double* grav6, c
         for (int i = 0; i < n; ++i) {
             if (!incremental) { cy.atime = 0.0; cy.xli = e.xlamo; cy.xni = e.no_unkozai; }
             double r[3], v[3];
-            int rc = az_sdp4_step<true>(e, cold, g, ts[i], cy, r, v);
+            int rc = az_sdp4_step<true>(e, cold, g, az_rotk(), ts[i], cy, r, v);
             if (rc) { r[0]=r[1]=r[2]=v[0]=v[1]=v[2]=0.0; }
             memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
             rc_out[i] = rc;
@@ -47,7 +47,7 @@ void emul_propagate(const double* fields, unsigned flags, const double* grav6, c
         st.t_prev = 0; st.sW = st.cW = st.sO = st.cO = st.sA = st.cA = 0;
         for (int i = 0; i < n; ++i) {
             double r[3], v[3];
-            az_sgp4_step<true>(e, cold, fields, 1, 0, g, ts[i], (i == 0) || !incremental, st, r, v);
+            az_sgp4_step<true>(e, cold, fields, 1, 0, g, az_rotk(), ts[i], (i == 0) || !incremental, st, r, v);
             memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
             rc_out[i] = 0;
         }
@@ -57,6 +57,6 @@ void emul_propagate(const double* fields, unsigned flags, const double* grav6, c
 void emul_sincos(double x, double* s, double* c) { az_sincos(x, *s, *c); }
 double emul_rcp(double x) { return az_rcp(x); }
 double emul_rsqrt(double x) { return az_rsqrt(x); }
-void emul_rotate(double* s, double* c, double d) { az_rotate(*s, *c, d); }
+void emul_rotate(double* s, double* c, double d) { az_rotate(*s, *c, d, az_rotk()); }
 void emul_geodetic(double* p) { az_ecef_to_geodetic(p); }
 }
