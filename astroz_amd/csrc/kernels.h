@@ -440,17 +440,31 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     const RotK rk = az_rotk();
     double *prow = p.pos + (size_t)s * p.n_times * 3;
     double *vrow = VEL ? p.vel + (size_t)s * p.n_times * 3 : nullptr;
+    // the time value of the NEXT iteration is fetched before this iteration's stores are issued, so
+    // the s_waitcnt in front of its first use (vmcnt counts in issue order) never has to wait for
+    // those stores to be acknowledged by memory
+    double t_next = p.times[min(t_lo + lane, t_hi - 1)];
 #pragma unroll 1
     for (unsigned base = t_lo; base < t_hi; base += 64) {
         const unsigned i = base + lane;
         const bool live = i < t_hi;
-        const double t = p.times[live ? i : t_hi - 1] + off;
+        const double t = t_next + off;
+        t_next = p.times[min(i + 64, t_hi - 1)];
         double r[3], v[3];
         // full re-seed of the carried pairs at the start and every 64 iterations (4,096 grid points)
         const bool first = ((base - t_lo) & (64u * 64u - 1u)) == 0;
+#if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
+        r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
+        (void)first;
+#else
         az_sgp4_step<VEL, ColdUniform, true>(e, cold, p.el, p.n_pad, s, p.g, rk, t, first, c, r, v);
+#endif
         if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
+#if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only */
+        if (live && r[0] == 1.2345e300) {
+#else
         if (live) {
+#endif
             double *o = prow + (size_t)i * 3;
             o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
             if (VEL) {

@@ -4,7 +4,7 @@ cross-compiles); `run` (on the GPU box) benches each variant x time-tile and pri
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VAR = os.path.join(ROOT, "tools", "variants")
-VARIANTS = {"nt": (256, 1, 0), "nt_nocompute": (256, 1, 2)}
+VARIANTS = {"full": (256, 1, 0), "nostore": (256, 1, 1), "nocompute": (256, 1, 2)}
 
 def build():
     os.makedirs(VAR, exist_ok=True)
@@ -18,7 +18,7 @@ def build():
         cur = None
         for ln in r.stderr.splitlines():
             if "Function Name" in ln: cur = ln.split("Function Name:")[1].split()[0]
-            if cur and "k_propagateILi1ELb1ELb0ELb0E" in cur and any(k in ln for k in ("VGPRs:", "ScratchSize", "Occupancy")):
+            if cur and "k_rowsILb1ELb0" in cur and any(k in ln for k in ("VGPRs:", "ScratchSize", "Occupancy")):
                 info.append(ln.split("remark:")[1].strip().split(" [")[0])
         print(name, r.returncode, "; ".join(info))
 
