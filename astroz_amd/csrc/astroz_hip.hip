@@ -280,7 +280,8 @@ unsigned auto_tile(unsigned n_list, unsigned n_times, unsigned forced, unsigned 
 template <bool DEEP, bool FRAME>
 void launch_propagate2(const PropArgs &a, int layout, bool vel, hipStream_t st)
 {
-    dim3 grid((a.n_list + AZ_BLOCK - 1) / AZ_BLOCK, (a.n_times + a.tile - 1) / a.tile);
+    // grid.x padded to a multiple of 8: XCD-aware placement (see k_propagate)
+    dim3 grid(((a.n_list + AZ_BLOCK - 1) / AZ_BLOCK + 7) / 8 * 8, (a.n_times + a.tile - 1) / a.tile);
     dim3 block(AZ_BLOCK);
     if (layout == AZ_LAYOUT_TIME_MAJOR) {
         if (vel)
@@ -305,7 +306,7 @@ void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStr
         unsigned segs = std::max(1u, std::min((16384u + a.n_list - 1) / a.n_list, (a.n_times + 255) / 256));
         if (a.tile_forced) segs = std::max(1u, (a.n_times + a.tile_forced - 1) / a.tile_forced);
         b.tile = ((a.n_times + segs - 1) / segs + 63) / 64 * 64;
-        dim3 grid(a.n_list, (a.n_times + b.tile - 1) / b.tile), block(64);
+        dim3 grid((a.n_list + 7) / 8 * 8, (a.n_times + b.tile - 1) / b.tile), block(64);
         const PropArgs &a = b;
         if (frame) {
             if (vel) hipLaunchKernelGGL((k_rows<true, true>), grid, block, 0, st, a);

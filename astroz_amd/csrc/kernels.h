@@ -129,8 +129,10 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
     double *cold = lds_w + (VEL ? 2 : 1) * SLICE + lane;
     ColdLds cold4{cold};
 
+    // gridDim.x is padded to a multiple of 8, so workgroup (x, y) lands on XCD x % 8 for every time
+    // tile y: a satellite group's element columns are fetched into one XCD's L2 only
     const unsigned li0 = blockIdx.x * AZ_BLOCK + wave * 64; // first list slot of this wave
-    if (li0 >= p.n_list) return;                            // whole wave beyond the list (AZ_BLOCK > 64 only)
+    if (li0 >= p.n_list) return;                            // padding workgroup / wave beyond the list
     const unsigned li = li0 + lane;
     const bool in_range = li < p.n_list;
     // out-of-range lanes shadow the last satellite (the reference pads its last batch the same way,
@@ -414,7 +416,13 @@ template <bool VEL, bool FRAME>
 __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
 {
     const unsigned lane = threadIdx.x;
-    const unsigned s = p.list[blockIdx.x]; // wave-uniform
+    // XCD-aware row assignment: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the
+    // rows are dealt out in eight contiguous ranges -- every XCD then reads one eighth of the SoA
+    // element table (8 satellites share each 64-B line) instead of all of it
+    const unsigned per_xcd = gridDim.x >> 3; // gridDim.x is a multiple of 8
+    const unsigned row = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (row >= p.n_list) return;
+    const unsigned s = p.list[row]; // wave-uniform
     const unsigned fl = p.flags[s];
     if (p.mask != nullptr && p.mask[s] == 0) return;
     // blockIdx.y: time segment of p.tile grid points (a multiple of 64) -- splits long rows so that

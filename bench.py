@@ -112,12 +112,13 @@ def main():
     import torch.distributed as dist
 
     import __graft_entry__ as entry
-    if rank == 0:
-        entry.build()
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist.barrier()
+    if rank == 0:
+        entry.build()          # no-op when the in-tree .so files are current
+    if world > 1:
+        dist.barrier()         # nobody loads the library before rank 0 has (re)built it
     from astroz_amd import _native, synth
 
     # ---- workload -------------------------------------------------------------------------
@@ -205,6 +206,16 @@ def main():
     gbs = bytes_per_launch / launch_s / 1e9
     tflops = local_props * FLOPS_PER_PROP / launch_s / 1e12
 
+    # HBM traffic per launch from the PMC counters: collected offline with rocprofv3 on this same
+    # command (separate --pmc passes, tools/profile.sh) and committed under profiles/
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+        if layout == _native.SAT_MAJOR and vel_on and a.sats == 13478 and n_times == 1440 and not a.deep:
+            traffic = pm["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     out = {
         "metric": "propagations/sec, 13,478 sats x 1,440 times, at 1/2/4/8 MI355X",
         "value": value, "unit": "propagations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -222,7 +233,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
             "kernel": ("k_rows<%s> (one wave per satellite row, lane = time)" if layout == _native.SAT_MAJOR else
                        "k_propagate<time-major,%s> (lane = satellite)") % ("pos+vel" if vel_on else "pos"),
             "avg_launch_ms": launch_s * 1e3, "last_launch_ms_hipevent": last_kernel_ms,
