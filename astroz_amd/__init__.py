@@ -193,4 +193,37 @@ def propagate(source, times, *, start_time=None, output="ecef", velocities=False
     return (pos, vel) if velocities else pos
 
 
-__all__ = ["__version__", "Constellation", "propagate", "WGS72", "WGS84"]
+def screen(source, times, threshold=10.0, *, target=None, start_time=None, norad_id=None):
+    """Screen a constellation for conjunction events (reference __init__.py L535-658).
+
+    ``target`` set: fused propagate+screen on the GPU against that satellite; returns
+    ``(min_distances (n_sats,) float64 km, min_t_indices (n_sats,) uint32)`` -- a satellite that never
+    comes within ``threshold`` (and the target itself) reports ``threshold`` and index 0.
+    ``target`` None: all-vs-all; returns ``(pairs (k, 2) uint32, t_indices (k,) uint32)`` for every pair
+    closer than ``threshold`` km at a grid time, sorted by (t, s, other).  Positions stay in HBM.
+    Deep-space members take part in both modes (the reference's fused routine covers pure-SGP4
+    constellations only and falls back to propagate-then-screen otherwise, L655-658)."""
+    const = source if isinstance(source, Constellation) else Constellation(source, norad_id=norad_id)
+    times = np.ascontiguousarray(times, dtype=np.float64)
+    start = _start_jd(start_time)
+    offsets = (start - const._dev.epochs) * 1440.0
+    if target is not None:
+        d, ti = const._dev.screen_target(times, int(target), float(threshold), offsets, reference_jd=start)
+        return d, ti
+    return const._dev.screen_all(times, float(threshold), offsets)
+
+
+def coarse_screen(positions, num_sats, threshold, valid_mask=None):
+    """``_astroz.coarse_screen(positions, num_sats, threshold, [valid_mask])`` (bindings/python/src/
+    conjunction.zig L152-260): positions satellite-major ``(num_sats, n_times, 3)`` float64 (any shape
+    with that memory order); returns ``(pairs, t_indices)`` as lists like the reference -- sorted by
+    (t, s, other) rather than in hash-chain order."""
+    pos = np.ascontiguousarray(positions, dtype=np.float64)
+    if num_sats <= 0 or pos.size % (num_sats * 3) != 0:
+        raise ValueError("positions array size not consistent with num_sats")
+    pos = pos.reshape(num_sats, pos.size // (num_sats * 3), 3)
+    pairs, tt = _native.coarse_screen(pos, threshold, valid_mask, layout=_native.SAT_MAJOR)
+    return [tuple(int(x) for x in p) for p in pairs], [int(x) for x in tt]
+
+
+__all__ = ["__version__", "Constellation", "propagate", "screen", "coarse_screen", "WGS72", "WGS84"]

@@ -29,7 +29,9 @@ EXPORTS = [
     "azh_num_satellites", "azh_num_sgp4", "azh_num_sdp4", "azh_get_epochs", "azh_get_status",
     "azh_get_field", "azh_propagate_host", "azh_propagate_device", "azh_propagate_device_cached",
     "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile", "azh_set_timing",
-    "azh_last_kernel_ms",
+    "azh_last_kernel_ms", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
+    "azh_screen_target_host", "azh_screen_target_device", "azh_coarse_screen_device", "azh_coarse_screen_host",
+    "azh_screen_all_host",
 ]
 
 
@@ -114,6 +116,20 @@ def lib():
     L.azh_set_timing.restype = i32
     L.azh_last_kernel_ms.argtypes = [vp]
     L.azh_last_kernel_ms.restype = dbl
+    L.azh_propagate_device_f32.argtypes = L.azh_propagate_device.argtypes
+    L.azh_propagate_device_f32.restype = i32
+    L.azh_propagate_device_cached_f32.argtypes = L.azh_propagate_device_cached.argtypes
+    L.azh_propagate_device_cached_f32.restype = i32
+    L.azh_screen_target_host.argtypes = [vp, vp, sz, vp, sz, dbl, dbl, vp, vp]
+    L.azh_screen_target_host.restype = i32
+    L.azh_screen_target_device.argtypes = [vp, vp, sz, vp, sz, dbl, dbl, vp, vp, vp]
+    L.azh_screen_target_device.restype = i32
+    L.azh_coarse_screen_device.argtypes = [vp, sz, sz, i32, sz, dbl, vp, vp, vp, sz, C.POINTER(sz), vp]
+    L.azh_coarse_screen_device.restype = i32
+    L.azh_coarse_screen_host.argtypes = [vp, sz, sz, i32, sz, dbl, vp, vp, vp, sz, C.POINTER(sz), i32]
+    L.azh_coarse_screen_host.restype = i32
+    L.azh_screen_all_host.argtypes = [vp, vp, sz, vp, dbl, vp, vp, sz, C.POINTER(sz)]
+    L.azh_screen_all_host.restype = i32
     _lib = L
     return L
 
@@ -238,18 +254,49 @@ class DeviceConstellation:
                                        _ptr(err)), "azh_propagate_host")
 
     def propagate_device(self, times_min, offsets_min, d_pos, d_vel=None, *, mode=OUT_TEME, reference_jd=0.0,
-                         mask=None, layout=TIME_MAJOR, stride=0, d_err=None, stream=None):
-        """d_pos/d_vel/d_err are raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous."""
+                         mask=None, layout=TIME_MAJOR, stride=0, d_err=None, stream=None, f32=False):
+        """d_pos/d_vel/d_err are raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous.
+        f32=True: d_pos/d_vel are float32 arrays (fp64 arithmetic, rounded at the store)."""
         times = _f64(times_min)
         off = None if offsets_min is None else _f64(offsets_min)
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-        check(lib().azh_propagate_device(self._h, times.ctypes.data, len(times), _ptr(off), d_pos, d_vel, mode,
-                                         float(reference_jd), _ptr(m), layout, stride, d_err, stream),
-              "azh_propagate_device")
+        fn = lib().azh_propagate_device_f32 if f32 else lib().azh_propagate_device
+        check(fn(self._h, times.ctypes.data, len(times), _ptr(off), d_pos, d_vel, mode,
+                 float(reference_jd), _ptr(m), layout, stride, d_err, stream), "azh_propagate_device")
 
-    def propagate_device_cached(self, d_pos, d_vel=None, *, layout=TIME_MAJOR, stride=0, d_err=None, stream=None):
-        check(lib().azh_propagate_device_cached(self._h, d_pos, d_vel, layout, stride, d_err, stream),
-              "azh_propagate_device_cached")
+    def propagate_device_cached(self, d_pos, d_vel=None, *, layout=TIME_MAJOR, stride=0, d_err=None, stream=None,
+                                f32=False):
+        fn = lib().azh_propagate_device_cached_f32 if f32 else lib().azh_propagate_device_cached
+        check(fn(self._h, d_pos, d_vel, layout, stride, d_err, stream), "azh_propagate_device_cached")
+
+    # -- conjunction screening ------------------------------------------------------------
+    def screen_target(self, times_min, target, threshold=10.0, offsets_min=None, reference_jd=0.0):
+        """Fused propagate+screen against satellite `target`: (min_dist km (n,), min_t_index (n,) u32)."""
+        times = _f64(times_min)
+        off = None if offsets_min is None else _f64(offsets_min)
+        if off is not None and len(off) < self.n:
+            raise ValueError("epoch_offsets must have at least num_satellites elements")
+        if not 0 <= int(target) < self.n:
+            raise ValueError("target index out of range")
+        d = np.empty(self.n, dtype=np.float64)
+        ti = np.empty(self.n, dtype=np.uint32)
+        check(lib().azh_screen_target_host(self._h, times.ctypes.data, len(times), _ptr(off), int(target),
+                                           float(threshold), float(reference_jd), d.ctypes.data, ti.ctypes.data),
+              "azh_screen_target_host")
+        return d, ti
+
+    def screen_all(self, times_min, threshold=10.0, offsets_min=None, max_results=10_000_000):
+        """All-vs-all: propagate on the device and screen there: (pairs (k,2) u32, t_index (k,) u32),
+        sorted by (t, s, other)."""
+        times = _f64(times_min)
+        off = None if offsets_min is None else _f64(offsets_min)
+        pairs = np.empty((max_results, 2), dtype=np.uint32)
+        tt = np.empty(max_results, dtype=np.uint32)
+        k = C.c_size_t(0)
+        check(lib().azh_screen_all_host(self._h, times.ctypes.data, len(times), _ptr(off), float(threshold),
+                                        pairs.ctypes.data, tt.ctypes.data, max_results, C.byref(k)),
+              "azh_screen_all_host")
+        return pairs[:k.value].copy(), tt[:k.value].copy()
 
     def propagate_one(self, sat_index, tsince_min):
         t = _f64(np.atleast_1d(tsince_min))
@@ -278,6 +325,34 @@ def parse_tle_lines(line1, line2):
     if rc != 0:
         raise ValueError("Failed to parse TLE lines")
     return out
+
+
+def coarse_screen(positions, threshold, valid_mask=None, *, layout=SAT_MAJOR, max_results=10_000_000, device=0,
+                  device_ptr=None, shape=None, stream=None):
+    """All-vs-all cell-list screen of a position array on the GPU (coarseScreen, conjunction.zig).
+    `positions`: float64 host array (n_sats, n_times, 3) [sat-major] or (n_times, n_sats, 3)
+    [time-major]; or pass device_ptr= + shape= for positions already in HBM."""
+    if device_ptr is None:
+        pos = np.ascontiguousarray(positions, dtype=np.float64)
+        shape = pos.shape
+    if len(shape) != 3 or shape[2] != 3:
+        raise ValueError("positions must have shape (n_sats, n_times, 3) or (n_times, n_sats, 3)")
+    ns, nt = (shape[0], shape[1]) if layout == SAT_MAJOR else (shape[1], shape[0])
+    m = None if valid_mask is None else np.ascontiguousarray(valid_mask, dtype=np.uint8)
+    if m is not None and len(m) < ns:
+        raise ValueError("valid_mask must have num_sats elements")
+    pairs = np.empty((max_results, 2), dtype=np.uint32)
+    tt = np.empty(max_results, dtype=np.uint32)
+    k = C.c_size_t(0)
+    if device_ptr is None:
+        check(lib().azh_coarse_screen_host(pos.ctypes.data, ns, nt, layout, 0, float(threshold), _ptr(m),
+                                           pairs.ctypes.data, tt.ctypes.data, max_results, C.byref(k), device),
+              "azh_coarse_screen_host")
+    else:
+        check(lib().azh_coarse_screen_device(device_ptr, ns, nt, layout, 0, float(threshold), _ptr(m),
+                                             pairs.ctypes.data, tt.ctypes.data, max_results, C.byref(k), stream),
+              "azh_coarse_screen_device")
+    return pairs[:k.value].copy(), tt[:k.value].copy()
 
 
 def device_count():

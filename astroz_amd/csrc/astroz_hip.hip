@@ -97,6 +97,8 @@ struct azh_constellation {
     unsigned n_sgp4 = 0, n_sdp4 = 0, n_bad = 0;
     // per-call scratch
     DevBuf<double> d_times, d_offsets, d_sin, d_cos, d_seeds;
+    DevBuf<double> d_tgt, d_part_d2, d_out_d; // fused screen: target track, partial minima, results
+    DevBuf<unsigned> d_part_t, d_out_t;
     bool seeds_valid = false; // resonance seeds match the staged times/offsets and tile
     unsigned seeds_tile = 0;
     DevBuf<unsigned char> d_mask;
@@ -126,6 +128,11 @@ void destroy(azh_constellation *c)
     c->d_sin.release();
     c->d_cos.release();
     c->d_seeds.release();
+    c->d_tgt.release();
+    c->d_part_d2.release();
+    c->d_out_d.release();
+    c->d_part_t.release();
+    c->d_out_t.release();
     c->d_mask.release();
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -296,25 +303,62 @@ void launch_propagate2(const PropArgs &a, int layout, bool vel, hipStream_t st)
     }
 }
 
+// k_rows time segments: enough waves for ~4 rounds of 4 waves/SIMD, segments of >= 256 grid points,
+// a multiple of 64 grid points each
+unsigned rows_tile(unsigned n_list, unsigned n_times, unsigned forced)
+{
+    unsigned segs = std::max(1u, std::min((16384u + n_list - 1) / std::max(n_list, 1u), (n_times + 255) / 256));
+    if (forced) segs = std::max(1u, (n_times + forced - 1) / forced);
+    return ((n_times + segs - 1) / segs + 63) / 64 * 64;
+}
+
+bool use_rows(const PropArgs &a, int layout, bool deep)
+{
+    // satellite-major near-earth rows (and the fused screen, which stores nothing): one wave per
+    // satellite, lane = time
+    return !deep && (layout == AZ_LAYOUT_SAT_MAJOR || a.screen_target) && a.n_times >= 32;
+}
+
+// number of partial minima per list slot a screen launch produces
+unsigned screen_parts(const PropArgs &a, bool deep)
+{
+    if (use_rows(a, AZ_LAYOUT_SAT_MAJOR, deep)) {
+        const unsigned tile = rows_tile(a.n_list, a.n_times, a.tile_forced);
+        return (a.n_times + tile - 1) / tile;
+    }
+    return (a.n_times + a.tile - 1) / a.tile;
+}
+
+template <bool VEL, bool FRAME>
+void launch_rows2(const PropArgs &a, dim3 grid, hipStream_t st)
+{
+    if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
+}
+
 void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStream_t st)
 {
     const bool frame = a.mode != AZ_OUT_TEME;
-    if (!deep && layout == AZ_LAYOUT_SAT_MAJOR && a.n_times >= 32) {
-        // satellite-major near-earth rows: one wave per satellite, lane = time (k_rows)
-        // time segments: enough waves for ~4 rounds of 4 waves/SIMD, segments of >= 256 grid points
+    if (use_rows(a, layout, deep)) {
         PropArgs b = a;
-        unsigned segs = std::max(1u, std::min((16384u + a.n_list - 1) / a.n_list, (a.n_times + 255) / 256));
-        if (a.tile_forced) segs = std::max(1u, (a.n_times + a.tile_forced - 1) / a.tile_forced);
-        b.tile = ((a.n_times + segs - 1) / segs + 63) / 64 * 64;
-        dim3 grid((a.n_list + 7) / 8 * 8, (a.n_times + b.tile - 1) / b.tile), block(64);
-        const PropArgs &a = b;
-        if (frame) {
-            if (vel) hipLaunchKernelGGL((k_rows<true, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_rows<false, true>), grid, block, 0, st, a);
+        b.tile = rows_tile(a.n_list, a.n_times, a.tile_forced);
+        dim3 grid((a.n_list + 7) / 8 * 8, (a.n_times + b.tile - 1) / b.tile);
+        if (a.screen_target) {
+            hipLaunchKernelGGL((k_rows<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);
+        } else if (frame) {
+            if (vel) launch_rows2<true, true>(b, grid, st);
+            else launch_rows2<false, true>(b, grid, st);
         } else {
-            if (vel) hipLaunchKernelGGL((k_rows<true, false>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_rows<false, false>), grid, block, 0, st, a);
+            if (vel) launch_rows2<true, false>(b, grid, st);
+            else launch_rows2<false, false>(b, grid, st);
         }
+        return;
+    }
+    if (a.screen_target) {
+        // fused screen, lane = satellite (deep-space members; near-earth on very short grids)
+        dim3 grid(((a.n_list + AZ_BLOCK - 1) / AZ_BLOCK + 7) / 8 * 8, (a.n_times + a.tile - 1) / a.tile);
+        if (deep) hipLaunchKernelGGL((k_propagate<0, false, true, false, true>), grid, dim3(AZ_BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((k_propagate<0, false, false, false, true>), grid, dim3(AZ_BLOCK), 0, st, a);
         return;
     }
     if (deep) {
@@ -355,9 +399,32 @@ int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, 
     return AZ_OK;
 }
 
+// deep-space launch arguments: list slice, tile, and the resonance state at every tile start --
+// computed once per (time grid, offsets, tile) and kept in the handle, like the reference keeps its
+// carries (src/Constellation.zig L88, L294)
+int32_t prepare_deep(azh_constellation *c, PropArgs &d, hipStream_t st)
+{
+    const unsigned n_times = d.n_times;
+    d.list = c->d_list.p + c->n_sgp4;
+    d.n_list = c->n_sdp4;
+    d.tile = auto_tile(c->n_sdp4, n_times, c->tile_sdp4, 8);
+    d.tile_forced = c->tile_sdp4;
+    const unsigned n_tiles = (n_times + d.tile - 1) / d.tile;
+    if (!c->seeds_valid || c->seeds_tile != d.tile) {
+        if (c->d_seeds.ensure((size_t)n_tiles * 3 * c->n_sdp4) != AZ_OK) return AZ_ERR_HIP;
+        hipLaunchKernelGGL(k_deep_seed, dim3((c->n_sdp4 + 63) / 64), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
+                           d.list, c->n_sdp4, d.times, n_times, d.offsets, d.tile, c->d_seeds.p);
+        HIP_TRY(hipGetLastError());
+        c->seeds_valid = true;
+        c->seeds_tile = d.tile;
+    }
+    d.seeds = c->d_seeds.p;
+    return AZ_OK;
+}
+
 // the launches proper; inputs already staged on the device
 int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layout, size_t stride, uint8_t *d_err,
-                   hipStream_t st)
+                   hipStream_t st, int f32 = 0)
 {
     const unsigned n_times = c->cached_n_times;
     if (n_times == 0) return AZ_OK;
@@ -379,6 +446,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     a.err = d_err;
     a.stride_sats = stride;
     a.mode = c->cached_mode;
+    a.f32 = f32;
     a.g = c->g;
 
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
@@ -389,21 +457,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         HIP_TRY(hipEventRecord(c->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(c->s_deep, c->ev_fork, 0));
         PropArgs d = a;
-        d.list = c->d_list.p + c->n_sgp4;
-        d.n_list = c->n_sdp4;
-        d.tile = auto_tile(c->n_sdp4, n_times, c->tile_sdp4, 8);
-        // resonance state at every tile start: computed once per (time grid, offsets, tile) and kept
-        // in the handle, like the reference keeps its carries (src/Constellation.zig L88, L294)
-        const unsigned n_tiles = (n_times + d.tile - 1) / d.tile;
-        if (!c->seeds_valid || c->seeds_tile != d.tile) {
-            if (c->d_seeds.ensure((size_t)n_tiles * 3 * c->n_sdp4) != AZ_OK) return AZ_ERR_HIP;
-            hipLaunchKernelGGL(k_deep_seed, dim3((c->n_sdp4 + 63) / 64), dim3(64), 0, c->s_deep, c->d_el, c->d_flags,
-                               c->n_pad, d.list, c->n_sdp4, d.times, n_times, d.offsets, d.tile, c->d_seeds.p);
-            HIP_TRY(hipGetLastError());
-            c->seeds_valid = true;
-            c->seeds_tile = d.tile;
-        }
-        d.seeds = c->d_seeds.p;
+        if (int32_t rc = prepare_deep(c, d, c->s_deep); rc != AZ_OK) return rc;
         launch_propagate(d, layout, d_vel != nullptr, true, c->s_deep);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_join, c->s_deep));
@@ -419,7 +473,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     if (c->n_bad > 0) {
         hipLaunchKernelGGL(k_fill_bad, dim3((n_times + 255) / 256, c->n_bad), dim3(256), 0, st,
                            c->d_list.p + c->n_sgp4 + c->n_sdp4, c->n_bad, c->d_flags, n_times, d_pos, d_vel, d_err,
-                           c->have_mask ? c->d_mask.p : nullptr, layout, stride);
+                           c->have_mask ? c->d_mask.p : nullptr, layout, stride, f32);
         HIP_TRY(hipGetLastError());
     }
     if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
@@ -573,6 +627,284 @@ int32_t azh_propagate_device_cached(azh_constellation *c, double *d_pos, double 
     return launch_all(c, d_pos, d_vel, layout, stride, d_err, stream ? (hipStream_t)stream : c->s_main);
 }
 
+int32_t azh_propagate_device_f32(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+                                 float *d_pos, float *d_vel, int32_t mode, double reference_jd, const uint8_t *mask,
+                                 int32_t layout, size_t stride, uint8_t *d_err, void *stream)
+{
+    if (!c || !d_pos || (n_times && !times)) return AZ_ERR_NULL_POINTER;
+    if (mode < 0 || mode > 2 || layout < 0 || layout > 1) return AZ_ERR_VALUE;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    hipStream_t st = stream ? (hipStream_t)stream : c->s_main;
+    int32_t rc = stage_inputs(c, times, n_times, offsets, mask, mode, reference_jd, st);
+    if (rc != AZ_OK) return rc;
+    return launch_all(c, reinterpret_cast<double *>(d_pos), reinterpret_cast<double *>(d_vel), layout, stride, d_err, st, 1);
+}
+
+int32_t azh_propagate_device_cached_f32(azh_constellation *c, float *d_pos, float *d_vel, int32_t layout, size_t stride,
+                                        uint8_t *d_err, void *stream)
+{
+    if (!c || !d_pos) return AZ_ERR_NULL_POINTER;
+    if (layout < 0 || layout > 1) return AZ_ERR_VALUE;
+    if (c->cached_n_times == 0) return AZ_ERR_NOT_INITIALIZED;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    return launch_all(c, reinterpret_cast<double *>(d_pos), reinterpret_cast<double *>(d_vel), layout, stride, d_err,
+                      stream ? (hipStream_t)stream : c->s_main, 1);
+}
+
+// Fused single-target conjunction screen (Constellation.screenConstellation, src/Constellation.zig
+// L683-756): nothing but 12 bytes per satellite ever leaves the chip.
+int32_t azh_screen_target_device(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+                                 size_t target, double threshold_km, double reference_jd, double *d_min_dist,
+                                 uint32_t *d_min_t, void *stream)
+{
+    (void)reference_jd; // the reference rotates both vectors to ECEF first (L719, L737); distances do not change
+    if (!c || !d_min_dist || !d_min_t || (n_times && !times)) return AZ_ERR_NULL_POINTER;
+    if (target >= c->n) return AZ_ERR_VALUE;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    hipStream_t st = stream ? (hipStream_t)stream : c->s_main;
+    int32_t rc = stage_inputs(c, times, n_times, offsets, nullptr, AZ_OUT_TEME, 0.0, st);
+    if (rc != AZ_OK) return rc;
+    const unsigned nt = (unsigned)n_times;
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
+    hipLaunchKernelGGL(k_screen_fill, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, st, (unsigned)c->n, threshold_km,
+                       d_min_dist, d_min_t);
+    HIP_TRY(hipGetLastError());
+    if (nt > 0) {
+        if (c->d_tgt.ensure((size_t)nt * 3) != AZ_OK) return AZ_ERR_HIP;
+        hipLaunchKernelGGL(k_one_satellite, dim3((nt + 63) / 64), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
+                           (unsigned)target, c->d_times.p, nt, c->d_tgt.p, (double *)nullptr, (unsigned char *)nullptr, 0,
+                           c->g, c->have_offsets ? c->d_offsets.p : (const double *)nullptr, 1);
+        HIP_TRY(hipGetLastError());
+        PropArgs a{};
+        a.el = c->d_el;
+        a.flags = c->d_flags;
+        a.n_pad = c->n_pad;
+        a.times = c->d_times.p;
+        a.n_times = nt;
+        a.offsets = c->have_offsets ? c->d_offsets.p : nullptr;
+        a.stride_sats = c->n;
+        a.mode = AZ_OUT_TEME;
+        a.g = c->g;
+        a.screen_target = c->d_tgt.p;
+        PropArgs near = a, deep = a;
+        unsigned parts_near = 0, parts_deep = 0;
+        if (c->n_sgp4 > 0) {
+            near.list = c->d_list.p;
+            near.n_list = c->n_sgp4;
+            near.tile = auto_tile(c->n_sgp4, nt, c->tile_sgp4, 8);
+            near.tile_forced = c->tile_sgp4;
+            parts_near = screen_parts(near, false);
+        }
+        if (c->n_sdp4 > 0) {
+            if ((rc = prepare_deep(c, deep, st)) != AZ_OK) return rc;
+            parts_deep = screen_parts(deep, true);
+        }
+        const size_t np_near = (size_t)parts_near * c->n_sgp4, np_deep = (size_t)parts_deep * c->n_sdp4;
+        if (c->d_part_d2.ensure(np_near + np_deep) != AZ_OK || c->d_part_t.ensure(np_near + np_deep) != AZ_OK) return AZ_ERR_HIP;
+        const double thr2 = threshold_km * threshold_km;
+        if (c->n_sgp4 > 0) {
+            near.part_d2 = c->d_part_d2.p;
+            near.part_t = c->d_part_t.p;
+            launch_propagate(near, AZ_LAYOUT_SAT_MAJOR, false, false, st);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_screen_finalize, dim3((c->n_sgp4 + 255) / 256), dim3(256), 0, st, near.part_d2, near.part_t,
+                               parts_near, near.list, c->n_sgp4, thr2, (unsigned)target, d_min_dist, d_min_t);
+            HIP_TRY(hipGetLastError());
+        }
+        if (c->n_sdp4 > 0) {
+            deep.part_d2 = c->d_part_d2.p + np_near;
+            deep.part_t = c->d_part_t.p + np_near;
+            launch_propagate(deep, AZ_LAYOUT_SAT_MAJOR, false, true, st);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_screen_finalize, dim3((c->n_sdp4 + 255) / 256), dim3(256), 0, st, deep.part_d2, deep.part_t,
+                               parts_deep, deep.list, c->n_sdp4, thr2, (unsigned)target, d_min_dist, d_min_t);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev_t1, st));
+        c->timed = true;
+    }
+    return AZ_OK;
+}
+
+int32_t azh_screen_target_host(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+                               size_t target, double threshold_km, double reference_jd, double *min_dist,
+                               uint32_t *min_t)
+{
+    if (!c || !min_dist || !min_t) return AZ_ERR_NULL_POINTER;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    if (c->d_out_d.ensure(c->n) != AZ_OK || c->d_out_t.ensure(c->n) != AZ_OK) return AZ_ERR_HIP;
+    int32_t rc = azh_screen_target_device(c, times, n_times, offsets, target, threshold_km, reference_jd, c->d_out_d.p,
+                                          c->d_out_t.p, nullptr);
+    if (rc != AZ_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(min_dist, c->d_out_d.p, sizeof(double) * c->n, hipMemcpyDeviceToHost, c->s_main));
+    HIP_TRY(hipMemcpyAsync(min_t, c->d_out_t.p, sizeof(uint32_t) * c->n, hipMemcpyDeviceToHost, c->s_main));
+    HIP_TRY(hipStreamSynchronize(c->s_main));
+    return AZ_OK;
+}
+
+// All-vs-all coarse screen of device-resident positions (coarseScreen, bindings/python/src/
+// conjunction.zig L11-150).  Result triplets come back on the host sorted by (t, s, other) -- the
+// reference's order within one (t, s) depends on its hash-chain order; the set is identical.
+namespace {
+int32_t coarse_screen(const double *d_pos, size_t n_sats, size_t n_times, int32_t layout, size_t stride,
+                      double threshold_km, const uint8_t *valid_mask, uint32_t *out_pairs, uint32_t *out_t,
+                      size_t max_results, size_t *n_found, void *stream, int skip_zero)
+{
+    if (!d_pos || !n_found || (max_results && (!out_pairs || !out_t))) return AZ_ERR_NULL_POINTER;
+    *n_found = 0;
+    if (layout < 0 || layout > 1 || !(threshold_km > 0.0)) return AZ_ERR_VALUE;
+    if (n_sats == 0 || n_times == 0) return AZ_OK;
+    if (n_sats > 0x7fffffffu || n_times > 0xffffffffu) return AZ_ERR_VALUE;
+    if (stride == 0) stride = n_sats;
+    hipStream_t st = (hipStream_t)stream;
+    // one bucket table per time step of a chunk; >= 2 buckets per satellite, at least the reference's 2^16
+    unsigned bits = 16;
+    while (bits < 24 && ((size_t)1 << bits) < 2 * n_sats) ++bits;
+    const size_t table = (size_t)1 << bits;
+    const unsigned chunk = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n_times, 64), ((size_t)1 << 25) / (table + n_sats)));
+    unsigned *d_head = nullptr, *d_next = nullptr, *d_pairs = nullptr, *d_t = nullptr;
+    unsigned long long *d_count = nullptr;
+    uint8_t *d_valid = nullptr;
+    int32_t rc = AZ_OK;
+    std::vector<uint32_t> hp, ht;
+    size_t cap = std::max<size_t>(max_results, 1 << 16);
+    unsigned long long total = 0;
+    do {
+        if (!hip_ok(hipMalloc((void **)&d_head, sizeof(unsigned) * table * chunk), "hipMalloc(head)") ||
+            !hip_ok(hipMalloc((void **)&d_next, sizeof(unsigned) * n_sats * chunk), "hipMalloc(next)") ||
+            !hip_ok(hipMalloc((void **)&d_count, sizeof(unsigned long long)), "hipMalloc(count)")) { rc = AZ_ERR_HIP; break; }
+        if (valid_mask) {
+            if (!hip_ok(hipMalloc((void **)&d_valid, n_sats), "hipMalloc(valid)") ||
+                !hip_ok(hipMemcpyAsync(d_valid, valid_mask, n_sats, hipMemcpyHostToDevice, st), "H2D valid")) { rc = AZ_ERR_HIP; break; }
+        }
+        for (int pass = 0; pass < 2 && rc == AZ_OK; ++pass) {
+            if (d_pairs) (void)hipFree(d_pairs);
+            if (d_t) (void)hipFree(d_t);
+            d_pairs = d_t = nullptr;
+            if (!hip_ok(hipMalloc((void **)&d_pairs, sizeof(unsigned) * 2 * cap), "hipMalloc(pairs)") ||
+                !hip_ok(hipMalloc((void **)&d_t, sizeof(unsigned) * cap), "hipMalloc(t)") ||
+                !hip_ok(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st), "memset count")) { rc = AZ_ERR_HIP; break; }
+            CellArgs a{};
+            a.pos = d_pos;
+            a.n_sats = (unsigned)n_sats;
+            a.n_times = (unsigned)n_times;
+            a.layout = layout;
+            a.stride_sats = stride;
+            a.valid = d_valid;
+            a.inv_cell = 1.0 / threshold_km;
+            a.thr2 = threshold_km * threshold_km;
+            a.table_mask = (unsigned)(table - 1);
+            a.head = d_head;
+            a.next = d_next;
+            a.out_pairs = d_pairs;
+            a.out_t = d_t;
+            a.count = d_count;
+            a.max_results = cap;
+            a.skip_zero = skip_zero;
+            for (size_t t0 = 0; t0 < n_times && rc == AZ_OK; t0 += chunk) {
+                a.t0 = (unsigned)t0;
+                a.n_steps = (unsigned)std::min<size_t>(chunk, n_times - t0);
+                if (!hip_ok(hipMemsetAsync(d_head, 0xff, sizeof(unsigned) * table * a.n_steps, st), "memset head")) { rc = AZ_ERR_HIP; break; }
+                dim3 grid((unsigned)((n_sats + 255) / 256), a.n_steps);
+                hipLaunchKernelGGL(k_cells_build, grid, dim3(256), 0, st, a);
+                hipLaunchKernelGGL(k_cells_probe, grid, dim3(256), 0, st, a);
+                if (!hip_ok(hipGetLastError(), "k_cells")) { rc = AZ_ERR_HIP; break; }
+            }
+            if (rc != AZ_OK) break;
+            if (!hip_ok(hipMemcpyAsync(&total, d_count, sizeof(total), hipMemcpyDeviceToHost, st), "D2H count") ||
+                !hip_ok(hipStreamSynchronize(st), "sync(screen)")) { rc = AZ_ERR_HIP; break; }
+            if (total <= cap) break;
+            cap = (size_t)total; // the result buffer overflowed: one more pass with room for everything
+        }
+        if (rc != AZ_OK) break;
+        const size_t got = (size_t)std::min<unsigned long long>(total, cap);
+        hp.resize(2 * got);
+        ht.resize(got);
+        if (got) {
+            if (!hip_ok(hipMemcpy(hp.data(), d_pairs, sizeof(uint32_t) * 2 * got, hipMemcpyDeviceToHost), "D2H pairs") ||
+                !hip_ok(hipMemcpy(ht.data(), d_t, sizeof(uint32_t) * got, hipMemcpyDeviceToHost), "D2H t")) { rc = AZ_ERR_HIP; break; }
+        }
+        std::vector<size_t> order(got);
+        for (size_t i = 0; i < got; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+            if (ht[x] != ht[y]) return ht[x] < ht[y];
+            if (hp[2 * x] != hp[2 * y]) return hp[2 * x] < hp[2 * y];
+            return hp[2 * x + 1] < hp[2 * y + 1];
+        });
+        const size_t keep = std::min(got, max_results);
+        for (size_t i = 0; i < keep; ++i) {
+            out_pairs[2 * i] = hp[2 * order[i]];
+            out_pairs[2 * i + 1] = hp[2 * order[i] + 1];
+            out_t[i] = ht[order[i]];
+        }
+        *n_found = keep;
+    } while (0);
+    if (rc != AZ_OK) (void)hipStreamSynchronize(st);
+    if (d_head) (void)hipFree(d_head);
+    if (d_next) (void)hipFree(d_next);
+    if (d_pairs) (void)hipFree(d_pairs);
+    if (d_t) (void)hipFree(d_t);
+    if (d_count) (void)hipFree(d_count);
+    if (d_valid) (void)hipFree(d_valid);
+    return rc;
+}
+} // namespace
+
+int32_t azh_coarse_screen_device(const double *d_pos, size_t n_sats, size_t n_times, int32_t layout, size_t stride,
+                                 double threshold_km, const uint8_t *valid_mask, uint32_t *out_pairs, uint32_t *out_t,
+                                 size_t max_results, size_t *n_found, void *stream)
+{
+    return coarse_screen(d_pos, n_sats, n_times, layout, stride, threshold_km, valid_mask, out_pairs, out_t, max_results,
+                         n_found, stream, 0);
+}
+
+int32_t azh_coarse_screen_host(const double *pos, size_t n_sats, size_t n_times, int32_t layout, size_t stride,
+                               double threshold_km, const uint8_t *valid_mask, uint32_t *out_pairs, uint32_t *out_t,
+                               size_t max_results, size_t *n_found, int32_t device)
+{
+    if (!pos || !n_found) return AZ_ERR_NULL_POINTER;
+    HIP_TRY(hipSetDevice(device));
+    if (stride == 0) stride = n_sats;
+    const size_t rows = (layout == AZ_LAYOUT_TIME_MAJOR) ? stride : n_sats;
+    const size_t bytes = rows * n_times * 3 * sizeof(double);
+    double *d_pos = nullptr;
+    if (bytes == 0) { *n_found = 0; return AZ_OK; }
+    HIP_TRY(hipMalloc((void **)&d_pos, bytes));
+    int32_t rc = AZ_OK;
+    if (!hip_ok(hipMemcpy(d_pos, pos, bytes, hipMemcpyHostToDevice), "H2D pos")) rc = AZ_ERR_HIP;
+    if (rc == AZ_OK)
+        rc = azh_coarse_screen_device(d_pos, n_sats, n_times, layout, stride, threshold_km, valid_mask, out_pairs, out_t,
+                                      max_results, n_found, nullptr);
+    (void)hipFree(d_pos);
+    return rc;
+}
+
+// screen() without a target (bindings/python/astroz/__init__.py L633-658): propagate every member
+// to TEME on the device (time-major scratch, never copied to the host) and run the coarse screen on it
+int32_t azh_screen_all_host(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+                            double threshold_km, uint32_t *out_pairs, uint32_t *out_t, size_t max_results,
+                            size_t *n_found)
+{
+    if (!c || !n_found || (n_times && !times)) return AZ_ERR_NULL_POINTER;
+    *n_found = 0;
+    if (n_times == 0) return AZ_OK;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    double *d_pos = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_pos, sizeof(double) * 3 * c->n * n_times));
+    int32_t rc = azh_propagate_device(c, times, n_times, offsets, d_pos, nullptr, AZ_OUT_TEME, 0.0, nullptr,
+                                      AZ_LAYOUT_TIME_MAJOR, 0, nullptr, nullptr);
+    // rows the propagator zero-filled (failed init, failed deep-space step) are skipped: a satellite
+    // is never at the geocentre, and two such rows must not be reported as a conjunction
+    if (rc == AZ_OK)
+        rc = coarse_screen(d_pos, c->n, n_times, AZ_LAYOUT_TIME_MAJOR, 0, threshold_km, nullptr, out_pairs, out_t,
+                           max_results, n_found, c->s_main, 1);
+    (void)hipStreamSynchronize(c->s_main);
+    (void)hipFree(d_pos);
+    return rc;
+}
+
 int32_t azh_propagate_host(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
                            double *pos, double *vel, int32_t mode, double reference_jd, const uint8_t *mask,
                            int32_t layout, size_t stride, uint8_t *err)
@@ -662,7 +994,7 @@ int32_t azh_propagate_one_host(azh_constellation *c, size_t sat, const double *t
             !hip_ok(hipMalloc((void **)&d_e, n), "hipMalloc")) { rc = AZ_ERR_HIP; break; }
         if (!hip_ok(hipMemcpyAsync(d_t, tsince, sizeof(double) * n, hipMemcpyHostToDevice, st), "H2D")) { rc = AZ_ERR_HIP; break; }
         hipLaunchKernelGGL(k_one_satellite, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->d_el,
-                           c->d_flags, c->n_pad, (unsigned)sat, d_t, (unsigned)n, d_p, d_v, d_e, 0, c->g);
+                           c->d_flags, c->n_pad, (unsigned)sat, d_t, (unsigned)n, d_p, d_v, d_e, 0, c->g, (const double *)nullptr, 0);
         if (!hip_ok(hipGetLastError(), "k_one_satellite")) { rc = AZ_ERR_HIP; break; }
         if (!hip_ok(hipMemcpyAsync(pos, d_p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st), "D2H")) { rc = AZ_ERR_HIP; break; }
         if (vel && !hip_ok(hipMemcpyAsync(vel, d_v, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st), "D2H")) { rc = AZ_ERR_HIP; break; }
@@ -768,7 +1100,8 @@ int32_t sgp4_propagate_batch(void *h, const double *times, double *results, uint
             !hip_ok(hipMalloc((void **)&d_o, sizeof(double) * 6 * count), "hipMalloc")) { rc = AZ_ERR_HIP; break; }
         if (!hip_ok(hipMemcpyAsync(d_t, times, sizeof(double) * count, hipMemcpyHostToDevice, st), "H2D")) { rc = AZ_ERR_HIP; break; }
         hipLaunchKernelGGL(k_one_satellite, dim3((count + 63) / 64), dim3(64), 0, st, c->d_el, c->d_flags,
-                           c->n_pad, 0u, d_t, count, d_o, (double *)nullptr, (unsigned char *)nullptr, 1, c->g);
+                           c->n_pad, 0u, d_t, count, d_o, (double *)nullptr, (unsigned char *)nullptr, 1, c->g,
+                           (const double *)nullptr, 0);
         if (!hip_ok(hipGetLastError(), "k_one_satellite")) { rc = AZ_ERR_HIP; break; }
         if (!hip_ok(hipMemcpyAsync(results, d_o, sizeof(double) * 6 * count, hipMemcpyDeviceToHost, st), "D2H")) { rc = AZ_ERR_HIP; break; }
         if (!hip_ok(hipStreamSynchronize(st), "sync")) { rc = AZ_ERR_HIP; break; }

@@ -10,6 +10,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "init_device.h"
 #include "propagate_device.h"
 
@@ -52,8 +54,23 @@ struct PropArgs {
     unsigned tile_forced;        // user override (0 = automatic)
     const double *seeds;         // deep space: resonance state at each tile start, [tile][3][n_list]; may be null
     int mode;
+    int f32; // outputs are float arrays (pos/vel point to float): fp64 arithmetic, results rounded once at the store
+    // fused single-target conjunction screen (sink instead of stores): the target's TEME track,
+    // [n_times][3], NaN where the target itself failed; partial minima per (segment or tile, list slot)
+    const double *screen_target;
+    double *part_d2;
+    unsigned *part_t;
     AzGrav g;
 };
+
+// one result vector -> memory, fp64 or fp32
+template <class T>
+__device__ __forceinline__ void az_put3(T *o, const double r[3])
+{
+    o[0] = (T)r[0];
+    o[1] = (T)r[1];
+    o[2] = (T)r[2];
+}
 
 __device__ __forceinline__ void az_epilogue(double r[3], double v[3], int mode, bool vel, const double *sin_g,
                                             const double *cos_g, unsigned i)
@@ -111,7 +128,7 @@ __device__ __forceinline__ void az_wave_lds_fence()
 
 // FRAME = false: TEME output, no epilogue code at all (keeps its registers and SGPRs out of the
 // hot kernel); FRAME = true: ECEF / geodetic chosen at run time by p.mode.
-template <int LAYOUT, bool VEL, bool DEEP, bool FRAME>
+template <int LAYOUT, bool VEL, bool DEEP, bool FRAME, bool SCREEN = false>
 __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (FRAME ? 1 : (DEEP ? AZ_DEEP_WAVES : 3)))) k_propagate(PropArgs p)
 {
     constexpr int WAVES = AZ_BLOCK / 64;
@@ -147,7 +164,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
     // time-major fast path: this wave's 64 satellites are consecutive catalog rows
     const unsigned s_first = p.list[li0];
     const bool dense = (LAYOUT == 1) && !DEEP && (li0 + 63 < p.n_list) && (p.list[min(li0 + 63, p.n_list - 1)] - s_first == 63u) &&
-                       (p.mask == nullptr);
+                       (p.mask == nullptr) && !p.f32;
 
     Sgp4Lane e4;
     Sgp4Carry c4;
@@ -177,6 +194,8 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
 
     double tcache = 0.0;
     const RotK rk = az_rotk();
+    double best_d2 = __builtin_inf(); // fused screen only (SCREEN)
+    unsigned best_t = 0xffffffffu;
 #pragma unroll 1
     for (unsigned i = t0; i < t1; ++i) {
         // Time values: one coalesced 512-B vector load per 64 steps parks 64 of them in a VGPR (one
@@ -199,6 +218,17 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
         }
 #endif
         if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, i);
+        if (SCREEN) {
+            // fused single-target screen (lane = satellite): running minimum over this tile, no stores
+            const double *q = p.screen_target + (size_t)i * 3; // wave-uniform address
+            const double dx = q[0] - r[0], dy = q[1] - r[1], dz = q[2] - r[2];
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (rc == 0 && d2 < best_d2) {
+                best_d2 = d2;
+                best_t = i;
+            }
+            continue;
+        }
         if (DEEP) {
             if (rc != 0) {
                 r[0] = r[1] = r[2] = 0.0;
@@ -243,6 +273,11 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
 #else
                 const size_t ob = ((size_t)i * p.stride_sats + s) * 3;
 #endif
+                if (p.f32) {
+                    az_put3(reinterpret_cast<float *>(p.pos) + ob, r);
+                    if (VEL) az_put3(reinterpret_cast<float *>(p.vel) + ob, v);
+                    continue;
+                }
                 AZ_ST1(p.pos + ob, r[0]);
                 AZ_ST1(p.pos + ob + 1, r[1]);
                 AZ_ST1(p.pos + ob + 2, r[2]);
@@ -259,6 +294,11 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
             // staging, which keeps the occupancy of the time-major kernel.
             if (wr) {
                 const size_t ob = ((size_t)s * p.n_times + i) * 3;
+                if (p.f32) {
+                    az_put3(reinterpret_cast<float *>(p.pos) + ob, r);
+                    if (VEL) az_put3(reinterpret_cast<float *>(p.vel) + ob, v);
+                    continue;
+                }
                 AZ_ST1(p.pos + ob, r[0]);
                 AZ_ST1(p.pos + ob + 1, r[1]);
                 AZ_ST1(p.pos + ob + 2, r[2]);
@@ -294,14 +334,23 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
                         const unsigned sj = p.list[lj];
                         if (p.mask == nullptr || p.mask[sj] != 0) {
                             const size_t ob = ((size_t)sj * p.n_times + tb) * 3 + cw;
-                            p.pos[ob] = lds_p[rl * AZ_SM_ROW + cw];
-                            if (VEL) p.vel[ob] = lds_v[rl * AZ_SM_ROW + cw];
+                            if (p.f32) {
+                                reinterpret_cast<float *>(p.pos)[ob] = (float)lds_p[rl * AZ_SM_ROW + cw];
+                                if (VEL) reinterpret_cast<float *>(p.vel)[ob] = (float)lds_v[rl * AZ_SM_ROW + cw];
+                            } else {
+                                p.pos[ob] = lds_p[rl * AZ_SM_ROW + cw];
+                                if (VEL) p.vel[ob] = lds_v[rl * AZ_SM_ROW + cw];
+                            }
                         }
                     }
                 }
                 az_wave_lds_fence();
             }
         }
+    }
+    if (SCREEN && in_range) {
+        p.part_d2[(size_t)blockIdx.y * p.n_list + li] = best_d2;
+        p.part_t[(size_t)blockIdx.y * p.n_list + li] = best_t;
     }
 }
 
@@ -346,10 +395,11 @@ __global__ void __launch_bounds__(64) k_deep_seed(const double *el, const unsign
 __global__ void __launch_bounds__(64) k_one_satellite(const double *el, const unsigned *flags,
                                                             size_t n_pad, unsigned sat, const double *tsince,
                                                             unsigned n, double *pos, double *vel,
-                                                            unsigned char *err, int interleaved, AzGrav g)
+                                                            unsigned char *err, int interleaved, AzGrav g,
+                                                            const double *offsets, int nan_on_error)
 {
     const unsigned i = blockIdx.x * 64 + threadIdx.x;
-    const double t = tsince[i < n ? i : n - 1];
+    const double t = tsince[i < n ? i : n - 1] + (offsets ? offsets[sat] : 0.0);
     const unsigned fl = flags[sat];
     double r[3], v[3];
     int rc = AZ_FLAG_ERR(fl);
@@ -374,7 +424,7 @@ __global__ void __launch_bounds__(64) k_one_satellite(const double *el, const un
         }
     }
     if (rc != 0) {
-        r[0] = r[1] = r[2] = 0.0;
+        r[0] = r[1] = r[2] = nan_on_error ? __builtin_nan("") : 0.0;
         v[0] = v[1] = v[2] = 0.0;
     }
     if (i < n) {
@@ -412,9 +462,30 @@ struct ColdUniform {
     __device__ __forceinline__ void set(int k, double v) { c[k] = az_uniform(v); }
 };
 
-template <bool VEL, bool FRAME>
+// SINK: what happens to a result -- 0: fp64 rows, 1: fp32 rows, 2: fused single-target conjunction
+// screen (nothing is stored; each lane keeps the running minimum of |r - r_target|^2 over its grid
+// points, the wave reduces once at the end; src/Constellation.zig L683-756)
+enum { AZ_SINK_F64 = 0, AZ_SINK_F32 = 1, AZ_SINK_SCREEN = 2 };
+
+// lexicographic (d2, t) minimum across the wave: smallest distance, earliest grid point among equals
+// (the reference scans time ascending with a strict '<', Constellation.zig L744)
+__device__ __forceinline__ void az_wave_argmin(double &d2, unsigned &t)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double od = __shfl_xor(d2, off, 64);
+        const unsigned ot = __shfl_xor(t, off, 64);
+        if (od < d2 || (od == d2 && ot < t)) {
+            d2 = od;
+            t = ot;
+        }
+    }
+}
+
+template <bool VEL, bool FRAME, int SINK>
 __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
 {
+    typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
     const unsigned lane = threadIdx.x;
     // XCD-aware row assignment: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the
     // rows are dealt out in eight contiguous ranges -- every XCD then reads one eighth of the SoA
@@ -424,7 +495,7 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     if (row >= p.n_list) return;
     const unsigned s = p.list[row]; // wave-uniform
     const unsigned fl = p.flags[s];
-    if (p.mask != nullptr && p.mask[s] == 0) return;
+    if (SINK != AZ_SINK_SCREEN && p.mask != nullptr && p.mask[s] == 0) return;
     // blockIdx.y: time segment of p.tile grid points (a multiple of 64) -- splits long rows so that
     // the grid has enough waves to fill the chip several times over
     const unsigned t_lo = blockIdx.y * p.tile;
@@ -446,8 +517,10 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     c.sdA = c.pW = c.qW = 0.0;
     c.cdA = 1.0;
     const RotK rk = az_rotk();
-    double *prow = p.pos + (size_t)s * p.n_times * 3;
-    double *vrow = VEL ? p.vel + (size_t)s * p.n_times * 3 : nullptr;
+    out_t *prow = reinterpret_cast<out_t *>(p.pos) + (size_t)s * p.n_times * 3;
+    out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + (size_t)s * p.n_times * 3 : nullptr;
+    double best_d2 = __builtin_inf();
+    unsigned best_t = 0xffffffffu;
     // the time value of the NEXT iteration is fetched before this iteration's stores are issued, so
     // the s_waitcnt in front of its first use (vmcnt counts in issue order) never has to wait for
     // those stores to be acknowledged by memory
@@ -467,26 +540,184 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
 #else
         az_sgp4_step<VEL, ColdUniform, true>(e, cold, p.el, p.n_pad, s, p.g, rk, t, first, c, r, v);
 #endif
+        if (SINK == AZ_SINK_SCREEN) {
+            // distances are frame-independent (ECEF is a rotation of TEME about z), so the screen
+            // works on the TEME vectors directly
+            const double *q = p.screen_target + (size_t)(live ? i : t_hi - 1) * 3;
+            const double dx = q[0] - r[0], dy = q[1] - r[1], dz = q[2] - r[2];
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (live && d2 < best_d2) { // NaN (failed target step) never wins
+                best_d2 = d2;
+                best_t = i;
+            }
+            continue;
+        }
         if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
 #if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only */
         if (live && r[0] == 1.2345e300) {
 #else
         if (live) {
 #endif
-            double *o = prow + (size_t)i * 3;
-            o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
-            if (VEL) {
-                double *w = vrow + (size_t)i * 3;
-                w[0] = v[0]; w[1] = v[1]; w[2] = v[2];
+            az_put3(prow + (size_t)i * 3, r);
+            if (VEL) az_put3(vrow + (size_t)i * 3, v);
+        }
+    }
+    if (SINK == AZ_SINK_SCREEN) {
+        az_wave_argmin(best_d2, best_t);
+        if (lane == 0) {
+            p.part_d2[(size_t)blockIdx.y * p.n_list + row] = best_d2;
+            p.part_t[(size_t)blockIdx.y * p.n_list + row] = best_t;
+        }
+    }
+}
+
+// screen: combine the partial minima of one launch list (parts are in ascending time order) and apply
+// the reference's conventions: start from threshold^2 / index 0, strict '<', the target itself keeps
+// the threshold, distances leave as sqrt (src/Constellation.zig L700-703, L733, L744-747, L752-754)
+__global__ void k_screen_finalize(const double *part_d2, const unsigned *part_t, unsigned n_parts, const unsigned *list,
+                                  unsigned n_list, double threshold_sq, unsigned target, double *out_d,
+                                  unsigned *out_t)
+{
+    const unsigned li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= n_list) return;
+    const unsigned s = list[li];
+    double best = threshold_sq;
+    unsigned bt = 0;
+    if (s != target) {
+        for (unsigned k = 0; k < n_parts; ++k) {
+            const double d = part_d2[(size_t)k * n_list + li];
+            if (d < best) {
+                best = d;
+                bt = part_t[(size_t)k * n_list + li];
             }
         }
     }
+    out_d[s] = sqrt(best);
+    out_t[s] = bt;
+}
+
+__global__ void k_screen_fill(unsigned n, double threshold, double *out_d, unsigned *out_t)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_d[i] = threshold;
+    out_t[i] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// All-vs-all coarse conjunction screen on device-resident positions (coarseScreen,
+// bindings/python/src/conjunction.zig L11-150): per time step a cell list with cell edge =
+// threshold; every satellite probes the 27 cells around its own and reports partners with a larger
+// index that are closer than the threshold.  The reference builds one chained hash table per time
+// step on one CPU thread; here a chunk of time steps is processed at once, one table per step:
+//   k_cells_build : lane = (step, satellite): cell coordinates -> bucket -> push on the bucket's
+//                   chain (atomicExch on the head; chain order is irrelevant to the result set)
+//   k_cells_probe : lane = (step, satellite): walk the 27 chains, exact cell match (hash collisions),
+//                   distance test, append (s, other, t) through one atomic counter
+// Positions are read as stored (either layout); with the time-major layout a wave's loads coalesce.
+struct CellArgs {
+    const double *pos;
+    unsigned n_sats, n_times;
+    int layout;          // AZ_LAYOUT_*: 0 sat-major (s*n_times+t)*3, 1 time-major (t*stride+s)*3
+    size_t stride_sats;
+    const unsigned char *valid; // per satellite, may be null
+    double inv_cell, thr2;
+    unsigned t0, n_steps; // chunk of time steps
+    unsigned table_mask;  // buckets per step - 1
+    unsigned *head;       // [n_steps][table]
+    unsigned *next;       // [n_steps][n_sats]
+    unsigned *out_pairs;  // [max][2]
+    unsigned *out_t;      // [max]
+    unsigned long long *count;
+    unsigned long long max_results;
+    int skip_zero; // rows the propagator zero-filled (failed init / failed step) are not satellites
+};
+
+__device__ __forceinline__ unsigned az_cell_hash(int cx, int cy, int cz)
+{
+    // conjunction.zig L152-160 (Knuth multiplicative hash, wrapping arithmetic)
+    unsigned h = (unsigned)cx;
+    h *= 2654435761u;
+    h ^= (unsigned)cy;
+    h *= 2654435761u;
+    h ^= (unsigned)cz;
+    h *= 2654435761u;
+    return h;
+}
+
+__device__ __forceinline__ const double *az_cell_pos(const CellArgs &a, unsigned s, unsigned t)
+{
+    return a.pos + (a.layout == 0 ? ((size_t)s * a.n_times + t) * 3 : ((size_t)t * a.stride_sats + s) * 3);
+}
+
+__device__ __forceinline__ bool az_cell_of(const CellArgs &a, unsigned s, unsigned t, double r[3], int c[3])
+{
+    if (a.valid && a.valid[s] == 0) return false;
+    const double *q = az_cell_pos(a, s, t);
+    r[0] = q[0];
+    if (!(fabs(r[0]) <= 1.79769313486231570815e308)) return false; // isFinite(x), conjunction.zig L63
+    r[1] = q[1];
+    r[2] = q[2];
+    if (a.skip_zero && r[0] == 0.0 && r[1] == 0.0 && r[2] == 0.0) return false;
+    c[0] = (int)floor(r[0] * a.inv_cell);
+    c[1] = (int)floor(r[1] * a.inv_cell);
+    c[2] = (int)floor(r[2] * a.inv_cell);
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_cells_build(CellArgs a)
+{
+    const unsigned s = blockIdx.x * 256 + threadIdx.x;
+    const unsigned k = blockIdx.y;
+    if (s >= a.n_sats) return;
+    double r[3];
+    int c[3];
+    if (!az_cell_of(a, s, a.t0 + k, r, c)) return;
+    const unsigned h = az_cell_hash(c[0], c[1], c[2]) & a.table_mask;
+    a.next[(size_t)k * a.n_sats + s] = atomicExch(&a.head[(size_t)k * (a.table_mask + 1u) + h], s);
+}
+
+__global__ void __launch_bounds__(256) k_cells_probe(CellArgs a)
+{
+    const unsigned s = blockIdx.x * 256 + threadIdx.x;
+    const unsigned k = blockIdx.y;
+    if (s >= a.n_sats) return;
+    const unsigned t = a.t0 + k;
+    double r[3];
+    int c[3];
+    if (!az_cell_of(a, s, t, r, c)) return;
+    const unsigned *head = a.head + (size_t)k * (a.table_mask + 1u);
+    const unsigned *next = a.next + (size_t)k * a.n_sats;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const int nx = c[0] + dx, ny = c[1] + dy, nz = c[2] + dz;
+                unsigned idx = head[az_cell_hash(nx, ny, nz) & a.table_mask];
+                while (idx != 0xffffffffu) {
+                    const unsigned other = idx;
+                    idx = next[other];
+                    if (other <= s) continue;
+                    double q[3];
+                    int oc[3];
+                    az_cell_of(a, other, t, q, oc); // members of a chain are valid by construction
+                    if (oc[0] != nx || oc[1] != ny || oc[2] != nz) continue; // another cell in this bucket
+                    const double ex = r[0] - q[0], ey = r[1] - q[1], ez = r[2] - q[2];
+                    if (ex * ex + ey * ey + ez * ez < a.thr2) {
+                        const unsigned long long w = atomicAdd(a.count, 1ull);
+                        if (w < a.max_results) {
+                            a.out_pairs[2 * w] = s;
+                            a.out_pairs[2 * w + 1] = other;
+                            a.out_t[w] = t;
+                        }
+                    }
+                }
+            }
 }
 
 // rows of satellites whose init failed: zero state + the init error code at every time
 __global__ void k_fill_bad(const unsigned *list, unsigned n_list, const unsigned *flags, unsigned n_times,
                            double *pos, double *vel, unsigned char *err, const unsigned char *mask, int layout,
-                           size_t stride_sats)
+                           size_t stride_sats, int f32)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x; // time
     const unsigned li = blockIdx.y;
@@ -494,8 +725,14 @@ __global__ void k_fill_bad(const unsigned *list, unsigned n_list, const unsigned
     const unsigned s = list[li];
     if (mask && !mask[s]) return;
     const size_t ob = (layout == 0) ? ((size_t)s * n_times + i) * 3 : ((size_t)i * stride_sats + s) * 3;
-    pos[ob] = pos[ob + 1] = pos[ob + 2] = 0.0;
-    if (vel) vel[ob] = vel[ob + 1] = vel[ob + 2] = 0.0;
+    if (f32) {
+        float *p32 = reinterpret_cast<float *>(pos), *v32 = reinterpret_cast<float *>(vel);
+        p32[ob] = p32[ob + 1] = p32[ob + 2] = 0.0f;
+        if (vel) v32[ob] = v32[ob + 1] = v32[ob + 2] = 0.0f;
+    } else {
+        pos[ob] = pos[ob + 1] = pos[ob + 2] = 0.0;
+        if (vel) vel[ob] = vel[ob + 1] = vel[ob + 2] = 0.0;
+    }
     if (err) err[(size_t)s * n_times + i] = (unsigned char)AZ_FLAG_ERR(flags[s]);
 }
 

@@ -162,6 +162,52 @@ int32_t azh_propagate_device(azh_constellation *c, const double *times_min /*hos
  * the steady-state form used when the same grid is propagated repeatedly */
 int32_t azh_propagate_device_cached(azh_constellation *c, double *d_pos, double *d_vel, int32_t layout,
                                     size_t out_stride_sats, uint8_t *d_err, void *stream);
+/* fp32 OUTPUT variants (BASELINE config 5: 1M satellites x 10,000 steps would be 480 GB in fp64):
+ * identical fp64 arithmetic, every component rounded once when it is stored; d_pos/d_vel are
+ * float arrays of the same shapes.  No reference counterpart (astroz is fp64 only). */
+int32_t azh_propagate_device_f32(azh_constellation *c, const double *times_min, size_t n_times,
+                                 const double *epoch_offsets_min, float *d_pos, float *d_vel, int32_t output_mode,
+                                 double reference_jd, const uint8_t *sat_mask, int32_t layout,
+                                 size_t out_stride_sats, uint8_t *d_err, void *stream);
+int32_t azh_propagate_device_cached_f32(azh_constellation *c, float *d_pos, float *d_vel, int32_t layout,
+                                        size_t out_stride_sats, uint8_t *d_err, void *stream);
+
+/* Fused single-target conjunction screen = Constellation.screenConstellation
+ * (src/Constellation.zig L683-756; Python: Sgp4Constellation.screen_conjunction,
+ * bindings/python/astroz/__init__.py L625-632).  For every satellite the minimum distance (km) to
+ * satellite `target_index` over the grid and the grid index where it occurs; start value
+ * `threshold_km` / index 0 (a satellite that never comes closer, the target itself and failed
+ * members report exactly that); earliest index among equal minima.  Propagation and reduction
+ * are one kernel: no positions are written.  `reference_jd` is accepted for signature parity (the
+ * reference rotates to ECEF before differencing, which does not change a distance).  Deep-space
+ * members are screened too (the reference's routine covers SGP4 batches only). */
+int32_t azh_screen_target_host(azh_constellation *c, const double *times_min, size_t n_times,
+                               const double *epoch_offsets_min, size_t target_index, double threshold_km,
+                               double reference_jd, double *min_dist_km, uint32_t *min_t_index);
+int32_t azh_screen_target_device(azh_constellation *c, const double *times_min, size_t n_times,
+                                 const double *epoch_offsets_min, size_t target_index, double threshold_km,
+                                 double reference_jd, double *d_min_dist_km, uint32_t *d_min_t_index, void *stream);
+
+/* All-vs-all coarse screen = coarseScreen (bindings/python/src/conjunction.zig L11-150): every pair
+ * (s < other) closer than threshold_km at grid index t, found with a per-step cell list (cell edge =
+ * threshold).  Positions: fp64, either layout; rows with valid_mask[s] == 0 or a non-finite x are
+ * skipped (L53-66).  Results are written to HOST arrays sorted by (t, s, other); at most
+ * max_results (the first in that order), *n_found = number written.
+ *   _device: positions already in HBM (e.g. from azh_propagate_device)
+ *   _host  : positions in host memory (copied to `device` first)
+ *   azh_screen_all_host: propagate to TEME on the device and screen, positions never leave HBM
+ *                        (= screen(..., target=None), __init__.py L633-658) */
+int32_t azh_coarse_screen_device(const double *d_pos, size_t n_sats, size_t n_times, int32_t layout,
+                                 size_t stride_sats, double threshold_km, const uint8_t *valid_mask,
+                                 uint32_t *out_pairs, uint32_t *out_t_index, size_t max_results, size_t *n_found,
+                                 void *stream);
+int32_t azh_coarse_screen_host(const double *pos, size_t n_sats, size_t n_times, int32_t layout, size_t stride_sats,
+                               double threshold_km, const uint8_t *valid_mask, uint32_t *out_pairs,
+                               uint32_t *out_t_index, size_t max_results, size_t *n_found, int32_t device);
+int32_t azh_screen_all_host(azh_constellation *c, const double *times_min, size_t n_times,
+                            const double *epoch_offsets_min, double threshold_km, uint32_t *out_pairs,
+                            uint32_t *out_t_index, size_t max_results, size_t *n_found);
+
 /* Constellation.propagate (src/Constellation.zig L245-308): absolute times jd[t]+fr[t]; the
  * reference epoch is the first satellite's epoch (L139-140). Host pointers. */
 int32_t azh_propagate_jd_host(azh_constellation *c, const double *jd, const double *fr, size_t n_times,

@@ -1141,6 +1141,126 @@ void orc_propagate_constellation(const orc_sat *sats, size_t n_sats, const doubl
     free(cos_g);
 }
 
+/* ------------------------------------------------------------------ conjunction screening */
+/* Constellation.screenConstellation, src/Constellation.zig L683-756: time-outer loop, target and
+ * every satellite propagated per step, both rotated to ECEF (L719, L737), running minimum of the
+ * squared distance with a strict '<' (L744), start value threshold^2 / index 0 (L700-703), the
+ * target itself skipped (L735), sqrt at the end (L752-754).  Steps at which the target or the
+ * satellite fails are skipped (`catch continue`, L718, L730 -- the reference skips the satellite's
+ * whole batch of 8 there; this scalar restatement skips the satellite). */
+void orc_screen_target(const orc_sat *sats, size_t n_sats, const double *times, size_t n_times,
+                       const double *offsets, size_t target, double threshold, double reference_jd,
+                       const uint8_t *failed, double *out_min_dist, uint32_t *out_min_t)
+{
+    const double thr2 = threshold * threshold;
+    for (size_t i = 0; i < n_sats; i++) {
+        out_min_dist[i] = thr2;
+        out_min_t[i] = 0;
+    }
+    orc_carry *carry = (orc_carry *)malloc(sizeof(orc_carry) * (n_sats ? n_sats : 1));
+    for (size_t i = 0; i < n_sats; i++) orc_carry_init(&sats[i], &carry[i]);
+    for (size_t t = 0; t < n_times; t++) {
+        const double g = orc_julian_to_gmst(reference_jd + times[t] / 1440.0);
+        const double sg = sin(g), cg = cos(g);
+        double r[3], v[3], tp[3];
+        if (failed && failed[target]) continue;
+        /* the target is propagated statelessly here and with its carry in the loop below; both give
+         * the same state (tests/test_oracle_golden.py G9) */
+        if (orc_sat_propagate(&sats[target], times[t] + (offsets ? offsets[target] : 0.0), r, v) != ORC_OK) continue;
+        orc_eci_to_ecef(r, sg, cg, tp);
+        for (size_t s = 0; s < n_sats; s++) {
+            if (s == target) continue;
+            if (failed && failed[s]) continue;
+            if (orc_sat_propagate_carry(&sats[s], times[t] + (offsets ? offsets[s] : 0.0), &carry[s], r, v) != ORC_OK) continue;
+            double e[3];
+            orc_eci_to_ecef(r, sg, cg, e);
+            const double dx = tp[0] - e[0], dy = tp[1] - e[1], dz = tp[2] - e[2];
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (d2 < out_min_dist[s]) {
+                out_min_dist[s] = d2;
+                out_min_t[s] = (uint32_t)t;
+            }
+        }
+    }
+    for (size_t i = 0; i < n_sats; i++) out_min_dist[i] = sqrt(out_min_dist[i]);
+    free(carry);
+}
+
+/* spatialHash, bindings/python/src/conjunction.zig L152-160 */
+static uint32_t spatial_hash(int32_t cx, int32_t cy, int32_t cz)
+{
+    uint32_t h = (uint32_t)cx;
+    h *= 2654435761u;
+    h ^= (uint32_t)cy;
+    h *= 2654435761u;
+    h ^= (uint32_t)cz;
+    h *= 2654435761u;
+    return h;
+}
+
+/* coarseScreen, bindings/python/src/conjunction.zig L11-150: positions satellite-major
+ * (s*n_times + t)*3; per step a chained hash table of cells (edge = threshold, 2^16 buckets), every
+ * satellite walks the chains of its 27 neighbour cells and reports partners with a larger index in
+ * exactly that cell closer than the threshold.  Same traversal order as the reference. */
+size_t orc_coarse_screen(const double *positions, size_t num_sats, size_t num_times, double threshold,
+                         const uint8_t *valid_mask, uint32_t *out_pairs, uint32_t *out_t, size_t max_results)
+{
+    const double inv_cell = 1.0 / threshold, thr2 = threshold * threshold;
+    const uint32_t TABLE = 1u << 16, MASK = TABLE - 1u, EMPTY = 0xffffffffu;
+    size_t count = 0;
+    int32_t *cx = (int32_t *)malloc(sizeof(int32_t) * 3 * (num_sats ? num_sats : 1));
+    int32_t *cy = cx + num_sats, *cz = cx + 2 * num_sats;
+    uint32_t *hashes = (uint32_t *)malloc(sizeof(uint32_t) * (num_sats ? num_sats : 1));
+    uint32_t *head = (uint32_t *)malloc(sizeof(uint32_t) * TABLE);
+    uint32_t *next = (uint32_t *)malloc(sizeof(uint32_t) * (num_sats ? num_sats : 1));
+    for (size_t t = 0; t < num_times; t++) {
+        memset(head, 0xff, sizeof(uint32_t) * TABLE);
+        for (size_t s = 0; s < num_sats; s++) {
+            if (valid_mask && !valid_mask[s]) { hashes[s] = EMPTY; continue; }
+            const double *q = positions + (s * num_times + t) * 3;
+            if (!isfinite(q[0])) { hashes[s] = EMPTY; continue; }
+            cx[s] = (int32_t)floor(q[0] * inv_cell);
+            cy[s] = (int32_t)floor(q[1] * inv_cell);
+            cz[s] = (int32_t)floor(q[2] * inv_cell);
+            const uint32_t h = spatial_hash(cx[s], cy[s], cz[s]) & MASK;
+            hashes[s] = h;
+            next[s] = head[h];
+            head[h] = (uint32_t)s;
+        }
+        for (size_t s = 0; s < num_sats; s++) {
+            if (hashes[s] == EMPTY) continue;
+            const double *q = positions + (s * num_times + t) * 3;
+            for (int dx = -1; dx <= 1; dx++)
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dz = -1; dz <= 1; dz++) {
+                        const int32_t nx = cx[s] + dx, ny = cy[s] + dy, nz = cz[s] + dz;
+                        uint32_t idx = head[spatial_hash(nx, ny, nz) & MASK];
+                        while (idx != EMPTY) {
+                            const uint32_t other = idx;
+                            idx = next[idx];
+                            if (other <= s) continue;
+                            if (cx[other] != nx || cy[other] != ny || cz[other] != nz) continue;
+                            const double *o = positions + ((size_t)other * num_times + t) * 3;
+                            const double ex = q[0] - o[0], ey = q[1] - o[1], ez = q[2] - o[2];
+                            if (ex * ex + ey * ey + ez * ez < thr2) {
+                                if (count >= max_results) goto done;
+                                out_pairs[2 * count] = (uint32_t)s;
+                                out_pairs[2 * count + 1] = other;
+                                out_t[count] = (uint32_t)t;
+                                count++;
+                            }
+                        }
+                    }
+        }
+    }
+done:
+    free(cx);
+    free(hashes);
+    free(head);
+    free(next);
+    return count;
+}
+
 /* ------------------------------------------------------------------ field access by name (tests) */
 #define F(n)                                                                                                 \
     if (!strcmp(name, #n)) return (double)s->n

@@ -130,6 +130,15 @@ void orc_propagate_constellation(const orc_sat *sats, size_t n_sats,
 
 int orc_max_threads(void);
 
+/* Conjunction screening: single-target minimum distances (Constellation.zig L683-756)
+ * and the all-vs-all cell-list screen over satellite-major positions (conjunction.zig L11-150). */
+void orc_screen_target(const orc_sat *sats, size_t n_sats, const double *times_min, size_t n_times,
+                       const double *offsets_min, size_t target, double threshold_km, double reference_jd,
+                       const uint8_t *failed /* per satellite: init failed, never propagated; may be NULL */,
+                       double *out_min_dist, uint32_t *out_min_t);
+size_t orc_coarse_screen(const double *positions, size_t num_sats, size_t num_times, double threshold_km,
+                         const uint8_t *valid_mask, uint32_t *out_pairs, uint32_t *out_t, size_t max_results);
+
 #ifdef __cplusplus
 }
 #endif

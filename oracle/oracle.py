@@ -57,6 +57,12 @@ def lib():
             C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int]
         L.orc_propagate_constellation.restype = None
         L.orc_max_threads.restype = C.c_int
+        L.orc_screen_target.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_screen_target.restype = None
+        L.orc_coarse_screen.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_size_t]
+        L.orc_coarse_screen.restype = C.c_size_t
         _lib = L
     return _lib
 
@@ -161,6 +167,35 @@ class Catalog:
             None if vel is None else vel.ctypes.data, mode, float(reference_jd),
             None if m is None else m.ctypes.data, layout, st, err.ctypes.data, int(threads))
         return err, pos, vel
+
+
+def _catalog_screen_target(self, times_min, target, threshold, offsets_min=None, reference_jd=0.0):
+    """(min_dist (n,), min_t (n,) u32): Constellation.screenConstellation (Constellation.zig L683-756)."""
+    times = np.ascontiguousarray(times_min, dtype=np.float64)
+    off = None if offsets_min is None else np.ascontiguousarray(offsets_min, dtype=np.float64)
+    failed = np.ascontiguousarray(self.init_rc != 0, dtype=np.uint8)
+    d = np.zeros(self.n, dtype=np.float64)
+    ti = np.zeros(self.n, dtype=np.uint32)
+    lib().orc_screen_target(C.addressof(self._buf), self.n, times.ctypes.data, len(times),
+                            None if off is None else off.ctypes.data, int(target), float(threshold),
+                            float(reference_jd), failed.ctypes.data, d.ctypes.data, ti.ctypes.data)
+    return d, ti
+
+
+Catalog.screen_target = _catalog_screen_target
+
+
+def coarse_screen(positions, threshold, valid_mask=None, max_results=10_000_000):
+    """positions (n_sats, n_times, 3) float64 satellite-major -> (pairs (k,2) u32, t (k,) u32) in the
+    reference's traversal order (conjunction.zig L11-150)."""
+    pos = np.ascontiguousarray(positions, dtype=np.float64)
+    ns, nt = pos.shape[0], pos.shape[1]
+    pairs = np.zeros((max_results, 2), dtype=np.uint32)
+    tt = np.zeros(max_results, dtype=np.uint32)
+    m = None if valid_mask is None else np.ascontiguousarray(valid_mask, dtype=np.uint8)
+    k = lib().orc_coarse_screen(pos.ctypes.data, ns, nt, float(threshold), None if m is None else m.ctypes.data,
+                                pairs.ctypes.data, tt.ctypes.data, max_results)
+    return pairs[:k].copy(), tt[:k].copy()
 
 
 def gstime(jd):

@@ -144,3 +144,46 @@ def test_carry_equals_fresh(orc, golden):
             rc, r, v = c.propagate_one(s, t)
             np.testing.assert_allclose(pos[s, k], r, atol=1e-9, rtol=0)
             np.testing.assert_allclose(vel[s, k], v, atol=1e-12, rtol=0)
+
+
+def test_oracle_screens_vs_brute_force(orc):
+    """SURVEY 8 f3.  The reference holds no test vectors for screenConstellation / coarseScreen, so the
+    oracle's restatements are pinned against an independent brute-force evaluation (numpy, all
+    pairs / all times) of the positions of the golden-pinned propagator."""
+    from astroz_amd import synth
+    pairs = synth.synth_catalog(n_near=260, n_deep=25, seed=3)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    times = np.arange(0.0, 180.0, 1.5)
+    off = (synth.START_JD - cat.epoch_jd) * 1440.0
+    e, pos, _ = cat.propagate(times, off, velocities=False, layout=orc.SAT_MAJOR)
+    assert not e.any()
+    # single target (Constellation.zig L683-756): distances are frame independent
+    target, thr = 11, 2500.0
+    d, ti = cat.screen_target(times, target, thr, off, reference_jd=synth.START_JD)
+    dist = np.linalg.norm(pos - pos[target][None], axis=2)
+    dmin = dist.min(axis=1)
+    exp = np.where(dmin < thr, dmin, thr)
+    exp[target] = thr
+    assert np.abs(d - exp).max() < 1e-9
+    hit = (dmin < thr) & (np.arange(cat.n) != target)
+    assert hit.sum() > 3
+    assert (ti[hit] == dist.argmin(axis=1)[hit]).all()
+    assert (ti[~hit] == 0).all()
+    # all-vs-all (conjunction.zig L11-150)
+    thr = 150.0
+    pp, tt = orc.coarse_screen(pos, thr)
+    got = sorted(zip(tt.tolist(), pp[:, 0].tolist(), pp[:, 1].tolist()))
+    exp = []
+    for t in range(len(times)):
+        dd = np.linalg.norm(pos[:, t, None, :] - pos[None, :, t, :], axis=2)
+        a, b = np.nonzero(np.triu(dd < thr, k=1))
+        exp += [(t, int(x), int(y)) for x, y in zip(a, b)]
+    assert len(exp) > 10
+    assert got == sorted(exp)
+    # mask / non-finite rows are skipped, max_results truncates
+    mask = np.ones(cat.n, dtype=np.uint8)
+    mask[got[0][1]] = 0
+    pp2, tt2 = orc.coarse_screen(pos, thr, mask)
+    assert all(got[0][1] not in p for p in pp2.tolist())
+    pp3, _ = orc.coarse_screen(pos, thr, max_results=4)
+    assert len(pp3) == 4

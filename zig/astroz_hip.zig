@@ -39,3 +39,25 @@ pub extern "c" fn azh_synchronize(h: ?*Handle) i32;
 pub extern "c" fn azh_set_time_tile(h: ?*Handle, sgp4_tile: u32, sdp4_tile: u32) i32;
 pub extern "c" fn azh_set_timing(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_last_kernel_ms(h: ?*Handle) f64;
+
+// fp32 outputs (config 5)
+pub extern "c" fn azh_propagate_device_f32(h: ?*Handle, times_min: [*]const f64, n_times: usize, epoch_offsets_min: ?[*]const f64,
+    d_pos: [*]f32, d_vel: ?[*]f32, output_mode: i32, reference_jd: f64, sat_mask: ?[*]const u8, layout: i32,
+    out_stride_sats: usize, d_err: ?[*]u8, stream: ?*anyopaque) i32;
+pub extern "c" fn azh_propagate_device_cached_f32(h: ?*Handle, d_pos: [*]f32, d_vel: ?[*]f32, layout: i32,
+    out_stride_sats: usize, d_err: ?[*]u8, stream: ?*anyopaque) i32;
+
+// conjunction screening: Constellation.screenConstellation (src/Constellation.zig L683-756) and
+// coarseScreen (bindings/python/src/conjunction.zig L11-150)
+pub extern "c" fn azh_screen_target_host(h: ?*Handle, times_min: [*]const f64, n_times: usize, epoch_offsets_min: ?[*]const f64,
+    target_index: usize, threshold_km: f64, reference_jd: f64, min_dist_km: [*]f64, min_t_index: [*]u32) i32;
+pub extern "c" fn azh_screen_target_device(h: ?*Handle, times_min: [*]const f64, n_times: usize, epoch_offsets_min: ?[*]const f64,
+    target_index: usize, threshold_km: f64, reference_jd: f64, d_min_dist_km: [*]f64, d_min_t_index: [*]u32, stream: ?*anyopaque) i32;
+pub extern "c" fn azh_coarse_screen_device(d_pos: [*]const f64, n_sats: usize, n_times: usize, layout: i32, stride_sats: usize,
+    threshold_km: f64, valid_mask: ?[*]const u8, out_pairs: [*]u32, out_t_index: [*]u32, max_results: usize, n_found: *usize,
+    stream: ?*anyopaque) i32;
+pub extern "c" fn azh_coarse_screen_host(pos: [*]const f64, n_sats: usize, n_times: usize, layout: i32, stride_sats: usize,
+    threshold_km: f64, valid_mask: ?[*]const u8, out_pairs: [*]u32, out_t_index: [*]u32, max_results: usize, n_found: *usize,
+    device: i32) i32;
+pub extern "c" fn azh_screen_all_host(h: ?*Handle, times_min: [*]const f64, n_times: usize, epoch_offsets_min: ?[*]const f64,
+    threshold_km: f64, out_pairs: [*]u32, out_t_index: [*]u32, max_results: usize, n_found: *usize) i32;
