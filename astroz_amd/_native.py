@@ -51,6 +51,27 @@ def _detail(code):
     return ""
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels ship their own libamdhip64 / libhsa-runtime64
+    and ask for them by unversioned file name, so a process that loads /opt/rocm's runtime first (through
+    this library) and imports torch afterwards ends up with two ROCr instances, and the second one
+    finds no device.  When torch is installed, bind this library to torch's copy (same SONAME,
+    libamdhip64.so.7) -- device pointers and streams are then shared with torch tensors in either
+    import order.  ASTROZ_AMD_SYSTEM_HIP=1 keeps /opt/rocm's runtime (processes that never import torch)."""
+    if os.environ.get("ASTROZ_AMD_SYSTEM_HIP"):
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load libastroz_hip.so.  Fails loudly if the HIP extension has not been built."""
     global _lib
@@ -60,6 +81,7 @@ def lib():
         raise ImportError(
             "astroz_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, sz, dbl, i32, u32 = C.c_void_p, C.c_size_t, C.c_double, C.c_int32, C.c_uint32
     L.astroz_version.restype = u32
