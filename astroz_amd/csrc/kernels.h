@@ -461,6 +461,20 @@ struct ColdUniform {
     __device__ __forceinline__ double operator()(int k) const { return c[k]; }
     __device__ __forceinline__ void set(int k, double v) { c[k] = az_uniform(v); }
 };
+// ... or one LDS word per constant, read by all 64 lanes at once (broadcast ds_read_b64: no VALU
+// slot, no SGPRs -- the 33 uniform doubles of a satellite do not fit the SGPR file next to the
+// kernel's pointers, and every SGPR spilled to a VGPR lane costs a v_readlane per use)
+struct ColdBroadcast {
+    double *p;
+    __device__ __forceinline__ double operator()(int k) const { return p[k]; }
+    __device__ __forceinline__ void set(int k, double v) const { p[k] = v; }
+};
+#ifndef AZ_ROWS_TLDS
+#define AZ_ROWS_TLDS 512 /* k_rows: time values staged in LDS per refill (0 = per-iteration global loads) */
+#endif
+#ifndef AZ_ROWS_COLD
+#define AZ_ROWS_COLD 1 /* k_rows: once-per-step constants 0 = SGPRs (v_readfirstlane), 1 = LDS broadcast */
+#endif
 
 // SINK: what happens to a result -- 0: fp64 rows, 1: fp32 rows, 2: fused single-target conjunction
 // screen (nothing is stored; each lane keeps the running minimum of |r - r_target|^2 over its grid
@@ -501,7 +515,16 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     const unsigned t_lo = blockIdx.y * p.tile;
     const unsigned t_hi = min(t_lo + p.tile, p.n_times);
     Sgp4Lane e;
-    ColdUniform cold;
+#if AZ_ROWS_TLDS > 0 || AZ_ROWS_COLD
+    __shared__ __attribute__((aligned(16))) double rows_lds[(AZ_ROWS_TLDS > 0 ? AZ_ROWS_TLDS : 0) + C_NUM_MAX + 2];
+#endif
+#if AZ_ROWS_COLD
+    typedef ColdBroadcast ColdT;
+    ColdT cold{rows_lds + (AZ_ROWS_TLDS > 0 ? AZ_ROWS_TLDS : 0)};
+#else
+    typedef ColdUniform ColdT;
+    ColdT cold;
+#endif
     az_load_sgp4(p.el, p.n_pad, s, fl, e, cold);
     e.mdot = az_uniform(e.mdot); e.argpdot = az_uniform(e.argpdot); e.nodedot = az_uniform(e.nodedot);
     e.xnodcf = az_uniform(e.xnodcf); e.aycof = az_uniform(e.aycof); e.xlcof = az_uniform(e.xlcof);
@@ -517,20 +540,50 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     c.sdA = c.pW = c.qW = 0.0;
     c.cdA = 1.0;
     const RotK rk = az_rotk();
-    out_t *prow = reinterpret_cast<out_t *>(p.pos) + (size_t)s * p.n_times * 3;
-    out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + (size_t)s * p.n_times * 3 : nullptr;
+#if defined(AZ_ABLATE) && AZ_ABLATE == 3 /* tuning experiment: all rows alias 64 rows (L2-resident window) */
+    const size_t srow = s & 63u;
+#else
+    const size_t srow = s;
+#endif
+    out_t *prow = reinterpret_cast<out_t *>(p.pos) + srow * p.n_times * 3;
+    out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + srow * p.n_times * 3 : nullptr;
     double best_d2 = __builtin_inf();
     unsigned best_t = 0xffffffffu;
     // the time value of the NEXT iteration is fetched before this iteration's stores are issued, so
     // the s_waitcnt in front of its first use (vmcnt counts in issue order) never has to wait for
     // those stores to be acknowledged by memory
+#if defined(AZ_STAGGER) && AZ_STAGGER > 0
+    // tuning experiment: de-phase the waves so that their store bursts do not coincide
+    {
+        const unsigned h = (blockIdx.x * 2654435761u) >> 25; // 0..127
+        for (unsigned q = 0; q < (h * AZ_STAGGER) / 128u; ++q) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+#if AZ_ROWS_TLDS > 0
+    // Time values go through LDS (AZ_ROWS_TLDS grid points per refill): the loop then holds no
+    // vector-memory LOAD at all.  vmcnt counts loads and stores in issue order, so a load's
+    // s_waitcnt also waits for every output store issued before it -- one load per iteration
+    // serialises the arithmetic against the write stream; ds_read waits on lgkmcnt only.
+#else
     double t_next = p.times[min(t_lo + lane, t_hi - 1)];
+#endif
 #pragma unroll 1
     for (unsigned base = t_lo; base < t_hi; base += 64) {
         const unsigned i = base + lane;
         const bool live = i < t_hi;
+#if AZ_ROWS_TLDS > 0
+        const unsigned kk = (base - t_lo) & (AZ_ROWS_TLDS - 1u);
+        if (kk == 0) {
+            az_wave_lds_fence();
+#pragma unroll
+            for (unsigned j = 0; j < AZ_ROWS_TLDS; j += 64) rows_lds[j + lane] = p.times[min(i + j, t_hi - 1)];
+            az_wave_lds_fence();
+        }
+        const double t = rows_lds[kk + lane] + off;
+#else
         const double t = t_next + off;
         t_next = p.times[min(i + 64, t_hi - 1)];
+#endif
         double r[3], v[3];
         // full re-seed of the carried pairs at the start and every 64 iterations (4,096 grid points)
         const bool first = ((base - t_lo) & (64u * 64u - 1u)) == 0;
@@ -538,7 +591,7 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
         r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
         (void)first;
 #else
-        az_sgp4_step<VEL, ColdUniform, true>(e, cold, p.el, p.n_pad, s, p.g, rk, t, first, c, r, v);
+        az_sgp4_step<VEL, ColdT, true>(e, cold, p.el, p.n_pad, s, p.g, rk, t, first, c, r, v);
 #endif
         if (SINK == AZ_SINK_SCREEN) {
             // distances are frame-independent (ECEF is a rotation of TEME about z), so the screen
@@ -558,6 +611,9 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
 #else
         if (live) {
 #endif
+            // direct 24-byte (12-byte) pieces per lane: contiguous across the wave.  (Measured: a
+            // transpose through LDS into 16-byte pieces per lane is slower, 0.41 vs 0.36 ms -- the
+            // lgkmcnt round trip in front of the stores costs more than the fragmented requests.)
             az_put3(prow + (size_t)i * 3, r);
             if (VEL) az_put3(vrow + (size_t)i * 3, v);
         }
