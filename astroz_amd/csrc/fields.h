@@ -13,7 +13,7 @@
     X(no_unkozai) X(a) X(sinio) X(cosio) X(con41) X(x1mth2) X(x7thm1)                              \
     X(mdot) X(argpdot) X(nodedot)                                                                  \
     X(cc1) X(bc4) X(bc5) X(t2cof) X(omgcof) X(xnodcf) X(xlcof) X(xmcof) X(aycof) X(eta)            \
-    X(delmo) X(sinmao) X(d2) X(d3) X(d4) X(t3cof) X(t4cof) X(t5cof) X(a_base)
+    X(delmo) X(sinmao) X(d2) X(d3) X(d4) X(t3cof) X(t4cof) X(t5cof) X(a_base) X(sqrt_a_base)
 
 #define AZ_DEEP_FIELDS(X)                                                                          \
     X(se2) X(se3) X(si2) X(si3) X(sl2) X(sl3) X(sl4) X(sgh2) X(sgh3) X(sgh4) X(sh2) X(sh3)         \

@@ -148,6 +148,7 @@ AZ_DEVICE unsigned az_init_satellite(const double raw[AZ_NUM_RAW], const AzGrav 
     {
         const double ratio = g.xke / no_unkozai;
         S(a_base, cbrt(ratio * ratio));
+        S(sqrt_a_base, cbrt(ratio)); // sqrt(am) = sqrt_a_base * |tempa|: the step needs no square root of am
     }
 
     // higher-order drag (near-earth with perigee >= 220 km only)

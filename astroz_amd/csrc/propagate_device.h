@@ -92,7 +92,7 @@ AZ_DEVICE void az_load_sgp4(const double *__restrict__ el, size_t n_pad, size_t 
                   e.k_rv);
     e.x1mth2 = L(x1mth2);
     CS(C_cc1, L(cc1)); CS(C_bc4, L(bc4)); CS(C_t2cof, L(t2cof)); CS(C_ecco, L(ecco));
-    CS(C_a_base, L(a_base)); CS(C_no_unkozai, L(no_unkozai));
+    CS(C_a_base, L(sqrt_a_base)); CS(C_no_unkozai, L(no_unkozai)); // C_a_base slot: sqrt((xke/no)^(2/3))
     const bool ho = !(flags & AZ_FLAG_ISIMP);
     CS(C_omgcof, ho ? L(omgcof) : 0.0); CS(C_eta, L(eta)); CS(C_xmcof, ho ? L(xmcof) : 0.0);
     CS(C_delmo, L(delmo)); CS(C_bc5, ho ? L(bc5) : 0.0); CS(C_sinmao, L(sinmao));
@@ -122,12 +122,14 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
     // Newton on  E - aynl*cosE + axnl*sinE = u  with eps = E - u carried instead of E.
     // Exit test: the step after d would be ~ (el/2) d^2, so stop once el2 * d^4 < (2e-13)^2.
     const double el2 = fma(axnl, axnl, aynl * aynl);
-    double s = su0, c = cu0, eps = 0.0;
+    double s = su0, c = cu0, eps = 0.0, rden = 1.0;
+    bool converged = false; // wave-uniform
 #pragma unroll 1
     for (int it = 0; it < 10; ++it) {
         const double den = fma(-s, aynl, fma(-c, axnl, 1.0));
         const double num = fma(axnl, s, fma(-aynl, c, -eps));
-        double d = num * az_rcp1(den);
+        rden = az_rcp1(den);
+        double d = num * rden;
         d = fmin(fmax(d, -0.95), 0.95);
         eps += d;
         if (it == 0)
@@ -135,25 +137,44 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
         else
             az_rotate_le_tiny(s, c, d, rk);
         const double d2 = d * d;
-        if (!az_any(el2 * d2 * d2 >= 4.0e-26)) break;
+        if (!az_any(el2 * d2 * d2 >= 4.0e-26)) {
+            converged = true;
+            break;
+        }
     }
 
     const double inv_am = ra * ra;
     const double ecose = fma(axnl, c, aynl * s);
     const double esine = fma(axnl, s, -(aynl * c));
-    const double omel2 = 1.0 - el2;
-    const double rb = az_rsqrt(omel2);
-    const double betal = omel2 * rb;
     const double ome = 1.0 - ecose;
-    const double inv_ome = az_rcp(ome); // = am / rl
+    // 1/(1 - ecose): `den` of the last Newton trip was 1 - ecose BEFORE the final rotation by d, so
+    // its reciprocal is off by el*d relative (plus rcp1's 2^-46); one Newton step squares that:
+    // (el d)^2 <= el sqrt(el2 d^4) < 2e-13 el at loop exit -- below 1e-9 km in position
+    double inv_ome = fma(rden, fma(-ome, rden, 1.0), rden); // = am / rl
+    if (!converged) inv_ome = az_rcp(ome);                  // 10 trips without convergence: no such bound
     const double rl = am * ome;
-    const double est = esine * az_rcp(1.0 + betal);
+    // betal = sqrt(1 - el2), 1/(1 - el2) and 1/(1 + betal).  Nine members in ten have el2 < 1e-5:
+    // three short series in x = el2 (truncation < 1e-16 relative) replace a reciprocal square root and
+    // a reciprocal; the vote is wave-uniform by construction in the lane = time kernel
+    double betal, inv_omel2, inv_1pb;
+    if (!az_any(el2 > 1.0e-5)) {
+        betal = fma(el2, fma(el2, -0.125, -0.5), 1.0);                 // 1 - x/2 - x^2/8        (- x^3/16)
+        inv_omel2 = fma(el2, fma(el2, fma(el2, 1.0, 1.0), 1.0), 1.0);  // 1 + x + x^2 + x^3      (+ x^4)
+        inv_1pb = fma(el2, fma(el2, 0.0625, 0.125), 0.5);              // 1/2 + x/8 + x^2/16     (+ 5x^3/128)
+    } else {
+        const double omel2 = 1.0 - el2;
+        const double rb = az_rsqrt(omel2);
+        betal = omel2 * rb;
+        inv_omel2 = rb * rb;
+        inv_1pb = az_rcp(1.0 + betal);
+    }
+    const double est = esine * inv_1pb;
     const double sinu = inv_ome * (s - aynl - axnl * est);
     const double cosu = inv_ome * (c - axnl + aynl * est);
     const double sin2u = 2.0 * sinu * cosu;
     const double cos2u = fma(-2.0 * sinu, sinu, 1.0);
 
-    const double inv_pl = inv_am * rb * rb;
+    const double inv_pl = inv_am * inv_omel2;
     const double temp1 = g.half_j2 * inv_pl;
     const double temp2 = temp1 * inv_pl;
 
@@ -273,10 +294,16 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const Cold &cold, const double *_
     const double tempe = fma(CL(C_bc5), smm - CL(C_sinmao), CL(C_bc4) * t);
     const double templ = fma(CL(C_t2cof), t2, fma(CL(C_t3cof), t3, t4 * fma(t, CL(C_t5cof), CL(C_t4cof))));
 
-    const double am = CL(C_a_base) * tempa * tempa;
+    // am = a_base tempa^2 (Sgp4Batch.zig L146), so sqrt(am) = sqrt(a_base) |tempa| exactly: ONE
+    // reciprocal R = 1/(sqrt(am) (1 - em^2)) yields 1/sqrt(am) = R (1 - em^2) and
+    // temp = 1/(am (1 - em^2)) = R / sqrt(am) -- instead of a reciprocal square root plus a reciprocal
+    const double sqrt_am = CL(C_a_base) * fabs(tempa);
+    const double am = sqrt_am * sqrt_am;
     const double em = fmax(CL(C_ecco) - tempe, 1.0e-6);
-    const double ra = az_rsqrt(am);
-    const double temp = ra * ra * az_rcp(fma(-em, em, 1.0));
+    const double omem2 = fma(-em, em, 1.0);
+    const double R = az_rcp(sqrt_am * omem2);
+    const double ra = R * omem2;
+    const double temp = ra * R;
 
     const double axnl = em * cw;
     const double aynl = fma(em, sw, temp * e.aycof);
