@@ -38,7 +38,8 @@ enum AzField {
 #define AZ_FLAG_DEEP (1u << 8)
 #define AZ_FLAG_ISIMP (1u << 9)
 #define AZ_FLAG_IREZ(f) (((f) >> 10) & 3u)
-//  bits 12-13 eccentricity class of near-earth satellites (0: e < 0.0075, 1: e < 0.1, 2: rest);
+//  bits 12-13 eccentricity class of near-earth satellites (0: e < 0.0025 [el2 < 1.6e-5: the near-circular
+//             Kepler path], 1: e < 0.0075, 2: e < 0.1, 3: rest);
 //             classes 1-2 need more Kepler-Newton trips / wider rotation tiers; the host groups
 //             them inside each workgroup so they do not drag whole waves through the slow path
 #define AZ_FLAG_ECLASS(f) (((f) >> 12) & 3u)

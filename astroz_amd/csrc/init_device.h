@@ -169,7 +169,7 @@ AZ_DEVICE unsigned az_init_satellite(const double raw[AZ_NUM_RAW], const AzGrav 
         S(t5cof, 0.2 * (3.0 * d4 + 12.0 * cc1 * d3 + 6.0 * d2 * d2 + 15.0 * cc1sq * (2.0 * d2 + cc1sq)));
     }
     if (isimp) flags |= AZ_FLAG_ISIMP;
-    flags |= (ecco < 0.0075 ? 0u : (ecco < 0.1 ? 1u : 2u)) << 12;
+    flags |= (ecco < 0.0025 ? 0u : (ecco < 0.0075 ? 1u : (ecco < 0.1 ? 2u : 3u))) << 12;
 
     // ---------------------------------------------------------------- deep space
     unsigned irez = 0;

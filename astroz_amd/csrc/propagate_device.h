@@ -122,52 +122,72 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
     // Newton on  E - aynl*cosE + axnl*sinE = u  with eps = E - u carried instead of E.
     // Exit test: the step after d would be ~ (el/2) d^2, so stop once el2 * d^4 < (2e-13)^2.
     const double el2 = fma(axnl, axnl, aynl * aynl);
-    double s = su0, c = cu0, eps = 0.0, rden = 1.0;
-    bool converged = false; // wave-uniform
-#pragma unroll 1
-    for (int it = 0; it < 10; ++it) {
-        const double den = fma(-s, aynl, fma(-c, axnl, 1.0));
-        const double num = fma(axnl, s, fma(-aynl, c, -eps));
-        rden = az_rcp1(den);
-        double d = num * rden;
-        d = fmin(fmax(d, -0.95), 0.95);
-        eps += d;
-        if (it == 0)
-            az_rotate_le_small(s, c, d, rk);
-        else
-            az_rotate_le_tiny(s, c, d, rk);
-        const double d2 = d * d;
-        if (!az_any(el2 * d2 * d2 >= 4.0e-26)) {
-            converged = true;
-            break;
-        }
-    }
-
-    const double inv_am = ra * ra;
-    const double ecose = fma(axnl, c, aynl * s);
-    const double esine = fma(axnl, s, -(aynl * c));
-    const double ome = 1.0 - ecose;
-    // 1/(1 - ecose): `den` of the last Newton trip was 1 - ecose BEFORE the final rotation by d, so
-    // its reciprocal is off by el*d relative (plus rcp1's 2^-46); one Newton step squares that:
-    // (el d)^2 <= el sqrt(el2 d^4) < 2e-13 el at loop exit -- below 1e-9 km in position
-    double inv_ome = fma(rden, fma(-ome, rden, 1.0), rden); // = am / rl
-    if (!converged) inv_ome = az_rcp(ome);                  // 10 trips without convergence: no such bound
-    const double rl = am * ome;
-    // betal = sqrt(1 - el2), 1/(1 - el2) and 1/(1 + betal).  Nine members in ten have el2 < 1e-5:
-    // three short series in x = el2 (truncation < 1e-16 relative) replace a reciprocal square root and
-    // a reciprocal; the vote is wave-uniform by construction in the lane = time kernel
-    double betal, inv_omel2, inv_1pb;
-    if (!az_any(el2 > 1.0e-5)) {
+    double s = su0, c = cu0, rden;
+    double inv_ome, betal, inv_omel2, inv_1pb, ecose, esine, ome;
+    // Nine catalog members in ten have el2 < 1.6e-5 (el < 4e-3); the vote is wave-uniform by
+    // construction in the lane = time kernel, and in the lane = satellite kernel the host sorts each
+    // workgroup by eccentricity class.
+    if (!az_any(el2 > 1.6e-5)) {
+        // near-circular: one Newton step from E0 = u (|d0| <= el/(1-el)), then one CHORD step with the
+        // same reciprocal: error after step 1 is (el/2) d0^2 <= 3.2e-8, the stale slope is off by
+        // el*d0 <= 1.6e-5 relative, so step 2 leaves <= 5e-13 rad (4e-9 km); the rotation by d1 is
+        // first order (d1^2/2 < 2e-16).  37 instructions instead of two full trips (62).
+        rden = az_rcp1(fma(-s, aynl, fma(-c, axnl, 1.0)));
+        const double d0 = fma(axnl, s, -(aynl * c)) * rden;
+        az_rotate_le_tiny(s, c, d0, rk); // |d0| < 2^-10 for e < 1e-3, else the generic vote picks `small`
+        const double d1 = fma(axnl, s, fma(-aynl, c, -d0)) * rden;
+        const double s1 = fma(c, d1, s);
+        c = fma(-s, d1, c);
+        s = s1;
+        ecose = fma(axnl, c, aynl * s);
+        esine = fma(axnl, s, -(aynl * c));
+        ome = 1.0 - ecose;
+        // 1/(1 - ecose) from the reciprocal of step 1 (off by el*(d0+d1) ~ 1e-5): two Newton steps
+        inv_ome = fma(rden, fma(-ome, rden, 1.0), rden);
+        inv_ome = fma(inv_ome, fma(-ome, inv_ome, 1.0), inv_ome);
+        // betal = sqrt(1 - x), 1/(1 - x), 1/(1 + betal), x = el2: short series, truncation < 3e-16
         betal = fma(el2, fma(el2, -0.125, -0.5), 1.0);                 // 1 - x/2 - x^2/8        (- x^3/16)
         inv_omel2 = fma(el2, fma(el2, fma(el2, 1.0, 1.0), 1.0), 1.0);  // 1 + x + x^2 + x^3      (+ x^4)
         inv_1pb = fma(el2, fma(el2, 0.0625, 0.125), 0.5);              // 1/2 + x/8 + x^2/16     (+ 5x^3/128)
     } else {
+        // Exit test: the step after d would be ~ (el/2) d^2, so stop once el2 * d^4 < (2e-13)^2.
+        double eps = 0.0;
+        bool converged = false; // wave-uniform
+        rden = 1.0;
+#pragma unroll 1
+        for (int it = 0; it < 10; ++it) {
+            const double den = fma(-s, aynl, fma(-c, axnl, 1.0));
+            const double num = fma(axnl, s, fma(-aynl, c, -eps));
+            rden = az_rcp1(den);
+            double d = num * rden;
+            d = fmin(fmax(d, -0.95), 0.95);
+            eps += d;
+            if (it == 0)
+                az_rotate(s, c, d, rk);
+            else
+                az_rotate_le_tiny(s, c, d, rk);
+            const double d2 = d * d;
+            if (!az_any(el2 * d2 * d2 >= 4.0e-26)) {
+                converged = true;
+                break;
+            }
+        }
+        ecose = fma(axnl, c, aynl * s);
+        esine = fma(axnl, s, -(aynl * c));
+        ome = 1.0 - ecose;
+        // `den` of the last trip was 1 - ecose BEFORE the final rotation by d: its reciprocal is off
+        // by el*d relative (plus rcp1's 2^-46); one Newton step squares that:
+        // (el d)^2 <= el sqrt(el2 d^4) < 2e-13 el at loop exit -- below 1e-8 km even at GEO
+        inv_ome = fma(rden, fma(-ome, rden, 1.0), rden);
+        if (!converged) inv_ome = az_rcp(ome); // 10 trips without convergence: no such bound
         const double omel2 = 1.0 - el2;
         const double rb = az_rsqrt(omel2);
         betal = omel2 * rb;
         inv_omel2 = rb * rb;
         inv_1pb = az_rcp(1.0 + betal);
     }
+    const double inv_am = ra * ra;
+    const double rl = am * ome; // inv_ome = am / rl
     const double est = esine * inv_1pb;
     const double sinu = inv_ome * (s - aynl - axnl * est);
     const double cosu = inv_ome * (c - axnl + aynl * est);
