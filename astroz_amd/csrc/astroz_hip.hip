@@ -101,6 +101,7 @@ struct azh_constellation {
     DevBuf<unsigned> d_part_t, d_out_t;
     bool seeds_valid = false; // resonance seeds match the staged times/offsets and tile
     unsigned seeds_tile = 0;
+    bool seeds_rows = false; // seed table laid out for the lane = time kernel (64-point chunks)
     DevBuf<unsigned char> d_mask;
     bool have_offsets = false, have_mask = false;
     unsigned cached_n_times = 0;
@@ -316,7 +317,8 @@ bool use_rows(const PropArgs &a, int layout, bool deep)
 {
     // satellite-major near-earth rows (and the fused screen, which stores nothing): one wave per
     // satellite, lane = time
-    return !deep && (layout == AZ_LAYOUT_SAT_MAJOR || a.screen_target) && a.n_times >= 32;
+    (void)deep; // both populations have a lane = time kernel (k_rows, k_rows_deep)
+    return (layout == AZ_LAYOUT_SAT_MAJOR || a.screen_target) && a.n_times >= 32;
 }
 
 // number of partial minima per list slot a screen launch produces
@@ -330,10 +332,15 @@ unsigned screen_parts(const PropArgs &a, bool deep)
 }
 
 template <bool VEL, bool FRAME>
-void launch_rows2(const PropArgs &a, dim3 grid, hipStream_t st)
+void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st)
 {
-    if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
+    if (deep) {
+        if (a.f32) hipLaunchKernelGGL((k_rows_deep<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_rows_deep<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
+    } else {
+        if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
+    }
 }
 
 void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStream_t st)
@@ -344,13 +351,14 @@ void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStr
         b.tile = rows_tile(a.n_list, a.n_times, a.tile_forced);
         dim3 grid((a.n_list + 7) / 8 * 8, (a.n_times + b.tile - 1) / b.tile);
         if (a.screen_target) {
-            hipLaunchKernelGGL((k_rows<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);
+            if (deep) hipLaunchKernelGGL((k_rows_deep<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);
+            else hipLaunchKernelGGL((k_rows<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);
         } else if (frame) {
-            if (vel) launch_rows2<true, true>(b, grid, st);
-            else launch_rows2<false, true>(b, grid, st);
+            if (vel) launch_rows2<true, true>(b, grid, deep, st);
+            else launch_rows2<false, true>(b, grid, deep, st);
         } else {
-            if (vel) launch_rows2<true, false>(b, grid, st);
-            else launch_rows2<false, false>(b, grid, st);
+            if (vel) launch_rows2<true, false>(b, grid, deep, st);
+            else launch_rows2<false, false>(b, grid, deep, st);
         }
         return;
     }
@@ -402,21 +410,24 @@ int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, 
 // deep-space launch arguments: list slice, tile, and the resonance state at every tile start --
 // computed once per (time grid, offsets, tile) and kept in the handle, like the reference keeps its
 // carries (src/Constellation.zig L88, L294)
-int32_t prepare_deep(azh_constellation *c, PropArgs &d, hipStream_t st)
+int32_t prepare_deep(azh_constellation *c, PropArgs &d, hipStream_t st, bool rows)
 {
     const unsigned n_times = d.n_times;
     d.list = c->d_list.p + c->n_sgp4;
     d.n_list = c->n_sdp4;
     d.tile = auto_tile(c->n_sdp4, n_times, c->tile_sdp4, 8);
     d.tile_forced = c->tile_sdp4;
-    const unsigned n_tiles = (n_times + d.tile - 1) / d.tile;
-    if (!c->seeds_valid || c->seeds_tile != d.tile) {
+    // lane = time kernel: one state per 64-point chunk, taken at the chunk's grid point nearest to epoch
+    const unsigned seed_tile = rows ? 64u : d.tile;
+    const unsigned n_tiles = (n_times + seed_tile - 1) / seed_tile;
+    if (!c->seeds_valid || c->seeds_tile != seed_tile || c->seeds_rows != rows) {
         if (c->d_seeds.ensure((size_t)n_tiles * 3 * c->n_sdp4) != AZ_OK) return AZ_ERR_HIP;
         hipLaunchKernelGGL(k_deep_seed, dim3((c->n_sdp4 + 63) / 64), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
-                           d.list, c->n_sdp4, d.times, n_times, d.offsets, d.tile, c->d_seeds.p);
+                           d.list, c->n_sdp4, d.times, n_times, d.offsets, seed_tile, c->d_seeds.p, rows ? 1 : 0);
         HIP_TRY(hipGetLastError());
         c->seeds_valid = true;
-        c->seeds_tile = d.tile;
+        c->seeds_tile = seed_tile;
+        c->seeds_rows = rows;
     }
     d.seeds = c->d_seeds.p;
     return AZ_OK;
@@ -457,7 +468,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         HIP_TRY(hipEventRecord(c->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(c->s_deep, c->ev_fork, 0));
         PropArgs d = a;
-        if (int32_t rc = prepare_deep(c, d, c->s_deep); rc != AZ_OK) return rc;
+        if (int32_t rc = prepare_deep(c, d, c->s_deep, use_rows(d, layout, true)); rc != AZ_OK) return rc;
         launch_propagate(d, layout, d_vel != nullptr, true, c->s_deep);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_join, c->s_deep));
@@ -696,7 +707,7 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
             parts_near = screen_parts(near, false);
         }
         if (c->n_sdp4 > 0) {
-            if ((rc = prepare_deep(c, deep, st)) != AZ_OK) return rc;
+            if ((rc = prepare_deep(c, deep, st, use_rows(deep, AZ_LAYOUT_SAT_MAJOR, true))) != AZ_OK) return rc;
             parts_deep = screen_parts(deep, true);
         }
         const size_t np_near = (size_t)parts_near * c->n_sgp4, np_deep = (size_t)parts_deep * c->n_sdp4;

@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
     Sdp4Lane e8;
     Sdp4Carry c8;
     if (DEEP) {
-        az_load_sdp4(p.el, p.n_pad, s, fl, e8, cold);
+        az_load_sdp4(p.el, p.n_pad, s, fl, e8, ColdLds{cold});
         if (p.seeds) {
             // resonance state at this tile's first time, prepared once by k_deep_seed: a tile never
             // re-integrates from epoch (a 300-day-old resonant element set would cost 600+ integrator
@@ -182,8 +182,8 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
             c8.xni = sd[2 * (size_t)p.n_list];
         } else {
             c8.atime = 0.0;
-            c8.xli = e8.xlamo;
-            c8.xni = e8.no_unkozai;
+            c8.xli = e8(H_xlamo);
+            c8.xni = e8(H_no_unkozai);
         }
     } else {
         az_load_sgp4(p.el, p.n_pad, s, fl, e4, cold4);
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
         r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
 #else
         if (DEEP) {
-            rc = az_sdp4_step<VEL>(e8, cold, p.g, rk, t, c8, r, v);
+            rc = az_sdp4_step<VEL>(e8, ColdLds{cold}, p.g, rk, t, c8, r, v);
         } else {
             const bool first = ((i - t0) % AZ_RESEED) == 0;
             az_sgp4_step<VEL>(e4, cold4, p.el, p.n_pad, s, p.g, rk, t, first, c4, r, v);
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
 __global__ void __launch_bounds__(64) k_deep_seed(const double *el, const unsigned *flags, size_t n_pad,
                                                   const unsigned *list, unsigned n_list, const double *times,
                                                   unsigned n_times, const double *offsets, unsigned tile,
-                                                  double *seeds)
+                                                  double *seeds, int nearest)
 {
     __shared__ double cold_lds[D_NUM * 64];
     const unsigned li = blockIdx.x * 64 + threadIdx.x;
@@ -370,16 +370,24 @@ __global__ void __launch_bounds__(64) k_deep_seed(const double *el, const unsign
     const unsigned fl = flags[s];
     Sdp4Lane e;
     double *cold = cold_lds + threadIdx.x;
-    az_load_sdp4(el, n_pad, s, fl, e, cold);
+    az_load_sdp4(el, n_pad, s, fl, e, ColdLds{cold});
     Sdp4Carry cy;
     cy.atime = 0.0;
-    cy.xli = e.xlamo;
-    cy.xni = e.no_unkozai;
+    cy.xli = e(H_xlamo);
+    cy.xni = e(H_no_unkozai);
     const double off = offsets ? offsets[s] : 0.0;
     const unsigned n_tiles = (n_times + tile - 1) / tile;
     for (unsigned k = 0; k < n_tiles; ++k) {
-        const double t = times[k * tile] + off;
-        if (az_any(e.irez != 0)) az_resonance_advance(e, cold, t, cy);
+        double t = times[k * tile] + off;
+        if (nearest) {
+            // lane = time consumers (k_rows_deep): every lane of the chunk starts from this state and only
+            // ever integrates AWAY from epoch, so seed the chunk at its grid point nearest to epoch
+            // (t = 0, the epoch state itself, when the chunk straddles it)
+            const double t_end = times[min((k + 1) * tile, n_times) - 1] + off;
+            if (t * t_end <= 0.0) t = 0.0;
+            else if (fabs(t_end) < fabs(t)) t = t_end;
+        }
+        if (az_any(e.irez != 0)) az_resonance_advance(e, ColdLds{cold}, t, cy);
         if (in_range) {
             double *sd = seeds + (size_t)k * 3 * n_list + li;
             sd[0] = cy.atime;
@@ -409,11 +417,11 @@ __global__ void __launch_bounds__(64) k_one_satellite(const double *el, const un
             Sdp4Carry c;
             __shared__ double cold_deep[D_NUM * 64];
             double *cold = cold_deep + threadIdx.x;
-            az_load_sdp4(el, n_pad, sat, fl, e, cold);
+            az_load_sdp4(el, n_pad, sat, fl, e, ColdLds{cold});
             c.atime = 0.0;
-            c.xli = e.xlamo;
-            c.xni = e.no_unkozai;
-            rc = az_sdp4_step<true>(e, cold, g, az_rotk(), t, c, r, v);
+            c.xli = e(H_xlamo);
+            c.xni = e(H_no_unkozai);
+            rc = az_sdp4_step<true>(e, ColdLds{cold}, g, az_rotk(), t, c, r, v);
         } else {
             Sgp4Lane e;
             Sgp4Carry c;
@@ -614,6 +622,103 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
             // direct 24-byte (12-byte) pieces per lane: contiguous across the wave.  (Measured: a
             // transpose through LDS into 16-byte pieces per lane is slower, 0.41 vs 0.36 ms -- the
             // lgkmcnt round trip in front of the stores costs more than the fragmented requests.)
+            az_put3(prow + (size_t)i * 3, r);
+            if (VEL) az_put3(vrow + (size_t)i * 3, v);
+        }
+    }
+    if (SINK == AZ_SINK_SCREEN) {
+        az_wave_argmin(best_d2, best_t);
+        if (lane == 0) {
+            p.part_d2[(size_t)blockIdx.y * p.n_list + row] = best_d2;
+            p.part_t[(size_t)blockIdx.y * p.n_list + row] = best_t;
+        }
+    }
+}
+
+// Deep-space rows, satellite-major output (and the fused screen): ONE WAVE PER SATELLITE, lane = time,
+// like k_rows.  All 61 per-satellite constants are wave-uniform and live in LDS (broadcast reads), so
+// the kernel needs a third of the registers of the lane = satellite form (which holds 24 + carried
+// state per lane and runs at 1-2 waves/SIMD).  Each 64-point iteration starts from the resonance
+// state that k_deep_seed(nearest = 1) prepared for that chunk; a lane then advances at most a step
+// or two of 720 minutes on its own.
+#ifndef AZ_ROWSD_WAVES
+#define AZ_ROWSD_WAVES 3
+#endif
+template <bool VEL, bool FRAME, int SINK>
+__global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
+{
+    typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
+    constexpr unsigned TL = 512;
+    const unsigned lane = threadIdx.x;
+    const unsigned per_xcd = gridDim.x >> 3; // XCD-aware row assignment, see k_rows
+    const unsigned row = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (row >= p.n_list) return;
+    const unsigned s = p.list[row];
+    const unsigned fl = p.flags[s];
+    if (SINK != AZ_SINK_SCREEN && p.mask != nullptr && p.mask[s] == 0) return;
+    const unsigned t_lo = blockIdx.y * p.tile; // p.tile is a multiple of 64
+    const unsigned t_hi = min(t_lo + p.tile, p.n_times);
+    __shared__ double lds[TL + H_NUM + D_NUM];
+    int irez;
+    {
+        Sdp4Bcast e0{lds + TL, 0};
+        az_load_sdp4(p.el, p.n_pad, s, fl, e0, ColdBroadcast{lds + TL + H_NUM});
+        irez = e0.irez;
+    }
+    const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
+    const RotK rk = az_rotk();
+    out_t *prow = reinterpret_cast<out_t *>(p.pos) + (size_t)s * p.n_times * 3;
+    out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + (size_t)s * p.n_times * 3 : nullptr;
+    double best_d2 = __builtin_inf();
+    unsigned best_t = 0xffffffffu;
+#pragma unroll 1
+    for (unsigned base = t_lo; base < t_hi; base += 64) {
+        const unsigned i = base + lane;
+        const bool live = i < t_hi;
+        const unsigned kk = (base - t_lo) & (TL - 1u);
+        if (kk == 0) {
+            az_wave_lds_fence();
+#pragma unroll
+            for (unsigned j = 0; j < TL; j += 64) lds[j + lane] = p.times[min(i + j, t_hi - 1)];
+        }
+        az_wave_lds_fence();
+        const double t = lds[kk + lane] + off;
+        // the constants are re-read from LDS where they are used: an opaque zero in the address keeps the
+        // compiler from hoisting 61 loop-invariant loads into 122 VGPRs
+        unsigned zero = 0;
+        asm volatile("" : "+s"(zero));
+        const Sdp4Bcast e{lds + TL + zero, irez};
+        const ColdBroadcast cold{lds + TL + H_NUM + zero};
+        Sdp4Carry cy;
+        if (p.seeds) {
+            const double *sd = p.seeds + (size_t)(base >> 6) * 3 * p.n_list + row; // wave-uniform address
+            cy.atime = sd[0];
+            cy.xli = sd[p.n_list];
+            cy.xni = sd[2 * (size_t)p.n_list];
+        } else {
+            cy.atime = 0.0;
+            cy.xli = e(H_xlamo);
+            cy.xni = e(H_no_unkozai);
+        }
+        double r[3], v[3];
+        int rc = az_sdp4_step<VEL>(e, cold, p.g, rk, t, cy, r, v);
+        if (SINK == AZ_SINK_SCREEN) {
+            const double *q = p.screen_target + (size_t)(live ? i : t_hi - 1) * 3;
+            const double dx = q[0] - r[0], dy = q[1] - r[1], dz = q[2] - r[2];
+            const double d2 = dx * dx + dy * dy + dz * dz;
+            if (live && rc == 0 && d2 < best_d2) {
+                best_d2 = d2;
+                best_t = i;
+            }
+            continue;
+        }
+        if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
+        if (rc != 0) {
+            r[0] = r[1] = r[2] = 0.0;
+            v[0] = v[1] = v[2] = 0.0;
+            if (p.err && live) p.err[(size_t)s * p.n_times + i] = (unsigned char)rc;
+        }
+        if (live) {
             az_put3(prow + (size_t)i * 3, r);
             if (VEL) az_put3(vrow + (size_t)i * 3, v);
         }

@@ -340,15 +340,28 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const Cold &cold, const double *_
 // ------------------------------------------------------------------------------------------
 // deep space
 // Deep-space constants of one satellite, split like the near-earth ones:
-//   Sdp4Lane -- secular rates, epoch angles, resonance start values: VGPR resident (25 doubles)
+//   Sdp4Lane -- secular rates, epoch angles, resonance start values: VGPR resident (24 doubles),
+//               indexed by Sdp4Hot so that the same step code also runs from LDS-broadcast constants
 //   cold[]   -- the 24 lunar/solar periodic coefficients (one use per step in dpper) and the 13
 //               resonance coefficients (one use per integrator evaluation): LDS, one column per lane
+enum Sdp4Hot {
+    H_mo, H_mdot, H_argpo, H_argpdot, H_nodeo, H_nodedot, H_xnodcf, H_cc1, H_bc4, H_t2cof, H_ecco, H_inclo, H_no_unkozai, H_a_base, H_zmol, H_zmos, H_dedt, H_didt, H_dmdt, H_domdt, H_dnodt, H_xlamo, H_xfact, H_gsto,
+    H_NUM
+};
+// lane = satellite: the 24 hot values live in VGPRs ...
 struct Sdp4Lane {
-    double mo, mdot, argpo, argpdot, nodeo, nodedot, xnodcf;
-    double cc1, bc4, t2cof, ecco, inclo, no_unkozai, a_base;
-    double zmol, zmos, dedt, didt, dmdt, domdt, dnodt;
-    double xlamo, xfact, gsto;
+    double v[H_NUM];
     int irez;
+    AZ_MEMBER double operator()(int k) const { return v[k]; }
+    AZ_MEMBER void set(int k, double x) { v[k] = x; }
+};
+// ... lane = time (one wave per satellite): every constant is wave-uniform and sits in LDS, one word
+// each, read by all lanes at once (broadcast ds_read: no VALU slot, no SGPR/VGPR residency)
+struct Sdp4Bcast {
+    double *p;
+    int irez;
+    AZ_MEMBER double operator()(int k) const { return p[k]; }
+    AZ_MEMBER void set(int k, double x) const { p[k] = x; }
 };
 enum Sdp4Cold {
     D_se2, D_se3, D_si2, D_si3, D_sl2, D_sl3, D_sl4, D_sgh2, D_sgh3, D_sgh4, D_sh2, D_sh3,
@@ -361,24 +374,24 @@ struct Sdp4Carry {
     double atime, xli, xni;
 };
 
-AZ_DEVICE void az_load_sdp4(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags,
-                            Sdp4Lane &e, double *cold)
+template <class Lane, class Cold>
+AZ_DEVICE void az_load_sdp4(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags, Lane &e,
+                            const Cold &cold)
 {
 #define L(f) el[(size_t)F_##f * n_pad + i]
-#define CS(f) cold[D_##f * AZ_COLD_STRIDE] = L(f)
-    e.mo = L(mo); e.mdot = L(mdot); e.argpo = L(argpo); e.argpdot = L(argpdot);
-    e.nodeo = L(nodeo); e.nodedot = L(nodedot); e.xnodcf = L(xnodcf);
-    e.cc1 = L(cc1); e.bc4 = L(bc4); e.t2cof = L(t2cof); e.ecco = L(ecco); e.inclo = L(inclo);
-    e.no_unkozai = L(no_unkozai); e.a_base = L(a_base);
-    e.zmol = L(zmol); e.zmos = L(zmos); e.dedt = L(dedt); e.didt = L(didt); e.dmdt = L(dmdt);
-    e.domdt = L(domdt); e.dnodt = L(dnodt);
-    e.xlamo = L(xlamo); e.xfact = L(xfact); e.gsto = L(gsto);
+#define HS(f) e.set(H_##f, L(f))
+#define CS(f) cold.set(D_##f, L(f))
+    HS(mo); HS(mdot); HS(argpo); HS(argpdot); HS(nodeo); HS(nodedot); HS(xnodcf);
+    HS(cc1); HS(bc4); HS(t2cof); HS(ecco); HS(inclo); HS(no_unkozai); HS(a_base);
+    HS(zmol); HS(zmos); HS(dedt); HS(didt); HS(dmdt); HS(domdt); HS(dnodt);
+    HS(xlamo); HS(xfact); HS(gsto);
     e.irez = (int)AZ_FLAG_IREZ(flags);
     CS(se2); CS(se3); CS(si2); CS(si3); CS(sl2); CS(sl3); CS(sl4); CS(sgh2); CS(sgh3); CS(sgh4); CS(sh2); CS(sh3);
     CS(ee2); CS(e3); CS(xi2); CS(xi3); CS(xl2); CS(xl3); CS(xl4); CS(xgh2); CS(xgh3); CS(xgh4); CS(xh2); CS(xh3);
     CS(d2201); CS(d2211); CS(d3210); CS(d3222); CS(d4410); CS(d4422); CS(d5220); CS(d5232); CS(d5421); CS(d5433);
     CS(del1); CS(del2); CS(del3);
 #undef CS
+#undef HS
 #undef L
 }
 
@@ -403,14 +416,15 @@ AZ_DEVICE void az_load_sdp4(const double *__restrict__ el, size_t n_pad, size_t 
 // reference batch kernel (Sdp4Batch.zig L347-425: both branches for every lane) each branch is
 // only entered by waves that hold such a satellite; the host orders the deep-space index list by
 // resonance class so that waves are uniform.
-#define DL(f) cold[D_##f * AZ_COLD_STRIDE]
-AZ_DEVICE void az_resonance_accel(const Sdp4Lane &e, const double *cold, double xli, double xni,
+#define DL(f) cold(D_##f)
+template <class Lane, class Cold>
+AZ_DEVICE void az_resonance_accel(const Lane &e, const Cold &cold, double xli, double xni,
                                   double atime, double &xndt, double &xnddt, double &xldot)
 {
-    xldot = xni + e.xfact;
+    xldot = xni + e(H_xfact);
     double xndt_h = 0.0, xnddt_h = 0.0;
     if (az_any(e.irez == 2)) {
-        const double xomi = fma(e.argpdot, atime, e.argpo);
+        const double xomi = fma(e(H_argpdot), atime, e(H_argpo));
         const double x2omi = xomi + xomi, x2li = xli + xli;
         // ten phases, accumulated one at a time (short live ranges: the kernel is register-bound)
         double sn, cs, acc_s = 0.0, acc_c = 0.0, acc_c2 = 0.0;
@@ -456,13 +470,14 @@ AZ_DEVICE void az_resonance_accel(const Sdp4Lane &e, const double *cold, double 
 // reference's restart rule (src/Sdp4.zig L786-801, src/Sdp4Batch.zig L241-267).  The state reached
 // after k steps of +-720 min is a pure function of k, so carrying it, restarting from epoch, or
 // loading it from the per-tile seed table (k_deep_seed) are all equivalent.
-AZ_DEVICE void az_resonance_advance(const Sdp4Lane &e, const double *cold, double t, Sdp4Carry &cy)
+template <class Lane, class Cold>
+AZ_DEVICE void az_resonance_advance(const Lane &e, const Cold &cold, double t, Sdp4Carry &cy)
 {
     const bool res = e.irez != 0;
     if (res && (cy.atime == 0.0 || t * cy.atime <= 0.0 || fabs(t) < fabs(cy.atime))) {
         cy.atime = 0.0;
-        cy.xni = e.no_unkozai;
-        cy.xli = e.xlamo;
+        cy.xni = e(H_no_unkozai);
+        cy.xli = e(H_xlamo);
     }
     const double delt = (t > 0.0) ? AZ_STEPP : -AZ_STEPP;
     while (az_any(res && fabs(t - cy.atime) >= AZ_STEPP)) {
@@ -478,25 +493,25 @@ AZ_DEVICE void az_resonance_advance(const Sdp4Lane &e, const double *cold, doubl
 
 // one deep-space propagation; returns 0 / 1 (eccentricity) / 6 (decayed) per the scalar
 // reference path (src/Sdp4.zig L914-921, L937-938, L967).
-template <bool VEL>
-AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const double *cold, const AzGrav &g, const RotK &rk, double t,
+template <bool VEL, class Lane, class Cold>
+AZ_DEVICE int az_sdp4_step(const Lane &e, const Cold &cold, const AzGrav &g, const RotK &rk, double t,
                            Sdp4Carry &cy, double r[3], double v[3])
 {
     const double t2 = t * t;
-    const double tempa = 1.0 - e.cc1 * t;
-    const double tempe = e.bc4 * t;
-    const double templ = e.t2cof * t2;
+    const double tempa = 1.0 - e(H_cc1) * t;
+    const double tempe = e(H_bc4) * t;
+    const double templ = e(H_t2cof) * t2;
 
-    double em = fma(e.dedt, t, e.ecco);
-    double inclm = fma(e.didt, t, e.inclo);
-    double argpm = fma(e.argpdot, t, e.argpo) + e.domdt * t;
-    double nodem = fma(e.xnodcf, t2, fma(e.nodedot, t, e.nodeo)) + e.dnodt * t;
-    double mm = fma(e.mdot, t, e.mo) + e.dmdt * t;
-    double nm = e.no_unkozai;
+    double em = fma(e(H_dedt), t, e(H_ecco));
+    double inclm = fma(e(H_didt), t, e(H_inclo));
+    double argpm = fma(e(H_argpdot), t, e(H_argpo)) + e(H_domdt) * t;
+    double nodem = fma(e(H_xnodcf), t2, fma(e(H_nodedot), t, e(H_nodeo))) + e(H_dnodt) * t;
+    double mm = fma(e(H_mdot), t, e(H_mo)) + e(H_dmdt) * t;
+    double nm = e(H_no_unkozai);
     int rc = 0;
 
     // resonance integrator (dspace, src/Sdp4.zig L784-819)
-    double a23 = e.a_base; // (xke/nm)^(2/3)
+    double a23 = e(H_a_base); // (xke/nm)^(2/3)
     if (az_any(e.irez != 0)) {
         const bool res = e.irez != 0;
         az_resonance_advance(e, cold, t, cy);
@@ -506,20 +521,20 @@ AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const double *cold, const AzGrav &
             const double ft = t - cy.atime;
             nm = cy.xni + xndt * ft + xnddt * ft * ft * 0.5;
             const double xl = cy.xli + xldot * ft + xndt * ft * ft * 0.5;
-            const double theta = fma(t, AZ_RPTIM, e.gsto); // only ever used through sin/cos: no modulo
+            const double theta = fma(t, AZ_RPTIM, e(H_gsto)); // only ever used through sin/cos: no modulo
             mm = (e.irez != 2) ? xl - nodem - argpm + theta : xl - 2.0 * nodem + 2.0 * theta;
-            nm = e.no_unkozai + (nm - e.no_unkozai);
+            nm = e(H_no_unkozai) + (nm - e(H_no_unkozai));
         }
-        if (nm <= 0.0) { rc = 6; nm = e.no_unkozai; }
+        if (nm <= 0.0) { rc = 6; nm = e(H_no_unkozai); }
         // (xke/nm)^(2/3) = a_base (1+x)^(-2/3), x = nm/no - 1 (|x| ~ 1e-5 for real resonant orbits):
         // binomial series to x^5 (next term 0.4 x^6 < 3e-17 for |x| <= 2e-3), cbrt only beyond that
-        const double x = (nm - e.no_unkozai) * az_rcp(e.no_unkozai);
+        const double x = (nm - e(H_no_unkozai)) * az_rcp(e(H_no_unkozai));
         if (!az_any(fabs(x) > 2.0e-3)) {
             double f = fma(x, -308.0 / 729.0, 110.0 / 243.0);
             f = fma(x, f, -40.0 / 81.0);
             f = fma(x, f, 5.0 / 9.0);
             f = fma(x, f, -2.0 / 3.0);
-            a23 = e.a_base * fma(x, f, 1.0);
+            a23 = e(H_a_base) * fma(x, f, 1.0);
         } else {
             const double q = g.xke / nm;
             a23 = cbrt(q * q);
@@ -531,13 +546,13 @@ AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const double *cold, const AzGrav &
     if (rc == 0 && (em >= 1.0 || em < -0.001)) rc = 1;
     if (em < 1.0e-6) em = 1.0e-6;
     if (rc == 0 && am < 0.95) rc = 6;
-    mm += e.no_unkozai * templ;
+    mm += e(H_no_unkozai) * templ;
     // (no mod 2pi: the angles are only consumed by sin/cos, except inside the Lyddane branch)
 
     // lunar-solar periodics (dpper, src/Sdp4.zig L681-759)
     double sI, cI; // sin/cos of the perturbed inclination
     {
-        double zm = fma(AZ_ZNS, t, e.zmos);
+        double zm = fma(AZ_ZNS, t, e(H_zmos));
         double szm, czm, sinzf, coszf;
         az_sincos(zm, szm, czm);
         sinzf = szm; coszf = czm;
@@ -548,7 +563,7 @@ AZ_DEVICE int az_sdp4_step(const Sdp4Lane &e, const double *cold, const AzGrav &
         const double sls = DL(sl2) * f2 + DL(sl3) * f3 + DL(sl4) * sinzf;
         const double sghs = DL(sgh2) * f2 + DL(sgh3) * f3 + DL(sgh4) * sinzf;
         const double shs = DL(sh2) * f2 + DL(sh3) * f3;
-        zm = fma(AZ_ZNL, t, e.zmol);
+        zm = fma(AZ_ZNL, t, e(H_zmol));
         az_sincos(zm, szm, czm);
         sinzf = szm; coszf = czm;
         az_rotate_med(sinzf, coszf, 2.0 * AZ_ZEL * szm); // |.| <= 0.1098

@@ -30,11 +30,12 @@ void emul_propagate(const double* fields, unsigned flags, const double* grav6, c
 {
     AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
     if (flags & AZ_FLAG_DEEP) {
-        Sdp4Lane e; Sdp4Carry cy; double cold[D_NUM];
+        Sdp4Lane e; Sdp4Carry cy; double cold_store[D_NUM];
+        const ColdLds cold{cold_store};
         az_load_sdp4(fields, 1, 0, flags, e, cold);
-        cy.atime = 0.0; cy.xli = e.xlamo; cy.xni = e.no_unkozai;
+        cy.atime = 0.0; cy.xli = e(H_xlamo); cy.xni = e(H_no_unkozai);
         for (int i = 0; i < n; ++i) {
-            if (!incremental) { cy.atime = 0.0; cy.xli = e.xlamo; cy.xni = e.no_unkozai; }
+            if (!incremental) { cy.atime = 0.0; cy.xli = e(H_xlamo); cy.xni = e(H_no_unkozai); }
             double r[3], v[3];
             int rc = az_sdp4_step<true>(e, cold, g, az_rotk(), ts[i], cy, r, v);
             if (rc) { r[0]=r[1]=r[2]=v[0]=v[1]=v[2]=0.0; }
