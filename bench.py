@@ -6,8 +6,9 @@
          --master-port P bench.py --gpus N --steps K --warmup W
 
 One "step" = one pass of the hot path over the whole workload: every satellite of the rank's
-catalog propagated to every time, fp64, TEME, positions + velocities, written time-major into a
-device-resident (n_times, n_sats, 3) x 2 output.  Inputs (element table, time grid, epoch offsets)
+catalog propagated to every time, fp64, TEME, positions + velocities, written into a device-resident
+(n_sats, n_times, 3) x 2 output (the shape BASELINE.json's north_star names; `--layout time` selects
+the (n_times, n_sats, 3) layout and with it the lane = satellite kernel).  Inputs (element table, time grid, epoch offsets)
 are resident in HBM before the timed region starts; nothing is copied to the host inside it.
 
 Multi-GPU: satellites shard embarrassingly; there is no data-path collective.
