@@ -478,7 +478,7 @@ struct ColdBroadcast {
     __device__ __forceinline__ void set(int k, double v) const { p[k] = v; }
 };
 #ifndef AZ_ROWS_TLDS
-#define AZ_ROWS_TLDS 512 /* k_rows: time values staged in LDS per refill (0 = per-iteration global loads) */
+#define AZ_ROWS_TLDS 1024 /* k_rows: time values staged in LDS per refill (0 = per-iteration global loads) */
 #endif
 #ifndef AZ_ROWS_COLD
 #define AZ_ROWS_COLD 1 /* k_rows: once-per-step constants 0 = SGPRs (v_readfirstlane), 1 = LDS broadcast */
@@ -614,8 +614,8 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
             continue;
         }
         if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
-#if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only */
-        if (live && r[0] == 1.2345e300) {
+#if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only (every component stays live) */
+        if (live && (r[0] + r[1] + r[2] + (VEL ? v[0] + v[1] + v[2] : 0.0)) == 1.2345e300) {
 #else
         if (live) {
 #endif

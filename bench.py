@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--times", type=int, default=1440)
     ap.add_argument("--deep", type=int, default=0, help="extra deep-space satellites (config 3: 1522)")
     ap.add_argument("--pos-only", action="store_true")
+    ap.add_argument("--f32-out", action="store_true",
+                    help="fp32 OUTPUT arrays (BASELINE config 5); the arithmetic stays fp64")
     ap.add_argument("--layout", choices=["time", "sat"], default="sat",
                     help="physical output layout: sat = (n_sats, n_times, 3) [default], time = (n_times, n_sats, 3)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
@@ -145,11 +147,12 @@ def main():
     layout = _native.TIME_MAJOR if a.layout == "time" else _native.SAT_MAJOR
     shape = (n_times, n_local, 3) if layout == _native.TIME_MAJOR else (n_local, n_times, 3)
     cuda = torch.device("cuda", local_rank)
-    pos = torch.empty(shape, dtype=torch.float64, device=cuda)
-    vel = torch.empty(shape, dtype=torch.float64, device=cuda) if vel_on else None
+    odt = torch.float32 if a.f32_out else torch.float64
+    pos = torch.empty(shape, dtype=odt, device=cuda)
+    vel = torch.empty(shape, dtype=odt, device=cuda) if vel_on else None
     gathered = None
     if a.gather and world > 1:
-        gathered = [torch.empty((world,) + shape, dtype=torch.float64, device=cuda) for _ in range(2 if vel_on else 1)]
+        gathered = [torch.empty((world,) + shape, dtype=odt, device=cuda) for _ in range(2 if vel_on else 1)]
     # an explicit (non-null) stream: the kernels, the collectives and the timing events all live on it
     stream = torch.cuda.Stream(device=cuda)
     torch.cuda.set_stream(stream)
@@ -159,14 +162,14 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        dev.propagate_device_cached(p_ptr, v_ptr, layout=layout, stream=sptr)
+        dev.propagate_device_cached(p_ptr, v_ptr, layout=layout, stream=sptr, f32=a.f32_out)
         if gathered is not None:
             dist.all_gather_into_tensor(gathered[0], pos)
             if vel_on:
                 dist.all_gather_into_tensor(gathered[1], vel)
 
     # stage inputs (times, offsets) once; this call also runs the kernels (counts as warm-up)
-    dev.propagate_device(times, offsets, p_ptr, v_ptr, layout=layout, stream=sptr)
+    dev.propagate_device(times, offsets, p_ptr, v_ptr, layout=layout, stream=sptr, f32=a.f32_out)
     torch.cuda.synchronize()
     last_kernel_ms = dev.last_kernel_ms()   # the library's own hipEvent pair around that launch
     dev.set_timing(False)                    # the timed loop below is bracketed by events of its own
@@ -224,7 +227,7 @@ def main():
     launch_s = (ev_ms / 1e3) / a.steps            # average duration of one launch (HIP events on the launch stream)
     local_props = n_local * n_times
     n_tiles = max(1, -(-n_times // max(a.tile, 1))) if a.tile else None
-    bytes_per_launch = local_props * (BYTES_OUT_PV if vel_on else BYTES_OUT_P) + n_times * 8 + \
+    bytes_per_launch = local_props * (BYTES_OUT_PV if vel_on else BYTES_OUT_P) * (0.5 if a.f32_out else 1.0) + n_times * 8 + \
         n_local * ELEM_BYTES_PER_SAT  # elements counted once (re-reads across tiles are cache hits)
     gbs = bytes_per_launch / launch_s / 1e9
     tflops = local_props * FLOPS_PER_PROP / launch_s / 1e12
@@ -246,9 +249,9 @@ def main():
         "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
             "workload": "config 2: %d-sat synthetic active catalog (SGP4 near-earth%s) x %d one-minute steps, "
-                        "fp64 TEME %s, %s-major device-resident output%s" % (
+                        "fp64 arithmetic, %s TEME %s, %s-major device-resident output%s" % (
                             a.sats, " + %d deep-space SDP4" % a.deep if a.deep else "", n_times,
-                            "pos+vel" if vel_on else "pos only", a.layout,
+                            "fp32-stored" if a.f32_out else "fp64", "pos+vel" if vel_on else "pos only", a.layout,
                             ", per GPU" if (world > 1 and a.scaling == "weak") else ""),
             "n_sats_per_gpu": n_local, "n_times": n_times, "gather": bool(gathered is not None),
             "precondition_ms": a.precondition_ms, "precondition_steps": n_pre,
