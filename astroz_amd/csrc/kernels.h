@@ -453,8 +453,8 @@ __global__ void __launch_bounds__(64) k_one_satellite(const double *el, const un
 // per-satellite constants are wave-uniform (forced into SGPRs with v_readfirstlane): no LDS, ~100
 // VGPRs less than the lane = satellite kernel, and the Kepler-Newton trip count and every rotation
 // tier are uniform by construction (one orbit per wave).  Each lane carries its own (sin,cos) pairs
-// of the slow angles across iterations (64 steps apart: small tier); only the mean anomaly, which
-// moves ~4.5 rad per 64 minutes, takes a full sincos.
+// of the slow angles across iterations (64 grid points apart); on a uniform grid the increments of
+// the mean anomaly and of the argument of perigee are the same every iteration and are cached.
 AZ_DEVICE double az_uniform(double x)
 {
 #ifdef AZ_HOST_EMUL
@@ -464,24 +464,17 @@ AZ_DEVICE double az_uniform(double x)
                             __builtin_amdgcn_readfirstlane(__double2loint(x)));
 #endif
 }
-struct ColdUniform {
-    double c[C_NUM_MAX];
-    __device__ __forceinline__ double operator()(int k) const { return c[k]; }
-    __device__ __forceinline__ void set(int k, double v) { c[k] = az_uniform(v); }
-};
-// ... or one LDS word per constant, read by all 64 lanes at once (broadcast ds_read_b64: no VALU
-// slot, no SGPRs -- the 33 uniform doubles of a satellite do not fit the SGPR file next to the
-// kernel's pointers, and every SGPR spilled to a VGPR lane costs a v_readlane per use)
+// once-per-step constants of a lane = time kernel: one LDS word per constant, read by all 64 lanes
+// at once (broadcast ds_read_b64: no VALU slot, no SGPRs -- the 33 uniform doubles of a satellite do
+// not fit the SGPR file next to the kernel's pointers, and every SGPR spilled to a VGPR lane costs
+// a v_readlane per use)
 struct ColdBroadcast {
     double *p;
     __device__ __forceinline__ double operator()(int k) const { return p[k]; }
     __device__ __forceinline__ void set(int k, double v) const { p[k] = v; }
 };
 #ifndef AZ_ROWS_TLDS
-#define AZ_ROWS_TLDS 1024 /* k_rows: time values staged in LDS per refill (0 = per-iteration global loads) */
-#endif
-#ifndef AZ_ROWS_COLD
-#define AZ_ROWS_COLD 1 /* k_rows: once-per-step constants 0 = SGPRs (v_readfirstlane), 1 = LDS broadcast */
+#define AZ_ROWS_TLDS 1024 /* k_rows: time values staged in LDS per refill (a power of two >= 64) */
 #endif
 
 // SINK: what happens to a result -- 0: fp64 rows, 1: fp32 rows, 2: fused single-target conjunction
@@ -523,16 +516,9 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     const unsigned t_lo = blockIdx.y * p.tile;
     const unsigned t_hi = min(t_lo + p.tile, p.n_times);
     Sgp4Lane e;
-#if AZ_ROWS_TLDS > 0 || AZ_ROWS_COLD
-    __shared__ __attribute__((aligned(16))) double rows_lds[(AZ_ROWS_TLDS > 0 ? AZ_ROWS_TLDS : 0) + C_NUM_MAX + 2];
-#endif
-#if AZ_ROWS_COLD
+    __shared__ __attribute__((aligned(16))) double rows_lds[AZ_ROWS_TLDS + C_NUM_MAX + 2];
     typedef ColdBroadcast ColdT;
-    ColdT cold{rows_lds + (AZ_ROWS_TLDS > 0 ? AZ_ROWS_TLDS : 0)};
-#else
-    typedef ColdUniform ColdT;
-    ColdT cold;
-#endif
+    const ColdT cold{rows_lds + AZ_ROWS_TLDS};
     az_load_sgp4(p.el, p.n_pad, s, fl, e, cold);
     e.mdot = az_uniform(e.mdot); e.argpdot = az_uniform(e.argpdot); e.nodedot = az_uniform(e.nodedot);
     e.xnodcf = az_uniform(e.xnodcf); e.aycof = az_uniform(e.aycof); e.xlcof = az_uniform(e.xlcof);
@@ -557,29 +543,14 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + srow * p.n_times * 3 : nullptr;
     double best_d2 = __builtin_inf();
     unsigned best_t = 0xffffffffu;
-    // the time value of the NEXT iteration is fetched before this iteration's stores are issued, so
-    // the s_waitcnt in front of its first use (vmcnt counts in issue order) never has to wait for
-    // those stores to be acknowledged by memory
-#if defined(AZ_STAGGER) && AZ_STAGGER > 0
-    // tuning experiment: de-phase the waves so that their store bursts do not coincide
-    {
-        const unsigned h = (blockIdx.x * 2654435761u) >> 25; // 0..127
-        for (unsigned q = 0; q < (h * AZ_STAGGER) / 128u; ++q) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
-#if AZ_ROWS_TLDS > 0
     // Time values go through LDS (AZ_ROWS_TLDS grid points per refill): the loop then holds no
     // vector-memory LOAD at all.  vmcnt counts loads and stores in issue order, so a load's
     // s_waitcnt also waits for every output store issued before it -- one load per iteration
     // serialises the arithmetic against the write stream; ds_read waits on lgkmcnt only.
-#else
-    double t_next = p.times[min(t_lo + lane, t_hi - 1)];
-#endif
 #pragma unroll 1
     for (unsigned base = t_lo; base < t_hi; base += 64) {
         const unsigned i = base + lane;
         const bool live = i < t_hi;
-#if AZ_ROWS_TLDS > 0
         const unsigned kk = (base - t_lo) & (AZ_ROWS_TLDS - 1u);
         if (kk == 0) {
             az_wave_lds_fence();
@@ -588,10 +559,6 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
             az_wave_lds_fence();
         }
         const double t = rows_lds[kk + lane] + off;
-#else
-        const double t = t_next + off;
-        t_next = p.times[min(i + 64, t_hi - 1)];
-#endif
         double r[3], v[3];
         // full re-seed of the carried pairs at the start and every 64 iterations (4,096 grid points)
         const bool first = ((base - t_lo) & (64u * 64u - 1u)) == 0;
