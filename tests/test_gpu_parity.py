@@ -479,3 +479,37 @@ def test_full_size_properties(native, orc, synth, n_deep):
     assert ok.mean() > 0.99
     assert (np.abs(p_sm[idx].cpu().numpy() - p0) * ok).max() < TOL_R
     assert (np.abs(v_sm[idx].cpu().numpy() - v0) * ok).max() < TOL_V
+
+
+def test_screen_edge_cases(native, synth):
+    """Argument checking and degenerate sizes of the screening entry points."""
+    import ctypes as C
+    pairs = synth.synth_catalog(n_near=70, n_deep=3, seed=2)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    # empty grid: everything reports (threshold, 0)
+    d, ti = dev.screen_target(np.zeros(0), 5, 12.5)
+    assert (d == 12.5).all() and (ti == 0).all()
+    # a single grid point, one-satellite constellations
+    d, ti = dev.screen_target(np.array([3.0]), 0, 1e9)
+    assert d[0] == 1e9 and (d[1:] < 1e9).all() and (ti == 0).all()
+    one = native.DeviceConstellation.from_tle_lines(pairs[:1], 1, 0)
+    d, ti = one.screen_target(np.arange(100.0), 0, 10.0)
+    assert d.tolist() == [10.0] and ti.tolist() == [0]
+    pp, tt = one.screen_all(np.arange(100.0), 10.0)
+    assert len(pp) == 0 and len(tt) == 0
+    with pytest.raises(ValueError):
+        dev.screen_target(np.arange(10.0), dev.n, 10.0)
+    L = native.lib()
+    k = C.c_size_t(7)
+    buf = np.zeros((4, 3, 3))
+    out_p = np.zeros((8, 2), dtype=np.uint32)
+    out_t = np.zeros(8, dtype=np.uint32)
+    # non-positive threshold, bad layout
+    rc = L.azh_coarse_screen_host(buf.ctypes.data, 4, 3, 0, 0, 0.0, None, out_p.ctypes.data, out_t.ctypes.data, 8, C.byref(k), 0)
+    assert rc == -20 and k.value == 0
+    rc = L.azh_coarse_screen_host(buf.ctypes.data, 4, 3, 5, 0, 1.0, None, out_p.ctypes.data, out_t.ctypes.data, 8, C.byref(k), 0)
+    assert rc == -20
+    # all four satellites at the origin at every step: C(4,2) pairs x 3 steps, sorted by (t, s, other)
+    pp, tt = native.coarse_screen(buf, 1.0)
+    assert len(tt) == 18 and tt.tolist() == sorted(tt.tolist())
+    assert pp[:6].tolist() == [[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]]

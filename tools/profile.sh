@@ -7,14 +7,14 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-BENCH="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline $BENCH_EXTRA"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
-PM="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_EXTRA"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o pmc -- $PM > $OUT/pmc_sq.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_TRANS_F64 -d $OUT/pmc_sq2 -o pmc -- $PM > $OUT/pmc_sq2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $PM > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $PM > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $OUT/pmc_grbm -o pmc -- $PM > $OUT/pmc_grbm.log 2>&1
+BENCH="python $REPO/bench.py --steps 100 --warmup 20 --no-cpu-baseline $BENCH_EXTRA"
+timeout 180 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
+PM="python $REPO/bench.py --steps 3 --warmup 1 --precondition-ms 0 --no-cpu-baseline $BENCH_EXTRA"
+timeout 180 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o pmc -- $PM > $OUT/pmc_sq.log 2>&1
+timeout 180 rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_TRANS_F64 -d $OUT/pmc_sq2 -o pmc -- $PM > $OUT/pmc_sq2.log 2>&1
+timeout 180 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $PM > $OUT/pmc_fetch.log 2>&1
+timeout 180 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $PM > $OUT/pmc_write.log 2>&1
+timeout 180 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d $OUT/pmc_grbm -o pmc -- $PM > $OUT/pmc_grbm.log 2>&1
 cd $REPO
 find $OUT -name "*.csv" | head -40
 python - <<PY
