@@ -131,6 +131,33 @@ def _start_jd(start_time):
     return 2440587.5 + (start_time.timestamp() / 86400.0)
 
 
+class Tle:
+    """Two-Line Element set: ``astroz.Tle(tle_string)`` (bindings/python/src/tle.zig L14-104) over the
+    c_api ``tle_parse`` / ``tle_get_*`` exports.  Text parsing only -- no GPU involved."""
+
+    def __init__(self, tle_string):
+        import ctypes as C
+        if not isinstance(tle_string, str):
+            raise TypeError("tle_string must be str")
+        h = C.c_void_p()
+        if _native.lib().tle_parse(tle_string.encode(), C.byref(h)) != 0:
+            raise ValueError("Failed to parse TLE")
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            _native.lib().tle_free(h)
+            self._h = None
+
+    satellite_number = property(lambda self: int(_native.lib().tle_get_satellite_number(self._h)),
+                                doc="NORAD catalog number")
+    epoch = property(lambda self: float(_native.lib().tle_get_epoch(self._h)), doc="Epoch (J2000 seconds)")
+    inclination = property(lambda self: float(_native.lib().tle_get_inclination(self._h)), doc="Inclination (degrees)")
+    eccentricity = property(lambda self: float(_native.lib().tle_get_eccentricity(self._h)), doc="Eccentricity")
+    mean_motion = property(lambda self: float(_native.lib().tle_get_mean_motion(self._h)), doc="Mean motion (rev/day)")
+
+
 class Constellation:
     """Pre-parsed, device-resident orbital elements for repeated propagation.
 
@@ -226,4 +253,4 @@ def coarse_screen(positions, num_sats, threshold, valid_mask=None):
     return [tuple(int(x) for x in p) for p in pairs], [int(x) for x in tt]
 
 
-__all__ = ["__version__", "Constellation", "propagate", "screen", "coarse_screen", "WGS72", "WGS84"]
+__all__ = ["__version__", "Tle", "Constellation", "propagate", "screen", "coarse_screen", "WGS72", "WGS84"]

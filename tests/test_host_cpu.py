@@ -215,3 +215,20 @@ def test_emulated_kernels_match_oracle(emul, orc, step):
             worst_r = max(worst_r, np.abs(out[k, :3] - r).max())
             worst_v = max(worst_v, np.abs(out[k, 3:] - v).max())
     assert worst_r < 1e-6 and worst_v < 1e-9, (worst_r, worst_v)
+
+
+def test_python_tle_class():
+    """astroz.Tle mirror (bindings/python/src/tle.zig): text parsing through the c_api, no GPU."""
+    import astroz_amd
+    t = astroz_amd.Tle("1 25544U 98067A   24127.82853009  .00015698  00000+0  27310-3 0  9995\n"
+                       "2 25544  51.6393 160.4574 0003580 140.6673 205.7250 15.50957674452123")
+    assert t.satellite_number == 25544
+    assert abs(t.inclination - 51.6393) < 1e-12 and abs(t.eccentricity - 0.000358) < 1e-15
+    assert abs(t.mean_motion - 15.50957674) < 1e-9
+    # epoch: J2000 seconds of 2024 day 127.82853009
+    jd = 2460310.5 + 127.82853009 - 1.0
+    assert abs(t.epoch - (jd - 2451545.0) * 86400.0) < 1e-3
+    with pytest.raises(ValueError):
+        astroz_amd.Tle("not a tle")
+    with pytest.raises(TypeError):
+        astroz_amd.Tle(b"bytes")
