@@ -35,12 +35,6 @@ for k in kern:
     dur = {c: v[2] for (kk, c), v in vals.items() if kk == k}
     if "SQ_WAVES" in d and "SQ_INSTS_VALU" in d:
         out.append("  derived: VALU instr per wave = %.0f" % (d["SQ_INSTS_VALU"] / d["SQ_WAVES"]))
-    if "GRBM_GUI_ACTIVE" in d:
-        out.append("  derived: shader clock ~ %.2f GHz (GRBM_GUI_ACTIVE / 8 XCD / duration)" % (d["GRBM_GUI_ACTIVE"] / 8 / dur["GRBM_GUI_ACTIVE"]))
-    if "SQ_ACTIVE_INST_VALU" in d and "GRBM_GUI_ACTIVE" in d:
-        simd_cycles = d["GRBM_GUI_ACTIVE"] / 8 * 1024 * dur["SQ_ACTIVE_INST_VALU"] / dur["GRBM_GUI_ACTIVE"]
-        out.append("  derived: VALU busy = %.1f %% of SIMD cycles (4 x SQ_ACTIVE_INST_VALU quad-cycles / (1024 SIMD x cycles))" %
-                   (400.0 * d["SQ_ACTIVE_INST_VALU"] / simd_cycles))
     if "WRITE_SIZE" in d:
         out.append("  derived: HBM write traffic = %.1f MB/dispatch (WRITE_SIZE KB x 1024)" % (d["WRITE_SIZE"] * 1024 / 1e6))
     if "FETCH_SIZE" in d:
