@@ -166,23 +166,38 @@ def test_long_span_and_negative_times(native, orc, synth):
     assert np.abs((vel - v0) * ok).max() < 1e-8
 
 
-def test_output_modes_mask_and_stride(native, orc, synth):
+@pytest.mark.parametrize("layout", ["time_major", "sat_major"])
+def test_output_modes_mask_and_stride(native, orc, synth, layout):
+    """ECEF / geodetic epilogues in both layouts (lane = satellite and lane = time kernels, near-earth
+    and deep-space), satellite mask, output stride."""
     pairs = synth.synth_catalog(n_near=200, n_deep=40, seed=13)
     dev, cat = _dev_and_oracle(native, orc, pairs, grav=0)
     times = np.arange(0.0, 300.0, 5.0)
     ref = synth.START_JD + 0.25
     off = (ref - dev.epochs) * 1440.0
+    lay = native.TIME_MAJOR if layout == "time_major" else native.SAT_MAJOR
+    olay = orc.TIME_MAJOR if layout == "time_major" else orc.SAT_MAJOR
+    shape = (len(times), dev.n, 3) if lay == native.TIME_MAJOR else (dev.n, len(times), 3)
     for mode, omode, tol in ((native.OUT_ECEF, orc.ECEF, 1e-6), (native.OUT_GEODETIC, orc.GEODETIC, 1e-6)):
-        pos = np.empty((len(times), dev.n, 3))
+        pos = np.empty(shape)
         vel = np.empty_like(pos)
-        dev.propagate_host(times, off, pos=pos, vel=vel, mode=mode, reference_jd=ref)
-        _, p0, v0 = cat.propagate(times, off, mode=omode, reference_jd=ref, layout=orc.TIME_MAJOR)
+        dev.propagate_host(times, off, pos=pos, vel=vel, mode=mode, reference_jd=ref, layout=lay)
+        _, p0, v0 = cat.propagate(times, off, mode=omode, reference_jd=ref, layout=olay)
         if mode == native.OUT_GEODETIC:
             assert np.abs(pos[..., :2] - p0[..., :2]).max() < 1e-10  # rad
             assert np.abs(pos[..., 2] - p0[..., 2]).max() < tol      # km
         else:
             assert np.abs(pos - p0).max() < tol
         assert np.abs(vel - v0).max() < 1e-9
+    if lay == native.SAT_MAJOR:
+        # masked satellites keep their sentinel in the satellite-major kernels too
+        mask = (np.arange(dev.n) % 3 != 0).astype(np.uint8)
+        pos = np.full(shape, -7.0)
+        dev.propagate_host(times, off, pos=pos, mask=mask, layout=lay)
+        _, p0, _ = cat.propagate(times, off, layout=olay, velocities=False)
+        assert (pos[mask == 0] == -7.0).all()
+        assert np.abs(pos[mask == 1] - p0[mask == 1]).max() < TOL_R
+        return
     # mask + output stride: untouched cells keep their sentinel
     stride = dev.n + 7
     mask = (np.arange(dev.n) % 3 != 0).astype(np.uint8)
@@ -292,6 +307,15 @@ def test_fp32_outputs(native, orc, synth, layout):
     assert np.abs(v - v0).max() <= 0.5 * np.spacing(np.float32(np.abs(v0).max())) + 1e-9
     exact = (p == p0.astype(np.float32)).mean()
     assert exact > 0.9999, exact  # differs only where the fp64 value sits within 1e-8 km of a rounding boundary
+    # fp32 stores behind the ECEF epilogue (FRAME instantiations of both kernels)
+    ref = synth.START_JD
+    dev.propagate_device(times, off, p32.data_ptr(), v32.data_ptr(), layout=lay, stream=st.cuda_stream, f32=True,
+                         mode=native.OUT_ECEF, reference_jd=ref)
+    dev.synchronize()
+    st.synchronize()
+    _, p0, v0 = cat.propagate(times, off, layout=lay, threads=8, mode=orc.ECEF, reference_jd=ref)
+    assert np.abs(p32.cpu().numpy() - p0).max() <= 0.5 * np.spacing(np.float32(np.abs(p0).max())) + 1e-6
+    assert np.abs(v32.cpu().numpy() - v0).max() <= 0.5 * np.spacing(np.float32(np.abs(v0).max())) + 1e-9
 
 
 def test_fp32_config5_shape_properties(native, orc, synth):
