@@ -99,6 +99,11 @@ struct azh_constellation {
     DevBuf<double> d_times, d_offsets, d_sin, d_cos, d_seeds;
     DevBuf<double> d_tgt, d_part_d2, d_out_d; // fused screen: target track, partial minima, results
     DevBuf<unsigned> d_part_t, d_out_t;
+    // one satellite x many times (Satrec.sgp4 / sgp4_array / c_api sgp4_propagate*): persistent scratch so
+    // that a scalar call costs one small H2D, one launch, one D2H and one synchronisation -- no allocation
+    DevBuf<double> d_one_t, d_one_o;
+    DevBuf<unsigned char> d_one_e;
+    void *h_stage = nullptr; // pinned host staging for small calls (kOneStage points)
     bool seeds_valid = false; // resonance seeds match the staged times/offsets and tile
     unsigned seeds_tile = 0;
     bool seeds_rows = false; // seed table laid out for the lane = time kernel (64-point chunks)
@@ -134,6 +139,10 @@ void destroy(azh_constellation *c)
     c->d_out_d.release();
     c->d_part_t.release();
     c->d_out_t.release();
+    c->d_one_t.release();
+    c->d_one_o.release();
+    c->d_one_e.release();
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     c->d_mask.release();
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -493,6 +502,63 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         c->timed = true;
     }
     return AZ_OK;
+}
+
+constexpr size_t kOneStage = 1024; // points served through the pinned staging buffer
+
+// one satellite x n times.  interleaved = 1: out6 is n x 6 (x,y,z,vx,vy,vz; c_api batch layout); otherwise
+// pos (n x 3), vel (n x 3, optional), err (n, optional).
+int32_t run_one_satellite(azh_constellation *c, size_t sat, const double *tsince, size_t n, int interleaved,
+                          double *out6, double *pos, double *vel, uint8_t *err)
+{
+    if (n > 0xffffffffu) return AZ_ERR_VALUE;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    hipStream_t st = c->s_main;
+    if (c->d_one_t.ensure(n) != AZ_OK || c->d_one_o.ensure(6 * n) != AZ_OK || c->d_one_e.ensure(n) != AZ_OK) return AZ_ERR_HIP;
+    const bool staged = n <= kOneStage;
+    if (staged && !c->h_stage) HIP_TRY(hipHostMalloc(&c->h_stage, kOneStage * (7 * sizeof(double) + 8), hipHostMallocDefault));
+    double *hs_t = static_cast<double *>(c->h_stage);
+    double *hs_o = hs_t ? hs_t + kOneStage : nullptr;
+    uint8_t *hs_e = hs_o ? reinterpret_cast<uint8_t *>(hs_o + 6 * kOneStage) : nullptr;
+    double *d_p = c->d_one_o.p, *d_v = c->d_one_o.p + 3 * n;
+    if (staged) {
+        memcpy(hs_t, tsince, sizeof(double) * n);
+        HIP_TRY(hipMemcpyAsync(c->d_one_t.p, hs_t, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->d_one_t.p, tsince, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(k_one_satellite, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
+                       (unsigned)sat, c->d_one_t.p, (unsigned)n, d_p, interleaved ? (double *)nullptr : d_v,
+                       interleaved ? (unsigned char *)nullptr : c->d_one_e.p, interleaved, c->g, (const double *)nullptr, 0);
+    HIP_TRY(hipGetLastError());
+    int32_t rc = AZ_OK;
+    if (staged) {
+        if (!hip_ok(hipMemcpyAsync(hs_o, c->d_one_o.p, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, st), "D2H") ||
+            (!interleaved && !hip_ok(hipMemcpyAsync(hs_e, c->d_one_e.p, n, hipMemcpyDeviceToHost, st), "D2H")) ||
+            !hip_ok(hipStreamSynchronize(st), "sync"))
+            rc = AZ_ERR_HIP;
+        if (rc == AZ_OK) {
+            if (interleaved) {
+                memcpy(out6, hs_o, sizeof(double) * 6 * n);
+            } else {
+                memcpy(pos, hs_o, sizeof(double) * 3 * n);
+                if (vel) memcpy(vel, hs_o + 3 * n, sizeof(double) * 3 * n);
+                if (err) memcpy(err, hs_e, n);
+            }
+        }
+    } else {
+        bool ok = true;
+        if (interleaved) {
+            ok = hip_ok(hipMemcpyAsync(out6, c->d_one_o.p, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, st), "D2H");
+        } else {
+            ok = hip_ok(hipMemcpyAsync(pos, d_p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st), "D2H");
+            if (ok && vel) ok = hip_ok(hipMemcpyAsync(vel, d_v, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st), "D2H");
+            if (ok && err) ok = hip_ok(hipMemcpyAsync(err, c->d_one_e.p, n, hipMemcpyDeviceToHost, st), "D2H");
+        }
+        if (!ok || !hip_ok(hipStreamSynchronize(st), "sync")) rc = AZ_ERR_HIP;
+    }
+    if (rc != AZ_OK) (void)hipStreamSynchronize(st);
+    return rc;
 }
 
 } // namespace
@@ -992,32 +1058,7 @@ int32_t azh_propagate_one_host(azh_constellation *c, size_t sat, const double *t
     if (!c || !tsince || !pos) return AZ_ERR_NULL_POINTER;
     if (sat >= c->n) return AZ_ERR_VALUE;
     if (n == 0) return AZ_OK;
-    if (n > 0xffffffffu) return AZ_ERR_VALUE;
-    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
-    double *d_t = nullptr, *d_p = nullptr, *d_v = nullptr;
-    uint8_t *d_e = nullptr;
-    int32_t rc = AZ_OK;
-    hipStream_t st = c->s_main;
-    do {
-        if (!hip_ok(hipMalloc((void **)&d_t, sizeof(double) * n), "hipMalloc") ||
-            !hip_ok(hipMalloc((void **)&d_p, sizeof(double) * 3 * n), "hipMalloc") ||
-            !hip_ok(hipMalloc((void **)&d_v, sizeof(double) * 3 * n), "hipMalloc") ||
-            !hip_ok(hipMalloc((void **)&d_e, n), "hipMalloc")) { rc = AZ_ERR_HIP; break; }
-        if (!hip_ok(hipMemcpyAsync(d_t, tsince, sizeof(double) * n, hipMemcpyHostToDevice, st), "H2D")) { rc = AZ_ERR_HIP; break; }
-        hipLaunchKernelGGL(k_one_satellite, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->d_el,
-                           c->d_flags, c->n_pad, (unsigned)sat, d_t, (unsigned)n, d_p, d_v, d_e, 0, c->g, (const double *)nullptr, 0);
-        if (!hip_ok(hipGetLastError(), "k_one_satellite")) { rc = AZ_ERR_HIP; break; }
-        if (!hip_ok(hipMemcpyAsync(pos, d_p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st), "D2H")) { rc = AZ_ERR_HIP; break; }
-        if (vel && !hip_ok(hipMemcpyAsync(vel, d_v, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st), "D2H")) { rc = AZ_ERR_HIP; break; }
-        if (err && !hip_ok(hipMemcpyAsync(err, d_e, n, hipMemcpyDeviceToHost, st), "D2H")) { rc = AZ_ERR_HIP; break; }
-        if (!hip_ok(hipStreamSynchronize(st), "sync")) { rc = AZ_ERR_HIP; break; }
-    } while (0);
-    if (rc != AZ_OK) (void)hipStreamSynchronize(st);
-    if (d_t) (void)hipFree(d_t);
-    if (d_p) (void)hipFree(d_p);
-    if (d_v) (void)hipFree(d_v);
-    if (d_e) (void)hipFree(d_e);
-    return rc;
+    return run_one_satellite(c, sat, tsince, n, 0, nullptr, pos, vel, err);
 }
 
 // ======================================================================================= (A)
@@ -1101,26 +1142,7 @@ int32_t sgp4_propagate_batch(void *h, const double *times, double *results, uint
 {
     if (!h || !times || !results) return AZ_ERR_NULL_POINTER;
     if (count == 0) return AZ_OK;
-    azh_constellation *c = static_cast<Sgp4Handle *>(h)->c;
-    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
-    double *d_t = nullptr, *d_o = nullptr;
-    int32_t rc = AZ_OK;
-    hipStream_t st = c->s_main;
-    do {
-        if (!hip_ok(hipMalloc((void **)&d_t, sizeof(double) * count), "hipMalloc") ||
-            !hip_ok(hipMalloc((void **)&d_o, sizeof(double) * 6 * count), "hipMalloc")) { rc = AZ_ERR_HIP; break; }
-        if (!hip_ok(hipMemcpyAsync(d_t, times, sizeof(double) * count, hipMemcpyHostToDevice, st), "H2D")) { rc = AZ_ERR_HIP; break; }
-        hipLaunchKernelGGL(k_one_satellite, dim3((count + 63) / 64), dim3(64), 0, st, c->d_el, c->d_flags,
-                           c->n_pad, 0u, d_t, count, d_o, (double *)nullptr, (unsigned char *)nullptr, 1, c->g,
-                           (const double *)nullptr, 0);
-        if (!hip_ok(hipGetLastError(), "k_one_satellite")) { rc = AZ_ERR_HIP; break; }
-        if (!hip_ok(hipMemcpyAsync(results, d_o, sizeof(double) * 6 * count, hipMemcpyDeviceToHost, st), "D2H")) { rc = AZ_ERR_HIP; break; }
-        if (!hip_ok(hipStreamSynchronize(st), "sync")) { rc = AZ_ERR_HIP; break; }
-    } while (0);
-    if (rc != AZ_OK) (void)hipStreamSynchronize(st);
-    if (d_t) (void)hipFree(d_t);
-    if (d_o) (void)hipFree(d_o);
-    return rc;
+    return run_one_satellite(static_cast<Sgp4Handle *>(h)->c, 0, times, count, 1, results, nullptr, nullptr, nullptr);
 }
 
 } // extern "C"

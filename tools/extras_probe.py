@@ -81,4 +81,18 @@ for m in (1_000_000, 10_000_000):
     dt = time.perf_counter() - t0
     out["one_sat_%d_times_host_s" % m] = dt
     out["one_sat_%d_mprops_host" % m] = m / dt / 1e6
+# scalar calls: python-sgp4 style Satrec.sgp4(jd, fr) in a loop, and the raw C-ABI call
+from astroz_amd.api import Satrec, WGS72  # noqa: E402
+sat = Satrec.twoline2rv(pairs[0][0], pairs[0][1], WGS72)
+sat.sgp4(sat.jdsatepoch, sat.jdsatepochF)
+t0 = time.perf_counter()
+for k in range(500):
+    sat.sgp4(sat.jdsatepoch, sat.jdsatepochF + k / 1440.0)
+out["Satrec_sgp4_scalar_call_us"] = (time.perf_counter() - t0) / 500 * 1e6
+one = np.array([12.5])
+dev.propagate_one(0, one)
+t0 = time.perf_counter()
+for k in range(500):
+    dev.propagate_one(0, one)
+out["propagate_one_scalar_call_us"] = (time.perf_counter() - t0) / 500 * 1e6
 print(json.dumps(out, indent=1))
