@@ -139,6 +139,12 @@ void orc_screen_target(const orc_sat *sats, size_t n_sats, const double *times_m
 size_t orc_coarse_screen(const double *positions, size_t num_sats, size_t num_times, double threshold_km,
                          const uint8_t *valid_mask, uint32_t *out_pairs, uint32_t *out_t, size_t max_results);
 
+/* astroz_batch8.c: CPU baseline in the reference's multithreaded SIMD design (8 satellites per
+ * vector, polynomial sincos/atan2; NOT the parity oracle: ~1e-7 rad atan2 like the reference's). */
+size_t orc_batch8_propagate(const orc_sat *sats, size_t n_sats, const double *times_min, size_t n_times,
+                            const double *offsets_min, double *pos, double *vel, int layout, size_t stride,
+                            int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

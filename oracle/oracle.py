@@ -198,6 +198,58 @@ def coarse_screen(positions, threshold, valid_mask=None, max_results=10_000_000)
     return pairs[:k].copy(), tt[:k].copy()
 
 
+_b8 = None
+
+
+def batch8_lib():
+    """libastroz_batch8.<cpu tag>.so, compiled with -march=native on THIS host on first use."""
+    global _b8
+    if _b8 is None:
+        import hashlib
+        flags = ""
+        try:
+            for ln in open("/proc/cpuinfo"):
+                if ln.startswith("flags"):
+                    flags = ln
+                    break
+        except OSError:
+            pass
+        tag = hashlib.sha1(flags.encode()).hexdigest()[:10]
+        path = os.path.join(_HERE, "libastroz_batch8.%s.so" % tag)
+        src = os.path.join(_HERE, "astroz_batch8.c")
+        if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "batch8", "BATCH8_TAG=" + tag])
+        L = C.CDLL(path)
+        L.orc_batch8_propagate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_size_t, C.c_int]
+        L.orc_batch8_propagate.restype = C.c_size_t
+        _b8 = L
+    return _b8
+
+
+def _catalog_propagate_batch8(self, times_min, offsets_min=None, *, velocities=True, layout=SAT_MAJOR, threads=1,
+                              out=None):
+    """CPU baseline in the reference's SIMD design (astroz_batch8.c); near-earth members only.
+    Returns (failed_batch_steps, pos, vel)."""
+    assert not self.is_deep.any() and not self.init_rc.any(), "batch8 baseline: near-earth, initialised members only"
+    times = np.ascontiguousarray(times_min, dtype=np.float64)
+    nt, ns = len(times), self.n
+    shape = (ns, nt, 3) if layout == SAT_MAJOR else (nt, ns, 3)
+    if out is not None:
+        pos, vel = out
+    else:
+        pos = np.zeros(shape)
+        vel = np.zeros(shape) if velocities else None
+    off = None if offsets_min is None else np.ascontiguousarray(offsets_min, dtype=np.float64)
+    failed = batch8_lib().orc_batch8_propagate(
+        C.addressof(self._buf), ns, times.ctypes.data, nt, None if off is None else off.ctypes.data, pos.ctypes.data,
+        None if vel is None else vel.ctypes.data, layout, 0, int(threads))
+    return failed, pos, vel
+
+
+Catalog.propagate_batch8 = _catalog_propagate_batch8
+
+
 def gstime(jd):
     return lib().orc_gstime(float(jd))
 
