@@ -223,6 +223,23 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(tt[0]), float(tt[1])
 
+    # config 4 (--gather): the kernel alone, timed the same way, so that t_kernel and t_allgather can be
+    # reported next to t_total
+    kernel_only_ms = None
+    if gathered is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+        k0 = torch.cuda.Event(enable_timing=True)
+        k1 = torch.cuda.Event(enable_timing=True)
+        k0.record(stream)
+        for _ in range(a.steps):
+            dev.propagate_device_cached(p_ptr, v_ptr, layout=layout, stream=sptr, f32=a.f32_out)
+        k1.record(stream)
+        torch.cuda.synchronize()
+        kt = torch.tensor([k0.elapsed_time(k1) / a.steps], dtype=torch.float64, device=cuda)
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+        kernel_only_ms = float(kt[0])
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -231,6 +248,8 @@ def main():
     props_per_step = n_total * n_times if (a.scaling == "strong" and world > 1) else n_local * n_times * world
     value = props_per_step * a.steps / elapsed
     launch_s = (ev_ms / 1e3) / a.steps            # average duration of one launch (HIP events on the launch stream)
+    if kernel_only_ms is not None:
+        launch_s = kernel_only_ms / 1e3           # with --gather the step also holds the collective
     local_props = n_local * n_times
     n_tiles = max(1, -(-n_times // max(a.tile, 1))) if a.tile else None
     bytes_per_launch = local_props * (BYTES_OUT_PV if vel_on else BYTES_OUT_P) * (0.5 if a.f32_out else 1.0) + n_times * 8 + \
@@ -261,6 +280,8 @@ def main():
                             ", per GPU" if (world > 1 and a.scaling == "weak") else ""),
             "n_sats_per_gpu": n_local, "n_times": n_times, "gather": bool(gathered is not None),
             "precondition_ms": a.precondition_ms, "precondition_steps": n_pre,
+            **({"t_kernel_ms": kernel_only_ms, "t_allgather_ms": elapsed / a.steps * 1e3 - kernel_only_ms,
+                "t_total_ms": elapsed / a.steps * 1e3} if kernel_only_ms is not None else {}),
             "parallelism": "satellite-sharded x%d, no data-path collective" % world if gathered is None
                            else "satellite-sharded x%d + RCCL all-gather" % world,
         },
