@@ -56,6 +56,9 @@ def parse_args():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--gather", action="store_true", help="all-gather the result blocks (RCCL)")
     ap.add_argument("--tile", type=int, default=0, help="time steps per workgroup (0 = auto)")
+    ap.add_argument("--stride-align", type=int, default=0,
+                    help="time-major only: round the row length (out_stride_sats) up to a multiple of this many "
+                         "satellites (16 = 128-byte aligned rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0)
     return ap.parse_args()
@@ -151,7 +154,10 @@ def main():
     offsets = (synth.START_JD - dev.epochs) * 1440.0
     vel_on = not a.pos_only
     layout = _native.TIME_MAJOR if a.layout == "time" else _native.SAT_MAJOR
-    shape = (n_times, n_local, 3) if layout == _native.TIME_MAJOR else (n_local, n_times, 3)
+    stride = 0
+    if layout == _native.TIME_MAJOR and a.stride_align > 0:
+        stride = -(-n_local // a.stride_align) * a.stride_align
+    shape = (n_times, stride or n_local, 3) if layout == _native.TIME_MAJOR else (n_local, n_times, 3)
     cuda = torch.device("cuda", local_rank)
     odt = torch.float32 if a.f32_out else torch.float64
     pos = torch.empty(shape, dtype=odt, device=cuda)
@@ -168,14 +174,14 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        dev.propagate_device_cached(p_ptr, v_ptr, layout=layout, stream=sptr, f32=a.f32_out)
+        dev.propagate_device_cached(p_ptr, v_ptr, layout=layout, stride=stride, stream=sptr, f32=a.f32_out)
         if gathered is not None:
             dist.all_gather_into_tensor(gathered[0], pos)
             if vel_on:
                 dist.all_gather_into_tensor(gathered[1], vel)
 
     # stage inputs (times, offsets) once; this call also runs the kernels (counts as warm-up)
-    dev.propagate_device(times, offsets, p_ptr, v_ptr, layout=layout, stream=sptr, f32=a.f32_out)
+    dev.propagate_device(times, offsets, p_ptr, v_ptr, layout=layout, stride=stride, stream=sptr, f32=a.f32_out)
     torch.cuda.synchronize()
     last_kernel_ms = dev.last_kernel_ms()   # the library's own hipEvent pair around that launch
     dev.set_timing(False)                    # the timed loop below is bracketed by events of its own
@@ -233,7 +239,7 @@ def main():
         k1 = torch.cuda.Event(enable_timing=True)
         k0.record(stream)
         for _ in range(a.steps):
-            dev.propagate_device_cached(p_ptr, v_ptr, layout=layout, stream=sptr, f32=a.f32_out)
+            dev.propagate_device_cached(p_ptr, v_ptr, layout=layout, stride=stride, stream=sptr, f32=a.f32_out)
         k1.record(stream)
         torch.cuda.synchronize()
         kt = torch.tensor([k0.elapsed_time(k1) / a.steps], dtype=torch.float64, device=cuda)
