@@ -543,3 +543,17 @@ def test_screen_edge_cases(native, synth):
     pp, tt = native.coarse_screen(buf, 1.0)
     assert len(tt) == 18 and tt.tolist() == sorted(tt.tolist())
     assert pp[:6].tolist() == [[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]]
+
+
+def test_empty_time_grid_and_single_point(native, orc, synth):
+    pairs = synth.synth_catalog(n_near=65, n_deep=2, seed=4)
+    dev, cat = _dev_and_oracle(native, orc, pairs)
+    pos = np.full((0, dev.n, 3), 1.0)
+    dev.propagate_host(np.zeros(0), None, pos=pos)  # no-op
+    for lay, shape in ((native.TIME_MAJOR, (1, dev.n, 3)), (native.SAT_MAJOR, (dev.n, 1, 3))):
+        pos = np.empty(shape)
+        vel = np.empty(shape)
+        dev.propagate_host(np.array([123.456]), None, pos=pos, vel=vel, layout=lay)
+        _, p0, v0 = cat.propagate(np.array([123.456]), None,
+                                  layout=orc.TIME_MAJOR if lay == native.TIME_MAJOR else orc.SAT_MAJOR)
+        assert np.abs(pos - p0).max() < TOL_R and np.abs(vel - v0).max() < TOL_V

@@ -232,3 +232,18 @@ def test_python_tle_class():
         astroz_amd.Tle("not a tle")
     with pytest.raises(TypeError):
         astroz_amd.Tle(b"bytes")
+
+
+def test_empty_and_malformed_inputs_are_rejected_before_any_device_work():
+    """Argument errors come back as the reference's codes without touching the GPU."""
+    from astroz_amd import _native
+    z = np.zeros(0)
+    with pytest.raises(_native.NativeError) as ei:
+        _native.DeviceConstellation.from_elements(z, z, z, z, z, z, z, z)
+    assert ei.value.code == -20  # AZ_ERR_VALUE: empty constellation
+    with pytest.raises(_native.NativeError) as ei:
+        _native.DeviceConstellation.from_tle_text("no element sets in here\n")
+    assert ei.value.code == -1   # AZ_ERR_BAD_TLE_LENGTH: nothing parsable
+    with pytest.raises(_native.NativeError) as ei:
+        _native.DeviceConstellation.from_tle_lines([("1 25544U", "2 25544")])
+    assert ei.value.code == -1   # lines shorter than 69 columns (src/Tle.zig L50)
