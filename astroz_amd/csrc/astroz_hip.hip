@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -326,7 +327,10 @@ bool use_rows(const PropArgs &a, int layout, bool deep)
 {
     // satellite-major near-earth rows (and the fused screen, which stores nothing): one wave per
     // satellite, lane = time
-    (void)deep; // both populations have a lane = time kernel (k_rows, k_rows_deep)
+    // both populations have a lane = time kernel (k_rows, k_rows_deep).  Deep-space rows use theirs for the
+    // time-major layout too: the lane = satellite form needs 250+ VGPRs (1-2 waves/SIMD), which costs more
+    // than the scattered 24-byte stores of a few thousand rows.
+    if (deep && layout == AZ_LAYOUT_TIME_MAJOR && a.n_times >= 32) return true;
     return (layout == AZ_LAYOUT_SAT_MAJOR || a.screen_target) && a.n_times >= 32;
 }
 
@@ -358,6 +362,7 @@ void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStr
     if (use_rows(a, layout, deep)) {
         PropArgs b = a;
         b.tile = rows_tile(a.n_list, a.n_times, a.tile_forced);
+        b.tm_rows = (deep && layout == AZ_LAYOUT_TIME_MAJOR && !a.screen_target) ? 1 : 0;
         dim3 grid((a.n_list + 7) / 8 * 8, (a.n_times + b.tile - 1) / b.tile);
         if (a.screen_target) {
             if (deep) hipLaunchKernelGGL((k_rows_deep<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);

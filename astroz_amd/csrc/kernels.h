@@ -57,6 +57,7 @@ struct PropArgs {
     const double *seeds;         // deep space: resonance state at each tile start, [tile][3][n_list]; may be null
     int mode;
     int f32; // outputs are float arrays (pos/vel point to float): fp64 arithmetic, results rounded once at the store
+    int tm_rows; // k_rows_deep only: write the time-major layout (scattered 24-byte pieces, see launch_propagate)
     // fused single-target conjunction screen (sink instead of stores): the target's TEME track,
     // [n_times][3], NaN where the target itself failed; partial minima per (segment or tile, list slot)
     const double *screen_target;
@@ -716,6 +717,14 @@ __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
             if (p.err && live) p.err[(size_t)s * p.n_times + i] = (unsigned char)rc;
         }
         if (live) {
+            if (p.tm_rows) {
+                // time-major output from the lane = time kernel: each lane's 24 bytes land n_sats*24 bytes apart
+                // (plain stores: the rest of each cache line belongs to neighbouring satellites)
+                const size_t ob = ((size_t)i * p.stride_sats + s) * 3;
+                az_put3(reinterpret_cast<out_t *>(p.pos) + ob, r);
+                if (VEL) az_put3(reinterpret_cast<out_t *>(p.vel) + ob, v);
+                continue;
+            }
             az_put3_stream(prow + (size_t)i * 3, r);
             if (VEL) az_put3_stream(vrow + (size_t)i * 3, v);
         }
