@@ -2,11 +2,17 @@
 //
 // Work decomposition (the reverse of the reference's): the reference vectorises 8 satellites per
 // AVX-512 register and calls a kernel 1,685 x 1,440 times through a function pointer
-// (src/Constellation.zig L387-434, src/dispatch.zig L18-23).  Here one wave64 lane owns one
-// satellite for a whole tile of time steps: the ~32 per-satellite constants are loaded once per
-// tile with coalesced 512-B wave loads from the SoA table and stay in VGPRs; slowly drifting
-// angles are carried as (sin,cos) pairs between steps; a 2-D grid (satellite blocks x time tiles)
-// supplies the tens of thousands of waves needed to fill 256 CUs.
+// (src/Constellation.zig L387-434, src/dispatch.zig L18-23).  Here the lane mapping follows the
+// output layout, because the layout decides which mapping stores coalesced:
+//   k_rows / k_rows_deep  one wave64 per satellite, lane = time: per-satellite constants are
+//                         wave-uniform (SGPRs + LDS broadcast), control flow is uniform by
+//                         construction, a wave's 64 results are contiguous in a satellite-major row;
+//   k_propagate           one lane per satellite for a tile of time steps: constants in VGPRs / LDS
+//                         columns, 64 satellites' results of one step are contiguous in a time-major row.
+// Slowly drifting angles are carried as (sin,cos) pairs between a lane's steps in both mappings; 2-D
+// grids (rows x time segments, satellite blocks x time tiles) supply the tens of thousands of waves
+// needed to fill 256 CUs, with the workgroup -> XCD assignment chosen so that every XCD's L2 sees a
+// contiguous part of the element table.
 #pragma once
 #include <hip/hip_runtime.h>
 
