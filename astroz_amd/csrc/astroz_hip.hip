@@ -98,6 +98,8 @@ struct azh_constellation {
     unsigned n_sgp4 = 0, n_sdp4 = 0, n_bad = 0;
     // per-call scratch
     DevBuf<double> d_times, d_offsets, d_sin, d_cos, d_seeds;
+    DevBuf<double> d_inc;       // uniform grids: per-satellite rotation increments (k_prep_inc), [12][n_pad]
+    double uniform_step = 0.0;  // step of the staged grid if it is uniform, else 0
     DevBuf<double> d_tgt, d_part_d2, d_out_d; // fused screen: target track, partial minima, results
     DevBuf<unsigned> d_part_t, d_out_t;
     // one satellite x many times (Satrec.sgp4 / sgp4_array / c_api sgp4_propagate*): persistent scratch so
@@ -117,6 +119,7 @@ struct azh_constellation {
     bool timed = false;
     bool timing = true; // record the ev_t0/ev_t1 pair around every launch set (azh_set_timing)
     unsigned tile_sgp4 = 0, tile_sdp4 = 0;
+    bool fast_path = true; // use the branch-free uniform-grid step where it applies (azh_set_fast_path)
 };
 
 namespace {
@@ -135,6 +138,7 @@ void destroy(azh_constellation *c)
     c->d_sin.release();
     c->d_cos.release();
     c->d_seeds.release();
+    c->d_inc.release();
     c->d_tgt.release();
     c->d_part_d2.release();
     c->d_out_d.release();
@@ -418,6 +422,23 @@ int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, 
     c->cached_n_times = (unsigned)n_times;
     c->cached_mode = mode;
     c->seeds_valid = false; // new time grid / offsets
+    // uniform grid?  times[i] == times[0] + i*step up to the rounding of the grid itself: the fast step
+    // (fast_step.h) then advances its carried angles by per-satellite constant rotations
+    c->uniform_step = 0.0;
+    if (n_times >= 2) {
+        const double t0 = times[0], step = (times[n_times - 1] - t0) / (double)(n_times - 1);
+        double tmax = std::max(std::fabs(t0), std::fabs(times[n_times - 1]));
+        const double tol = 4.0 * 2.220446049250313e-16 * std::max(tmax, std::fabs(step));
+        bool uni = std::isfinite(step) && step != 0.0;
+        for (size_t i = 1; uni && i < n_times; ++i) uni = std::fabs(times[i] - (t0 + (double)i * step)) <= tol;
+        if (uni) {
+            if (c->d_inc.ensure((size_t)12 * c->n_pad) != AZ_OK) return AZ_ERR_HIP;
+            hipLaunchKernelGGL(k_prep_inc, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, st, c->d_el, c->n, c->n_pad,
+                               step, c->d_inc.p);
+            HIP_TRY(hipGetLastError());
+            c->uniform_step = step;
+        }
+    }
     return AZ_OK;
 }
 
@@ -473,6 +494,8 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     a.mode = c->cached_mode;
     a.f32 = f32;
     a.g = c->g;
+    a.uniform_step = c->fast_path ? c->uniform_step : 0.0;
+    a.inc = (a.uniform_step != 0.0) ? c->d_inc.p : nullptr;
 
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
     if (d_err) HIP_TRY(hipMemsetAsync(d_err, 0, c->n * (size_t)n_times, st));
@@ -678,6 +701,13 @@ int32_t azh_set_timing(azh_constellation *c, int32_t enabled)
     return AZ_OK;
 }
 
+int32_t azh_set_fast_path(azh_constellation *c, int32_t enabled)
+{
+    if (!c) return AZ_ERR_NULL_POINTER;
+    c->fast_path = enabled != 0;
+    return AZ_OK;
+}
+
 int32_t azh_set_time_tile(azh_constellation *c, uint32_t sgp4_tile, uint32_t sdp4_tile)
 {
     if (!c) return AZ_ERR_NULL_POINTER;
@@ -767,6 +797,8 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
         a.stride_sats = c->n;
         a.mode = AZ_OUT_TEME;
         a.g = c->g;
+        a.uniform_step = c->fast_path ? c->uniform_step : 0.0;
+        a.inc = (a.uniform_step != 0.0) ? c->d_inc.p : nullptr;
         a.screen_target = c->d_tgt.p;
         PropArgs near = a, deep = a;
         unsigned parts_near = 0, parts_deep = 0;

@@ -1,0 +1,240 @@
+// fast_step.h -- branch-free near-earth step for uniform time grids ("optimistic" path).
+//
+// Same quantities as az_sgp4_step (Sgp4Batch.propagateBatchDirect, src/Sgp4Batch.zig L113-157, +
+// Sgp4.keplerAndPosVel, src/Sgp4.zig L646-750), restricted to the case nine propagations in ten fall in:
+//   * the time grid is uniform, so the three slowly drifting angles advance by the SAME increment
+//     between a lane's consecutive steps: (sin,cos) of mdot*dt, argpdot*dt, nodedot*dt are
+//     per-satellite constants (prepared once per grid by k_prep_inc) and every carried pair moves by
+//     one angle addition (4 FMA-class instructions, no polynomial, no vote);
+//   * the orbit is near-circular (el^2 < 1.6e-5) and every small angle sits inside its usual
+//     rotation tier.
+// Instead of choosing tiers with wave votes and branches the step runs straight through and RETURNS a
+// per-lane `bad` predicate; the caller votes once per step and, on a violation, hands the remaining
+// grid points to the generic az_sgp4_step loop (results are only stored after the vote, so nothing
+// wrong ever reaches memory).  ~210 fp64 instructions per propagation against ~300 executed by the
+// generic loop (whose tier votes cost compares, branches and the register moves at every merge).
+#pragma once
+#include "propagate_device.h"
+
+// per-satellite constants of the fast step (wave-uniform in the lane = time kernel, per lane in the
+// lane = satellite kernel).  Folded products differ from the table rows by one rounding at most.
+struct FastK {
+    // drag polynomials (Horner): tempa = 1 - t (cc1 + t (d2 + t (d3 + t d4)));
+    // no_unkozai * templ = t^2 (nl2 + t (nl3 + t (nl4 + t nl5)))
+    double cc1, d2, d3, d4, nl2, nl3, nl4, nl5;
+    double eta, omgcof, xmcof, xd; // th = omgcof t + xmcof (1 + eta cos M)^3 - xd,  xd = xmcof delmo
+    double bc4, bc5, ecb;          // em = ecb - bc4 t - bc5 sin(mm),  ecb = ecco + bc5 sinmao
+    double sab;                    // sqrt(a_base)
+    double aycof, xlcof, xnodcf;
+    double sinio, cosio;
+    double k_mrt, k_c2u, k_su, k_node, k_inc, x1mth2, k_rv;
+    // (sin,cos) of the per-step increments of M, argp, node (linear part)
+    double sdA, cdA, sdW, cdW, sdO, cdO;
+};
+
+// carried (sin,cos) pairs: M = mo + mdot t, W = argpo + argpdot t, O = nodeo + nodedot t (the
+// xnodcf t^2 part of the node is folded into the J2 node correction, a tiny rotation anyway)
+struct FastCarry {
+    double sA, cA, sW, cW, sO, cO;
+};
+
+// row offsets of the increment table written by k_prep_inc: inc[(AZ_INC_* + 6*which) * n_pad + sat],
+// which = 0: dt = 64 grid steps (lane = time kernels), 1: dt = one grid step (lane = satellite kernels)
+enum { AZ_INC_sdA, AZ_INC_cdA, AZ_INC_sdW, AZ_INC_cdW, AZ_INC_sdO, AZ_INC_cdO, AZ_INC_NUM };
+
+template <class K>
+AZ_DEVICE void az_load_fast(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags,
+                            const double *__restrict__ inc, int which, K &k)
+{
+#define L(f) el[(size_t)F_##f * n_pad + i]
+    const bool ho = !(flags & AZ_FLAG_ISIMP);
+    const double no = L(no_unkozai);
+    k.cc1 = L(cc1); k.d2 = L(d2); k.d3 = L(d3); k.d4 = L(d4);
+    k.nl2 = no * L(t2cof); k.nl3 = no * L(t3cof); k.nl4 = no * L(t4cof); k.nl5 = no * L(t5cof);
+    k.eta = L(eta);
+    k.omgcof = ho ? L(omgcof) : 0.0;
+    k.xmcof = ho ? L(xmcof) : 0.0;
+    k.xd = k.xmcof * L(delmo);
+    k.bc4 = L(bc4);
+    k.bc5 = ho ? L(bc5) : 0.0;
+    k.ecb = fma(k.bc5, L(sinmao), L(ecco));
+    k.sab = L(sqrt_a_base);
+    k.aycof = L(aycof); k.xlcof = L(xlcof); k.xnodcf = L(xnodcf);
+    k.sinio = L(sinio); k.cosio = L(cosio);
+    az_j2_factors(L(con41), L(x1mth2), L(x7thm1), k.sinio, k.cosio, k.k_mrt, k.k_c2u, k.k_su, k.k_node, k.k_inc,
+                  k.k_rv);
+    k.x1mth2 = L(x1mth2);
+    const double *q = inc + (size_t)(6 * which) * n_pad + i;
+    k.sdA = q[(size_t)AZ_INC_sdA * n_pad]; k.cdA = q[(size_t)AZ_INC_cdA * n_pad];
+    k.sdW = q[(size_t)AZ_INC_sdW * n_pad]; k.cdW = q[(size_t)AZ_INC_cdW * n_pad];
+    k.sdO = q[(size_t)AZ_INC_sdO * n_pad]; k.cdO = q[(size_t)AZ_INC_cdO * n_pad];
+#undef L
+}
+
+// seed the carried pairs with full sincos at time t (the step BEFORE the first one to be produced: every
+// az_sgp4_fast_step call first advances the pairs by one increment)
+AZ_DEVICE void az_seed_fast(const double *__restrict__ el, size_t n_pad, size_t i, double t, FastCarry &st)
+{
+#define L(f) el[(size_t)F_##f * n_pad + i]
+    az_sincos(fma(L(mdot), t, L(mo)), st.sA, st.cA);
+    az_sincos(fma(L(argpdot), t, L(argpo)), st.sW, st.cW);
+    az_sincos(fma(L(nodedot), t, L(nodeo)), st.sO, st.cO);
+#undef L
+}
+
+// (s,c) <- (sin,cos)(angle + d): two FMAs per component.  One more rounding than az_rot_apply's
+// s + (s q + c p) form (1.1e-16 relative); used where the result is consumed, not carried.
+AZ_DEVICE void az_rot_apply2(double &s, double &c, double p, double q)
+{
+    const double ns = fma(c, p, fma(s, q, s));
+    c = fma(-s, p, fma(c, q, c));
+    s = ns;
+}
+// |d| <= 2^-10: sin to d^3, cos to d^2 (dropped d^4/24 < 3.8e-14, d^5/120 < 8e-18)
+AZ_DEVICE void az_rotate_tiny2(double &s, double &c, double d, const RotK &k)
+{
+    const double d2 = d * d;
+    const double q = -0.5 * d2;
+    const double p = fma(d2 * k.n6, d, d);
+    az_rot_apply2(s, c, p, q);
+}
+
+// (p,q) = (sin d, cos d - 1) for |d| <= 1/16: sin to d^7, cos to d^8 (d^9/9! < 3e-17, d^10/10! < 3e-19).
+// Two instructions more than the 2^-7 tier; used for the along-track drag term, which grows with t^2 and
+// leaves the 2^-7 tier within days for high-drag members.
+#define AZ_ROT_16TH 0.0625
+AZ_DEVICE void az_pq_16th(double d, const RotK &k, double &p, double &q)
+{
+    const double d2 = d * d;
+    q = d2 * fma(d2, fma(d2, fma(d2, 1.0 / 40320.0, k.n720), k.p24), -0.5);
+    p = d * fma(d2, fma(d2, fma(d2, -1.0 / 5040.0, k.p120), k.n6), 1.0);
+}
+
+// validation thresholds of the fast step
+#define AZ_FAST_EL2 1.6e-5
+#define AZ_FAST_TEMP2 6.0e-4
+
+// one near-earth propagation on a uniform grid; returns true when an assumption of the fast path does
+// not hold for this lane (the caller must then discard r/v and use az_sgp4_step)
+template <bool VEL, class K>
+AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, double t, FastCarry &st, double r[3],
+                                  double v[3])
+{
+    // advance the carried pairs by their constant increments
+    {
+        const double nsA = fma(st.sA, k.cdA, st.cA * k.sdA);
+        st.cA = fma(st.cA, k.cdA, -(st.sA * k.sdA));
+        st.sA = nsA;
+        const double nsW = fma(st.sW, k.cdW, st.cW * k.sdW);
+        st.cW = fma(st.cW, k.cdW, -(st.sW * k.sdW));
+        st.sW = nsW;
+        const double nsO = fma(st.sO, k.cdO, st.cO * k.sdO);
+        st.cO = fma(st.cO, k.cdO, -(st.sO * k.sdO));
+        st.sO = nsO;
+    }
+    const double sA = st.sA, cA = st.cA;
+    const double t2 = t * t;
+
+    // secular gravity + drag (Sgp4Batch.zig L121-154)
+    const double dm = fma(k.eta, cA, 1.0);
+    const double th = fma(k.xmcof, dm * dm * dm, fma(k.omgcof, t, -k.xd)); // delomg + delm
+    const double tempa = fma(-t, fma(t, fma(t, fma(t, k.d4, k.d3), k.d2), k.cc1), 1.0);
+    const double nl = t2 * fma(t, fma(t, fma(t, k.nl5, k.nl4), k.nl3), k.nl2); // no_unkozai * templ
+    bool bad = !(fabs(th) <= AZ_ROT_SMALL);
+    double p, q;
+    az_pq_small(th, rk, p, q);
+    const double smm = fma(cA, p, fma(sA, q, sA));            // sin(M + th)
+    const double sw = fma(-st.cW, p, fma(st.sW, q, st.sW));   // (sin,cos)(W - th)
+    const double cw = fma(st.sW, p, fma(st.cW, q, st.cW));
+    const double em = fmax(fma(-k.bc5, smm, fma(-k.bc4, t, k.ecb)), 1.0e-6);
+
+    // am = a_base tempa^2: one reciprocal gives 1/sqrt(am) and 1/(am (1 - em^2))
+    const double sqrt_am = k.sab * fabs(tempa);
+    const double am = sqrt_am * sqrt_am;
+    const double omem2 = fma(-em, em, 1.0);
+    const double R = az_rcp(sqrt_am * omem2);
+    const double ra = R * omem2;
+    const double temp = ra * R;
+
+    const double axnl = em * cw;
+    const double aynl = fma(em, sw, temp * k.aycof);
+    // u0 = M + W + no*templ + temp*xlcof*axnl
+    double s = fma(sA, st.cW, cA * st.sW);
+    double c = fma(cA, st.cW, -(sA * st.sW));
+    {
+        const double eps = fma(temp * k.xlcof, axnl, nl);
+        bad |= !(fabs(eps) <= AZ_ROT_16TH);
+        az_pq_16th(eps, rk, p, q);
+        az_rot_apply2(s, c, p, q);
+    }
+
+    // Kepler, near-circular form (see az_kepler_posvel): Newton step from E0 = u, chord step with the
+    // same reciprocal, first-order rotation by the second correction
+    const double el2 = fma(axnl, axnl, aynl * aynl);
+    bad |= !(el2 <= AZ_FAST_EL2);
+    const double rden = az_rcp1(fma(-s, aynl, fma(-c, axnl, 1.0)));
+    const double d0 = fma(axnl, s, -(aynl * c)) * rden;
+    az_pq_small(d0, rk, p, q); // |d0| <= el/(1-el) < 2^-7
+    az_rot_apply2(s, c, p, q);
+    const double d1 = fma(axnl, s, fma(-aynl, c, -d0)) * rden;
+    {
+        const double s1 = fma(c, d1, s);
+        c = fma(-s, d1, c);
+        s = s1;
+    }
+    const double ecose = fma(axnl, c, aynl * s);
+    const double esine = fma(axnl, s, -(aynl * c));
+    const double ome = 1.0 - ecose;
+    double inv_ome = fma(rden, fma(-ome, rden, 1.0), rden);
+    inv_ome = fma(inv_ome, fma(-ome, inv_ome, 1.0), inv_ome);
+    const double betal = fma(el2, fma(el2, -0.125, -0.5), 1.0);   // sqrt(1-x)   (- x^3/16)
+    const double inv_omel2 = fma(el2, el2 + 1.0, 1.0);            // 1/(1-x)     (+ x^3 < 4.1e-15)
+    const double inv_1pb = fma(el2, fma(el2, 0.0625, 0.125), 0.5); // 1/(1+betal) (+ 5x^3/128)
+
+    const double est = esine * inv_1pb;
+    const double sinu = inv_ome * (s - fma(axnl, est, aynl));
+    const double cosu = inv_ome * (c + fma(aynl, est, -axnl));
+    const double sin2u = (sinu + sinu) * cosu;
+    const double cos2u = fma(-2.0 * sinu, sinu, 1.0);
+
+    const double inv_am = ra * ra;
+    const double rl = am * ome;
+    const double inv_pl = inv_am * inv_omel2;
+    const double temp1 = g.half_j2 * inv_pl;
+    const double temp2 = temp1 * inv_pl;
+    bad |= !(temp2 <= AZ_FAST_TEMP2);
+
+    const double mrt = fma(rl, fma(k.k_mrt * temp2, betal, 1.0), k.k_c2u * temp1 * cos2u);
+    const double t2s = temp2 * sin2u;
+    // J2 short-period corrections as tiny rotations (each bounded by 1.5 temp2 <= 9e-4); the secular
+    // xnodcf t^2 part of the node rides on the node correction
+    const double a_nd = fma(k.k_node, t2s, k.xnodcf * t2);
+    bad |= !(fabs(a_nd) <= AZ_ROT_MILLI);
+    double ssu = sinu, csu = cosu, sn = st.sO, cn = st.cO, si = k.sinio, ci = k.cosio;
+    az_rotate_tiny2(ssu, csu, k.k_su * t2s, rk);
+    az_rotate_tiny2(sn, cn, a_nd, rk);
+    az_rotate_tiny2(si, ci, k.k_inc * temp2 * cos2u, rk);
+
+    const double xmx = -sn * ci, xmy = cn * ci;
+    const double ux = fma(xmx, ssu, cn * csu);
+    const double uy = fma(xmy, ssu, sn * csu);
+    const double uz = si * ssu;
+    const double rs = mrt * g.radius_km;
+    r[0] = rs * ux;
+    r[1] = rs * uy;
+    r[2] = rs * uz;
+    if (VEL) {
+        const double rv = ra * g.vkmpersec;         // vkmpersec / sqrt(am)
+        const double vk = rv * inv_ome;             // common factor of rdotl, rvdotl (km/s)
+        const double nxt = rv * inv_am * temp1;     // (nm/xke) temp1, km/s
+        const double mvt = fma(-nxt * k.x1mth2, sin2u, vk * esine);
+        const double rvdot = fma(nxt, fma(k.x1mth2, cos2u, k.k_rv), vk * betal);
+        const double vx = fma(xmx, csu, -(cn * ssu));
+        const double vy = fma(xmy, csu, -(sn * ssu));
+        const double vz = si * csu;
+        v[0] = fma(mvt, ux, rvdot * vx);
+        v[1] = fma(mvt, uy, rvdot * vy);
+        v[2] = fma(mvt, uz, rvdot * vz);
+    }
+    return bad;
+}

@@ -20,6 +20,7 @@
 
 #include "init_device.h"
 #include "propagate_device.h"
+#include "fast_step.h"
 
 #ifndef AZ_BLOCK
 // 256 satellites per workgroup = four independent waves (no barriers anywhere).  The host orders
@@ -27,6 +28,9 @@
 // Kepler-Newton trips share one wave instead of slowing all four, while the group's output rows
 // stay one contiguous 6-KB span per step that a single CU fills within microseconds.
 #define AZ_BLOCK 256
+#endif
+#ifndef AZ_PROP_FAST
+#define AZ_PROP_FAST 1 /* k_propagate (near-earth): try the branch-free fast step first (fast_step.h) */
 #endif
 #ifndef AZ_MIN_WAVES
 #define AZ_MIN_WAVES 1 /* __launch_bounds__ 2nd argument: waves per SIMD the register allocator must allow */
@@ -69,6 +73,10 @@ struct PropArgs {
     const double *screen_target;
     double *part_d2;
     unsigned *part_t;
+    // uniform grids: times[i] = times[0] + i * uniform_step (0 = not uniform), and the per-satellite
+    // rotation increments k_prep_inc prepared for it (fast_step.h); null = generic path only
+    double uniform_step;
+    const double *inc;
     AzGrav g;
 };
 
@@ -198,62 +206,19 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
     const unsigned t0 = blockIdx.y * p.tile;
     const unsigned t1 = min(t0 + p.tile, p.n_times);
 
-    // time-major fast path: this wave's 64 satellites are consecutive catalog rows
+    // time-major staged stores: this wave's 64 satellites are consecutive catalog rows IN LANE ORDER (the host
+    // orders every 256-slot group of the list by eccentricity class, so a wave that straddles a class boundary
+    // holds a permutation of -- or not even -- a run of rows: the vote looks at the real mapping)
     const unsigned s_first = p.list[li0];
-    const bool dense = (LAYOUT == 1) && !DEEP && (li0 + 63 < p.n_list) && (p.list[min(li0 + 63, p.n_list - 1)] - s_first == 63u) &&
-                       (p.mask == nullptr) && !p.f32;
-
-    Sgp4Lane e4;
-    Sgp4Carry c4;
-    Sdp4Lane e8;
-    Sdp4Carry c8;
-    if (DEEP) {
-        az_load_sdp4(p.el, p.n_pad, s, fl, e8, ColdLds{cold});
-        if (p.seeds) {
-            // resonance state at this tile's first time, prepared once by k_deep_seed: a tile never
-            // re-integrates from epoch (a 300-day-old resonant element set would cost 600+ integrator
-            // steps per tile otherwise)
-            const double *sd = p.seeds + (size_t)blockIdx.y * 3 * p.n_list + (in_range ? li : p.n_list - 1);
-            c8.atime = sd[0];
-            c8.xli = sd[p.n_list];
-            c8.xni = sd[2 * (size_t)p.n_list];
-        } else {
-            c8.atime = 0.0;
-            c8.xli = e8(H_xlamo);
-            c8.xni = e8(H_no_unkozai);
-        }
-    } else {
-        az_load_sgp4(p.el, p.n_pad, s, fl, e4, cold4);
-        c4.t_prev = 0.0;
-        c4.sW = c4.sO = c4.sA = 0.0;
-        c4.cW = c4.cO = c4.cA = 1.0;
-    }
+    const bool dense = (LAYOUT == 1) && !DEEP && (p.mask == nullptr) && !p.f32 && !az_any(!(in_range && s == s_first + lane));
 
     double tcache = 0.0;
     const RotK rk = az_rotk();
     double best_d2 = __builtin_inf(); // fused screen only (SCREEN)
     unsigned best_t = 0xffffffffu;
-#pragma unroll 1
-    for (unsigned i = t0; i < t1; ++i) {
-        // Time values: one coalesced 512-B vector load per 64 steps parks 64 of them in a VGPR (one
-        // per lane); each step then broadcasts its value with v_readlane.  A per-step load would be
-        // followed by s_waitcnt vmcnt(0), which also waits for every outstanding global STORE of the
-        // previous steps and serialises the arithmetic against the write stream.
-        const unsigned k64 = __builtin_amdgcn_readfirstlane((i - t0) & 63u);
-        if (k64 == 0) tcache = p.times[min(i + lane, p.n_times - 1)];
-        const double t = az_readlane_f64(tcache, k64) + off;
-        double r[3], v[3];
-        int rc = 0;
-#if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
-        r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
-#else
-        if (DEEP) {
-            rc = az_sdp4_step<VEL>(e8, ColdLds{cold}, p.g, rk, t, c8, r, v);
-        } else {
-            const bool first = ((i - t0) % AZ_RESEED) == 0;
-            az_sgp4_step<VEL>(e4, cold4, p.el, p.n_pad, s, p.g, rk, t, first, c4, r, v);
-        }
-#endif
+
+    // what happens to one step's result: the fused screen, or the store path of the layout
+    auto emit = [&](unsigned i, double (&r)[3], double (&v)[3], int rc) {
         if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, i);
         if (SCREEN) {
             // fused single-target screen (lane = satellite): running minimum over this tile, no stores
@@ -264,7 +229,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
                 best_d2 = d2;
                 best_t = i;
             }
-            continue;
+            return;
         }
         if (DEEP) {
             if (rc != 0) {
@@ -273,9 +238,8 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
                 if (p.err && wr) p.err[(size_t)s * p.n_times + i] = (unsigned char)rc;
             }
         }
-
 #if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only */
-        if (r[0] != 1.2345e300) continue;
+        if (r[0] != 1.2345e300) return;
 #endif
         if (LAYOUT == 1) {
             if (dense) {
@@ -313,7 +277,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
                 if (p.f32) {
                     az_put3(reinterpret_cast<float *>(p.pos) + ob, r);
                     if (VEL) az_put3(reinterpret_cast<float *>(p.vel) + ob, v);
-                    continue;
+                    return;
                 }
                 AZ_ST1(p.pos + ob, r[0]);
                 AZ_ST1(p.pos + ob + 1, r[1]);
@@ -334,7 +298,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
                 if (p.f32) {
                     az_put3(reinterpret_cast<float *>(p.pos) + ob, r);
                     if (VEL) az_put3(reinterpret_cast<float *>(p.vel) + ob, v);
-                    continue;
+                    return;
                 }
                 AZ_ST1(p.pos + ob, r[0]);
                 AZ_ST1(p.pos + ob + 1, r[1]);
@@ -383,6 +347,81 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
                 }
                 az_wave_lds_fence();
             }
+        }
+    };
+    // Time values: one coalesced 512-B vector load per 64 steps parks 64 of them in a VGPR (one
+    // per lane); each step then broadcasts its value with v_readlane.  A per-step load would be
+    // followed by s_waitcnt vmcnt(0), which also waits for every outstanding global STORE of the
+    // previous steps and serialises the arithmetic against the write stream.
+    auto time_at = [&](unsigned i) {
+        const unsigned k64 = __builtin_amdgcn_readfirstlane((i - t0) & 63u);
+        if (k64 == 0) tcache = p.times[min(i + lane, p.n_times - 1)];
+        return az_readlane_f64(tcache, k64) + off;
+    };
+
+    unsigned i = t0;
+#if AZ_PROP_FAST
+    // Optimistic straight-line loop (fast_step.h): uniform grid, all 64 orbits near-circular, every small
+    // angle inside its usual tier; one vote per step, the generic loop takes over on a violation.
+    if (!DEEP && p.inc != nullptr && p.uniform_step != 0.0 && !az_any(AZ_FLAG_ECLASS(fl) != 0)) {
+        FastK k;
+        az_load_fast(p.el, p.n_pad, s, fl, p.inc, 1, k);
+        FastCarry fc;
+        az_seed_fast(p.el, p.n_pad, s, p.times[t0] + off - p.uniform_step, fc);
+#pragma unroll 1
+        for (; i < t1; ++i) {
+            const double t = time_at(i);
+            double r[3], v[3];
+            const bool bad = az_sgp4_fast_step<VEL>(k, p.g, rk, t, fc, r, v);
+            if (az_any(bad && in_range)) break;
+            emit(i, r, v, 0);
+        }
+    }
+#endif
+    if (i < t1) {
+        const unsigned g0 = i; // first step of the generic loop
+        if ((g0 - t0) & 63u) tcache = p.times[min(g0 - ((g0 - t0) & 63u) + lane, p.n_times - 1)];
+        Sgp4Lane e4;
+        Sgp4Carry c4;
+        Sdp4Lane e8;
+        Sdp4Carry c8;
+        if (DEEP) {
+            az_load_sdp4(p.el, p.n_pad, s, fl, e8, ColdLds{cold});
+            if (p.seeds) {
+                // resonance state at this tile's first time, prepared once by k_deep_seed: a tile never
+                // re-integrates from epoch (a 300-day-old resonant element set would cost 600+ integrator
+                // steps per tile otherwise)
+                const double *sd = p.seeds + (size_t)blockIdx.y * 3 * p.n_list + (in_range ? li : p.n_list - 1);
+                c8.atime = sd[0];
+                c8.xli = sd[p.n_list];
+                c8.xni = sd[2 * (size_t)p.n_list];
+            } else {
+                c8.atime = 0.0;
+                c8.xli = e8(H_xlamo);
+                c8.xni = e8(H_no_unkozai);
+            }
+        } else {
+            az_load_sgp4(p.el, p.n_pad, s, fl, e4, cold4);
+            c4.t_prev = 0.0;
+            c4.sW = c4.sO = c4.sA = 0.0;
+            c4.cW = c4.cO = c4.cA = 1.0;
+        }
+#pragma unroll 1
+        for (; i < t1; ++i) {
+            const double t = time_at(i);
+            double r[3], v[3];
+            int rc = 0;
+#if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
+            r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
+#else
+            if (DEEP) {
+                rc = az_sdp4_step<VEL>(e8, ColdLds{cold}, p.g, rk, t, c8, r, v);
+            } else {
+                const bool first = ((i - g0) % AZ_RESEED) == 0;
+                az_sgp4_step<VEL>(e4, cold4, p.el, p.n_pad, s, p.g, rk, t, first, c4, r, v);
+            }
+#endif
+            emit(i, r, v, rc);
         }
     }
     if (SCREEN && in_range) {
@@ -510,6 +549,9 @@ struct ColdBroadcast {
     __device__ __forceinline__ double operator()(int k) const { return p[k]; }
     __device__ __forceinline__ void set(int k, double v) const { p[k] = v; }
 };
+#ifndef AZ_ROWS_FAST
+#define AZ_ROWS_FAST 1 /* k_rows: try the branch-free fast step first (fast_step.h) */
+#endif
 #ifndef AZ_ROWS_TLDS
 #define AZ_ROWS_TLDS 1024 /* k_rows: time values staged in LDS per refill (a power of two >= 64) */
 #endif
@@ -552,24 +594,8 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     // the grid has enough waves to fill the chip several times over
     const unsigned t_lo = blockIdx.y * p.tile;
     const unsigned t_hi = min(t_lo + p.tile, p.n_times);
-    Sgp4Lane e;
     __shared__ __attribute__((aligned(16))) double rows_lds[AZ_ROWS_TLDS + C_NUM_MAX + 2];
-    typedef ColdBroadcast ColdT;
-    const ColdT cold{rows_lds + AZ_ROWS_TLDS};
-    az_load_sgp4(p.el, p.n_pad, s, fl, e, cold);
-    e.mdot = az_uniform(e.mdot); e.argpdot = az_uniform(e.argpdot); e.nodedot = az_uniform(e.nodedot);
-    e.xnodcf = az_uniform(e.xnodcf); e.aycof = az_uniform(e.aycof); e.xlcof = az_uniform(e.xlcof);
-    e.sinio = az_uniform(e.sinio); e.cosio = az_uniform(e.cosio); e.k_mrt = az_uniform(e.k_mrt);
-    e.k_c2u = az_uniform(e.k_c2u); e.k_su = az_uniform(e.k_su); e.k_node = az_uniform(e.k_node);
-    e.k_inc = az_uniform(e.k_inc); e.x1mth2 = az_uniform(e.x1mth2); e.k_rv = az_uniform(e.k_rv);
     const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
-    Sgp4Carry c;
-    c.t_prev = 0.0;
-    c.sW = c.sO = c.sA = 0.0;
-    c.cW = c.cO = c.cA = 1.0;
-    c.dt_c = -1.0e300;
-    c.sdA = c.pW = c.qW = 0.0;
-    c.cdA = 1.0;
     const RotK rk = az_rotk();
 #if defined(AZ_ABLATE) && AZ_ABLATE == 3 /* tuning experiment: all rows alias 64 rows (L2-resident window) */
     const size_t srow = s & 63u;
@@ -584,21 +610,89 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     // vector-memory LOAD at all.  vmcnt counts loads and stores in issue order, so a load's
     // s_waitcnt also waits for every output store issued before it -- one load per iteration
     // serialises the arithmetic against the write stream; ds_read waits on lgkmcnt only.
+    unsigned base = t_lo;
+#if AZ_ROWS_FAST
+    // Optimistic straight-line loop (fast_step.h): uniform grid, near-circular orbit, every small angle
+    // inside its usual tier.  No votes, no branches inside a step; one vote per iteration on the
+    // accumulated `bad` predicate.  On a violation nothing of that iteration has been stored and the
+    // generic loop below takes over from the same grid point.
+    if (p.inc != nullptr && p.uniform_step != 0.0 && AZ_FLAG_ECLASS(fl) == 0) {
+        FastK k;
+        az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k);
+        FastCarry fc;
+        {
+            // seed one increment BEFORE this lane's first grid point
+            const double t0 = p.times[min(t_lo + lane, p.n_times - 1)] + off - 64.0 * p.uniform_step;
+            az_seed_fast(p.el, p.n_pad, s, t0, fc);
+        }
 #pragma unroll 1
-    for (unsigned base = t_lo; base < t_hi; base += 64) {
+        for (; base < t_hi; base += 64) {
+            const unsigned i = base + lane;
+            const bool live = i < t_hi;
+            const unsigned kk = (base - t_lo) & (AZ_ROWS_TLDS - 1u);
+            if (kk == 0) {
+                az_wave_lds_fence();
+#pragma unroll
+                for (unsigned j = 0; j < AZ_ROWS_TLDS; j += 64) rows_lds[j + lane] = p.times[min(i + j, t_hi - 1)];
+                az_wave_lds_fence();
+            }
+            const double t = rows_lds[kk + lane] + off;
+            double r[3], v[3];
+            const bool bad = az_sgp4_fast_step<VEL>(k, p.g, rk, t, fc, r, v);
+            if (az_any(bad && live)) break;
+            if (SINK == AZ_SINK_SCREEN) {
+                const double *q = p.screen_target + (size_t)(live ? i : t_hi - 1) * 3;
+                const double dx = q[0] - r[0], dy = q[1] - r[1], dz = q[2] - r[2];
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                if (live && d2 < best_d2) { // NaN (failed target step) never wins
+                    best_d2 = d2;
+                    best_t = i;
+                }
+                continue;
+            }
+            if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
+            if (live) {
+                az_put3_stream(prow + (size_t)i * 3, r);
+                if (VEL) az_put3_stream(vrow + (size_t)i * 3, v);
+            }
+        }
+    }
+#endif
+    const unsigned g_lo = base; // first grid point of the generic loop (re-seeds its carried pairs there)
+    if (base < t_hi) {
+    // generic loop: any grid, any eccentricity (tier votes inside the step)
+    Sgp4Lane e;
+    typedef ColdBroadcast ColdT;
+    const ColdT cold{rows_lds + AZ_ROWS_TLDS};
+    az_load_sgp4(p.el, p.n_pad, s, fl, e, cold);
+    e.mdot = az_uniform(e.mdot); e.argpdot = az_uniform(e.argpdot); e.nodedot = az_uniform(e.nodedot);
+    e.xnodcf = az_uniform(e.xnodcf); e.aycof = az_uniform(e.aycof); e.xlcof = az_uniform(e.xlcof);
+    e.sinio = az_uniform(e.sinio); e.cosio = az_uniform(e.cosio); e.k_mrt = az_uniform(e.k_mrt);
+    e.k_c2u = az_uniform(e.k_c2u); e.k_su = az_uniform(e.k_su); e.k_node = az_uniform(e.k_node);
+    e.k_inc = az_uniform(e.k_inc); e.x1mth2 = az_uniform(e.x1mth2); e.k_rv = az_uniform(e.k_rv);
+    Sgp4Carry c;
+    c.t_prev = 0.0;
+    c.sW = c.sO = c.sA = 0.0;
+    c.cW = c.cO = c.cA = 1.0;
+    c.dt_c = -1.0e300;
+    c.sdA = c.pW = c.qW = 0.0;
+    c.cdA = 1.0;
+#pragma unroll 1
+    for (; base < t_hi; base += 64) {
         const unsigned i = base + lane;
         const bool live = i < t_hi;
         const unsigned kk = (base - t_lo) & (AZ_ROWS_TLDS - 1u);
-        if (kk == 0) {
+        if (kk == 0 || base == g_lo) {
             az_wave_lds_fence();
+            const unsigned b0 = base - kk; // start of the staged window
 #pragma unroll
-            for (unsigned j = 0; j < AZ_ROWS_TLDS; j += 64) rows_lds[j + lane] = p.times[min(i + j, t_hi - 1)];
+            for (unsigned j = 0; j < AZ_ROWS_TLDS; j += 64) rows_lds[j + lane] = p.times[min(b0 + lane + j, t_hi - 1)];
             az_wave_lds_fence();
         }
         const double t = rows_lds[kk + lane] + off;
         double r[3], v[3];
         // full re-seed of the carried pairs at the start and every 64 iterations (4,096 grid points)
-        const bool first = ((base - t_lo) & (64u * 64u - 1u)) == 0;
+        const bool first = ((base - g_lo) & (64u * 64u - 1u)) == 0;
 #if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
         r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
         (void)first;
@@ -630,6 +724,7 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
             if (VEL) az_put3_stream(vrow + (size_t)i * 3, v);
         }
     }
+    } // generic loop
     if (SINK == AZ_SINK_SCREEN) {
         az_wave_argmin(best_d2, best_t);
         if (lane == 0) {
@@ -923,6 +1018,27 @@ __global__ void k_gmst(const double *times, unsigned n, double reference_jd, dou
     gm *= AZ_PI / 180.0;
     sin_g[i] = sin(gm);
     cos_g[i] = cos(gm);
+}
+
+// uniform time grid: (sin,cos) of the per-step increments of the three secular angles, per satellite,
+// for the two lane mappings (fast_step.h).  One lane per satellite, once per staged grid.
+__global__ void __launch_bounds__(256) k_prep_inc(const double *el, size_t n, size_t n_pad, double step, double *inc)
+{
+    const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const double rate[3] = {el[(size_t)F_mdot * n_pad + s], el[(size_t)F_argpdot * n_pad + s],
+                            el[(size_t)F_nodedot * n_pad + s]};
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        const double dt = which == 0 ? 64.0 * step : step;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            double sn, cs;
+            az_sincos(rate[a] * dt, sn, cs);
+            inc[(size_t)(6 * which + 2 * a) * n_pad + s] = sn;
+            inc[(size_t)(6 * which + 2 * a + 1) * n_pad + s] = cs;
+        }
+    }
 }
 
 // element initialisation: raw[k*n_pad + s] -> el rows + flags

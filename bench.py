@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument("--stride-align", type=int, default=0,
                     help="time-major only: round the row length (out_stride_sats) up to a multiple of this many "
                          "satellites (16 = 128-byte aligned rows)")
+    ap.add_argument("--no-fast-path", action="store_true",
+                    help="disable the branch-free uniform-grid step (A/B against the generic tier-voting loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0)
     return ap.parse_args()
@@ -149,6 +151,8 @@ def main():
     dev = _native.DeviceConstellation.from_tle_lines(pairs, _native.WGS72, local_rank)
     if a.tile:
         dev.set_time_tile(a.tile, a.tile)
+    if a.no_fast_path:
+        dev.set_fast_path(False)
     n_local, n_times = dev.n, a.times
     times = np.arange(n_times, dtype=np.float64)
     offsets = (synth.START_JD - dev.epochs) * 1440.0

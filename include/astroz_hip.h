@@ -223,6 +223,9 @@ int32_t azh_propagate_one_host(azh_constellation *c, size_t sat_index, const dou
 
 /* tuning knobs (kernel time-tile length; 0 = automatic).  Not part of the reference surface. */
 int32_t azh_set_time_tile(azh_constellation *c, uint32_t sgp4_tile, uint32_t sdp4_tile);
+/* enable (default) / disable the branch-free uniform-grid step (astroz_amd/csrc/fast_step.h).  Results
+ * of the two paths agree to rounding; the switch exists so that tests can compare them. */
+int32_t azh_set_fast_path(azh_constellation *c, int32_t enabled);
 /* enable (default) / disable the hipEvent pair recorded around every propagate call; disabling it
  * removes two event records per call from tight replay loops (azh_last_kernel_ms then returns -1) */
 int32_t azh_set_timing(azh_constellation *c, int32_t enabled);

@@ -11,6 +11,7 @@
 #include <cstring>
 #include "../../astroz_amd/csrc/init_device.h"
 #include "../../astroz_amd/csrc/propagate_device.h"
+#include "../../astroz_amd/csrc/fast_step.h"
 
 extern "C" {
 
@@ -52,6 +53,27 @@ void emul_propagate(const double* fields, unsigned flags, const double* grav6, c
             memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
             rc_out[i] = 0;
         }
+    }
+}
+
+// the branch-free uniform-grid step (fast_step.h) as one lane of the lane = time kernel runs it: seeded one
+// increment before ts0, then n steps of `dt` minutes.  bad_out[i] = the step's validation predicate.
+void emul_propagate_fast(const double* fields, unsigned flags, const double* grav6, double ts0, double dt, int n,
+                         double* out6, int* bad_out)
+{
+    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
+    double inc[12];
+    const double rate[3] = {fields[F_mdot], fields[F_argpdot], fields[F_nodedot]};
+    for (int which = 0; which < 2; ++which)
+        for (int a = 0; a < 3; ++a) az_sincos(rate[a] * dt, inc[6 * which + 2 * a], inc[6 * which + 2 * a + 1]);
+    FastK k;
+    az_load_fast(fields, 1, 0, flags, inc, 0, k);
+    FastCarry st;
+    az_seed_fast(fields, 1, 0, ts0 - dt, st);
+    for (int i = 0; i < n; ++i) {
+        double r[3], v[3];
+        bad_out[i] = az_sgp4_fast_step<true>(k, g, az_rotk(), ts0 + i * dt, st, r, v) ? 1 : 0;
+        memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
     }
 }
 

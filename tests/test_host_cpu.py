@@ -147,7 +147,7 @@ def emul():
     """Host build of the device math headers (tests/host_emul/emul.cpp)."""
     src = os.path.join(ROOT, "tests", "host_emul", "emul.cpp")
     lib = os.path.join(ROOT, "tests", "host_emul", "libemul.so")
-    hdrs = [os.path.join(ROOT, "astroz_amd", "csrc", h) for h in ("devmath.h", "fields.h", "init_device.h", "propagate_device.h")]
+    hdrs = [os.path.join(ROOT, "astroz_amd", "csrc", h) for h in ("devmath.h", "fields.h", "init_device.h", "propagate_device.h", "fast_step.h")]
     if not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-Wno-unknown-pragmas", "-o", lib, src])
@@ -155,6 +155,7 @@ def emul():
     E.emul_init.restype = C.c_uint
     E.emul_init.argtypes = [C.c_void_p] * 3
     E.emul_propagate.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    E.emul_propagate_fast.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
     E.emul_sincos.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
     E.emul_rcp.restype = C.c_double
     E.emul_rcp.argtypes = [C.c_double]
@@ -214,6 +215,43 @@ def test_emulated_kernels_match_oracle(emul, orc, step):
             assert orc_rc == rc[k]
             worst_r = max(worst_r, np.abs(out[k, :3] - r).max())
             worst_v = max(worst_v, np.abs(out[k, 3:] - v).max())
+    assert worst_r < 1e-6 and worst_v < 1e-9, (worst_r, worst_v)
+
+
+@pytest.mark.parametrize("dt", [64.0, 1.0, 640.0])
+def test_emulated_fast_step_matches_oracle(emul, orc, dt):
+    """fast_step.h (the branch-free uniform-grid step of k_rows / k_propagate), host-compiled: wherever its
+    validation predicate accepts a step the result must match the oracle; the predicate must accept the bulk
+    of a near-circular catalog and reject eccentric members."""
+    from astroz_amd import synth
+    pairs = synth.synth_catalog(300, 0, seed=9)
+    tles = [orc.parse_lines(a, b) for a, b in pairs]
+    cat = orc.Catalog(tles, 1)
+    g = _grav6(1)
+    nf = emul.emul_num_fields()
+    n = 40
+    off = (synth.START_JD - cat.epoch_jd) * 1440.0
+    worst_r = worst_v = 0.0
+    accepted = total = 0
+    for i, t in enumerate(tles):
+        raw = np.array([t.epoch_jd, t.mm_revday, t.ecc, t.incl_deg, t.raan_deg, t.argp_deg, t.ma_deg, t.bstar])
+        fields = np.zeros(nf)
+        flags = emul.emul_init(raw.ctypes.data, g.ctypes.data, fields.ctypes.data)
+        out = np.zeros((n, 6))
+        bad = np.zeros(n, dtype=np.int32)
+        ts0 = off[i] + 3.0
+        emul.emul_propagate_fast(fields.ctypes.data, flags, g.ctypes.data, ts0, dt, n, out.ctypes.data, bad.ctypes.data)
+        total += n
+        if t.ecc > 0.01:
+            assert bad.all(), "eccentric orbit accepted by the fast step"
+        for k in range(n):
+            if bad[k]:
+                continue
+            accepted += 1
+            _, r, v = cat.propagate_one(i, ts0 + k * dt)
+            worst_r = max(worst_r, np.abs(out[k, :3] - r).max())
+            worst_v = max(worst_v, np.abs(out[k, 3:] - v).max())
+    assert accepted > 0.8 * total, (accepted, total)
     assert worst_r < 1e-6 and worst_v < 1e-9, (worst_r, worst_v)
 
 
