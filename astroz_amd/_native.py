@@ -25,13 +25,14 @@ EXPORTS = [
     "tle_get_satellite_number", "tle_get_epoch", "tle_get_inclination", "tle_get_eccentricity",
     "tle_get_mean_motion", "sgp4_init", "sgp4_free", "sgp4_propagate", "sgp4_propagate_batch",
     "azh_device_count", "azh_last_error", "azh_parse_tle_lines", "azh_constellation_from_tle_text",
-    "azh_constellation_from_tle_lines", "azh_constellation_from_elements", "azh_constellation_free",
+    "azh_constellation_from_tle_lines", "azh_constellation_from_elements", "azh_constellation_subset", "azh_constellation_free",
     "azh_num_satellites", "azh_num_sgp4", "azh_num_sdp4", "azh_get_epochs", "azh_get_status",
-    "azh_get_field", "azh_propagate_host", "azh_propagate_device", "azh_propagate_device_cached",
+    "azh_get_field", "azh_propagate_host", "azh_propagate_device", "azh_propagate_device_cached", "azh_propagate_device_window",
     "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile", "azh_set_timing", "azh_set_fast_path",
     "azh_last_kernel_ms", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
     "azh_screen_target_host", "azh_screen_target_device", "azh_coarse_screen_device", "azh_coarse_screen_host",
-    "azh_screen_all_host",
+    "azh_screen_all_host", "azh_constellation_from_omm_json", "azh_propagate_one_device", "azh_selftest_math",
+    "coords_julian_to_gmst", "coords_eci_to_ecef", "coords_ecef_to_geodetic",
 ]
 
 
@@ -106,10 +107,24 @@ def lib():
     L.azh_parse_tle_lines.restype = i32
     L.azh_constellation_from_tle_text.argtypes = [C.c_char_p, sz, i32, i32, C.POINTER(vp)]
     L.azh_constellation_from_tle_text.restype = i32
+    L.azh_constellation_from_omm_json.argtypes = [C.c_char_p, sz, i32, i32, C.POINTER(vp)]
+    L.azh_constellation_from_omm_json.restype = i32
+    L.azh_propagate_one_device.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp]
+    L.azh_propagate_one_device.restype = i32
+    L.azh_selftest_math.argtypes = [vp, sz, vp, i32]
+    L.azh_selftest_math.restype = i32
+    L.coords_julian_to_gmst.argtypes = [dbl]
+    L.coords_julian_to_gmst.restype = dbl
+    L.coords_eci_to_ecef.argtypes = [vp, dbl, vp]
+    L.coords_eci_to_ecef.restype = None
+    L.coords_ecef_to_geodetic.argtypes = [vp, vp]
+    L.coords_ecef_to_geodetic.restype = None
     L.azh_constellation_from_tle_lines.argtypes = [vp, vp, sz, i32, i32, C.POINTER(vp)]
     L.azh_constellation_from_tle_lines.restype = i32
     L.azh_constellation_from_elements.argtypes = [sz] + [vp] * 8 + [i32, i32, C.POINTER(vp)]
     L.azh_constellation_from_elements.restype = i32
+    L.azh_constellation_subset.argtypes = [vp, vp, sz, i32, C.POINTER(vp)]
+    L.azh_constellation_subset.restype = i32
     L.azh_constellation_free.argtypes = [vp]
     for f in ("azh_num_satellites", "azh_num_sgp4", "azh_num_sdp4"):
         getattr(L, f).argtypes = [vp]
@@ -126,6 +141,8 @@ def lib():
     L.azh_propagate_device.restype = i32
     L.azh_propagate_device_cached.argtypes = [vp, vp, vp, i32, sz, vp, vp]
     L.azh_propagate_device_cached.restype = i32
+    L.azh_propagate_device_window.argtypes = [vp, sz, sz, vp, vp, i32, sz, vp, vp]
+    L.azh_propagate_device_window.restype = i32
     L.azh_propagate_jd_host.argtypes = [vp, vp, vp, sz, vp, vp, i32, i32, vp]
     L.azh_propagate_jd_host.restype = i32
     L.azh_synchronize.argtypes = [vp]
@@ -193,6 +210,14 @@ class DeviceConstellation:
         return cls(h)
 
     @classmethod
+    def from_omm_json(cls, text, grav=WGS72, device=0):
+        b = text.encode() if isinstance(text, str) else bytes(text)
+        h = C.c_void_p()
+        check(lib().azh_constellation_from_omm_json(b, len(b), grav, device, C.byref(h)),
+              "azh_constellation_from_omm_json")
+        return cls(h)
+
+    @classmethod
     def from_tle_lines(cls, pairs, grav=WGS72, device=0):
         n = len(pairs)
         a1 = (C.c_char_p * n)(*[p[0].encode() for p in pairs])
@@ -212,6 +237,14 @@ class DeviceConstellation:
         check(lib().azh_constellation_from_elements(n, *[c.ctypes.data for c in cols], grav, device,
                                                     C.byref(h)), "azh_constellation_from_elements")
         return cls(h)
+
+    def subset(self, indices, device=-1):
+        """New constellation with members `indices` (in that order); device -1 = same device."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint32)
+        h = C.c_void_p()
+        check(lib().azh_constellation_subset(self._h, idx.ctypes.data, len(idx), device, C.byref(h)),
+              "azh_constellation_subset")
+        return type(self)(h)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -293,6 +326,12 @@ class DeviceConstellation:
         fn = lib().azh_propagate_device_cached_f32 if f32 else lib().azh_propagate_device_cached
         check(fn(self._h, d_pos, d_vel, layout, stride, d_err, stream), "azh_propagate_device_cached")
 
+    def propagate_device_window(self, row_lo, row_hi, d_pos, d_vel=None, *, layout=SAT_MAJOR, stride=0, d_err=None,
+                                stream=None):
+        """Cached launch restricted to satellites [row_lo, row_hi) (chunked multi-GPU pipelines)."""
+        check(lib().azh_propagate_device_window(self._h, int(row_lo), int(row_hi), d_pos, d_vel, layout, stride, d_err,
+                                                stream), "azh_propagate_device_window")
+
     # -- conjunction screening ------------------------------------------------------------
     def screen_target(self, times_min, target, threshold=10.0, offsets_min=None, reference_jd=0.0):
         """Fused propagate+screen against satellite `target`: (min_dist km (n,), min_t_index (n,) u32)."""
@@ -331,6 +370,11 @@ class DeviceConstellation:
         check(lib().azh_propagate_one_host(self._h, sat_index, t.ctypes.data, n, pos.ctypes.data, vel.ctypes.data,
                                            err.ctypes.data), "azh_propagate_one_host")
         return err, pos, vel
+
+    def propagate_one_device(self, sat_index, d_tsince, n, d_pos, d_vel=None, d_err=None, stream=None):
+        """One satellite x n times, all buffers in HBM (raw device pointers); asynchronous."""
+        check(lib().azh_propagate_one_device(self._h, sat_index, d_tsince, n, d_pos, d_vel, d_err, stream),
+              "azh_propagate_one_device")
 
     def set_fast_path(self, enabled):
         check(lib().azh_set_fast_path(self._h, 1 if enabled else 0), "azh_set_fast_path")
@@ -380,6 +424,34 @@ def coarse_screen(positions, threshold, valid_mask=None, *, layout=SAT_MAJOR, ma
                                              pairs.ctypes.data, tt.ctypes.data, max_results, C.byref(k), stream),
               "azh_coarse_screen_device")
     return pairs[:k.value].copy(), tt[:k.value].copy()
+
+
+def selftest_math(x, device=0):
+    """Device-side known answers of the kernels' element math: dict of arrays (see azh_selftest_math)."""
+    x = _f64(np.atleast_1d(x))
+    n = len(x)
+    out = np.empty(6 * n)
+    check(lib().azh_selftest_math(x.ctypes.data, n, out.ctypes.data, device), "azh_selftest_math")
+    return {"sin": out[:n], "cos": out[n:2 * n], "x_rcp": out[2 * n:3 * n], "x_rsqrt2": out[3 * n:4 * n],
+            "rot_sin": out[4 * n:5 * n], "rot_cos": out[5 * n:]}
+
+
+def julian_to_gmst(jd):
+    return float(lib().coords_julian_to_gmst(float(jd)))
+
+
+def eci_to_ecef(eci, gmst):
+    a = _f64(eci)
+    out = np.empty(3)
+    lib().coords_eci_to_ecef(a.ctypes.data, float(gmst), out.ctypes.data)
+    return out
+
+
+def ecef_to_geodetic(ecef):
+    a = _f64(ecef)
+    out = np.empty(3)
+    lib().coords_ecef_to_geodetic(a.ctypes.data, out.ctypes.data)
+    return out
 
 
 def device_count():

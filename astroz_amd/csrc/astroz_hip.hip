@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -93,11 +94,13 @@ struct azh_constellation {
     unsigned *d_flags = nullptr;
     std::vector<unsigned> h_flags;
     std::vector<double> h_epoch;
+    std::vector<double> h_raw[AZ_NUM_RAW]; // the TLE-unit inputs (for azh_constellation_subset)
     // launch lists (table indices)
     DevBuf<unsigned> d_list; // [near-earth | deep (by irez) | bad]
     unsigned n_sgp4 = 0, n_sdp4 = 0, n_bad = 0;
     // per-call scratch
     DevBuf<double> d_times, d_offsets, d_sin, d_cos, d_seeds;
+    DevBuf<unsigned> d_redo;    // k_rows_fast -> k_rows redo list: [0] count, then (slot, first, end) triples
     DevBuf<double> d_inc;       // uniform grids: per-satellite rotation increments (k_prep_inc), [12][n_pad]
     double uniform_step = 0.0;  // step of the staged grid if it is uniform, else 0
     DevBuf<double> d_tgt, d_part_d2, d_out_d; // fused screen: target track, partial minima, results
@@ -111,6 +114,8 @@ struct azh_constellation {
     unsigned seeds_tile = 0;
     bool seeds_rows = false; // seed table laid out for the lane = time kernel (64-point chunks)
     DevBuf<unsigned char> d_mask;
+    DevBuf<double> d_host_pos, d_host_vel; // azh_propagate_host: grow-only device-side result buffers
+    DevBuf<unsigned char> d_host_err;
     bool have_offsets = false, have_mask = false;
     unsigned cached_n_times = 0;
     int cached_mode = 0;
@@ -139,6 +144,7 @@ void destroy(azh_constellation *c)
     c->d_cos.release();
     c->d_seeds.release();
     c->d_inc.release();
+    c->d_redo.release();
     c->d_tgt.release();
     c->d_part_d2.release();
     c->d_out_d.release();
@@ -149,6 +155,9 @@ void destroy(azh_constellation *c)
     c->d_one_e.release();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     c->d_mask.release();
+    c->d_host_pos.release();
+    c->d_host_vel.release();
+    c->d_host_err.release();
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
@@ -213,6 +222,7 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
             break;
         }
         c->h_epoch = cols[R_epoch_jd];
+        for (int k = 0; k < AZ_NUM_RAW; ++k) c->h_raw[k] = cols[k];
         // launch lists.
         //  [near-earth]  catalog order, except that inside every group of AZ_BLOCK consecutive
         //      members (= one workgroup = 4 waves) the members are ordered by eccentricity class.
@@ -354,6 +364,18 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st)
     if (deep) {
         if (a.f32) hipLaunchKernelGGL((k_rows_deep<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_rows_deep<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
+    } else if (a.redo_items != nullptr) {
+        // uniform grid: the branch-free kernel first; what it rejects (eccentric members, angles outside their
+        // tier: a few per cent of the segments) is listed and handed to the generic kernel
+        (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned), st);
+        dim3 rgrid(std::min(2048u, grid.x * grid.y), 4);
+        if (a.f32) {
+            hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
+            hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32, true>), rgrid, dim3(64), 0, st, a);
+        } else {
+            hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
+            hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
+        }
     } else {
         if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
@@ -368,6 +390,7 @@ void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStr
         b.tile = rows_tile(a.n_list, a.n_times, a.tile_forced);
         b.tm_rows = (deep && layout == AZ_LAYOUT_TIME_MAJOR && !a.screen_target) ? 1 : 0;
         dim3 grid((a.n_list + 7) / 8 * 8, (a.n_times + b.tile - 1) / b.tile);
+        if (deep || a.screen_target || a.inc == nullptr) b.redo_items = nullptr; // k_rows_fast: near-earth rows on a uniform grid
         if (a.screen_target) {
             if (deep) hipLaunchKernelGGL((k_rows_deep<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);
             else hipLaunchKernelGGL((k_rows<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);
@@ -470,10 +493,12 @@ int32_t prepare_deep(azh_constellation *c, PropArgs &d, hipStream_t st, bool row
 
 // the launches proper; inputs already staged on the device
 int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layout, size_t stride, uint8_t *d_err,
-                   hipStream_t st, int f32 = 0)
+                   hipStream_t st, int f32 = 0, size_t row_lo = 0, size_t row_hi = ~(size_t)0)
 {
     const unsigned n_times = c->cached_n_times;
     if (n_times == 0) return AZ_OK;
+    row_hi = std::min(row_hi, c->n);
+    if (row_lo >= row_hi) return AZ_OK;
     if (stride == 0) stride = c->n;
     if (layout == AZ_LAYOUT_TIME_MAJOR && stride < c->n) return AZ_ERR_VALUE;
 
@@ -496,9 +521,11 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     a.g = c->g;
     a.uniform_step = c->fast_path ? c->uniform_step : 0.0;
     a.inc = (a.uniform_step != 0.0) ? c->d_inc.p : nullptr;
+    a.row_lo = (unsigned)row_lo;
+    a.row_hi = (unsigned)row_hi;
 
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
-    if (d_err) HIP_TRY(hipMemsetAsync(d_err, 0, c->n * (size_t)n_times, st));
+    if (d_err) HIP_TRY(hipMemsetAsync(d_err + row_lo * (size_t)n_times, 0, (row_hi - row_lo) * (size_t)n_times, st));
     const bool fork = c->n_sdp4 > 0;
     if (fork) {
         // deep-space rows on their own stream, concurrent with the near-earth launch
@@ -515,13 +542,20 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         a.n_list = c->n_sgp4;
         a.tile = auto_tile(c->n_sgp4, n_times, c->tile_sgp4, 8);
         a.tile_forced = c->tile_sgp4;
+        if (a.inc != nullptr && use_rows(a, layout, false)) {
+            const unsigned tile = rows_tile(a.n_list, n_times, a.tile_forced);
+            const size_t segs = (n_times + tile - 1) / tile;
+            if (c->d_redo.ensure(4 + 3 * segs * a.n_list) != AZ_OK) return AZ_ERR_HIP;
+            a.redo_count = c->d_redo.p;
+            a.redo_items = c->d_redo.p + 4;
+        }
         launch_propagate(a, layout, d_vel != nullptr, false, st);
         HIP_TRY(hipGetLastError());
     }
     if (c->n_bad > 0) {
         hipLaunchKernelGGL(k_fill_bad, dim3((n_times + 255) / 256, c->n_bad), dim3(256), 0, st,
                            c->d_list.p + c->n_sgp4 + c->n_sdp4, c->n_bad, c->d_flags, n_times, d_pos, d_vel, d_err,
-                           c->have_mask ? c->d_mask.p : nullptr, layout, stride, f32);
+                           c->have_mask ? c->d_mask.p : nullptr, layout, stride, f32, a.row_lo, a.row_hi);
         HIP_TRY(hipGetLastError());
     }
     if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
@@ -629,6 +663,18 @@ int32_t azh_constellation_from_tle_text(const char *text, size_t len, int32_t gr
     return build_from_records(recs, grav, device, out);
 }
 
+int32_t azh_constellation_from_omm_json(const char *text, size_t len, int32_t grav, int32_t device,
+                                        azh_constellation **out)
+{
+    if (!text || !out) return AZ_ERR_NULL_POINTER;
+    std::vector<azh::TleRecord> recs;
+    const int rc = azh::parse_omm_json(std::string_view(text, len), recs);
+    if (rc == -1) return AZ_ERR_BAD_TLE_LENGTH; // Tle.zig L199: epoch string too short
+    if (rc != 0) return AZ_ERR_VALUE;
+    if (recs.empty()) return AZ_ERR_BAD_TLE_LENGTH;
+    return build_from_records(recs, grav, device, out);
+}
+
 int32_t azh_constellation_from_tle_lines(const char *const *line1, const char *const *line2, size_t n,
                                          int32_t grav, int32_t device, azh_constellation **out)
 {
@@ -653,6 +699,20 @@ int32_t azh_constellation_from_elements(size_t n, const double *epoch_jd, const 
     const double *src[AZ_NUM_RAW] = {epoch_jd, mm, ecc, incl, raan, argp, ma, bstar};
     for (int k = 0; k < AZ_NUM_RAW; ++k) cols[k].assign(src[k], src[k] + n);
     return build(cols, n, grav, device, out);
+}
+
+int32_t azh_constellation_subset(const azh_constellation *c, const uint32_t *indices, size_t n, int32_t device,
+                                 azh_constellation **out)
+{
+    if (!c || !indices || !out) return AZ_ERR_NULL_POINTER;
+    std::vector<double> cols[AZ_NUM_RAW];
+    for (auto &v : cols) v.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (indices[i] >= c->n) return AZ_ERR_VALUE;
+        for (int k = 0; k < AZ_NUM_RAW; ++k) cols[k][i] = c->h_raw[k][indices[i]];
+    }
+    const int grav = (c->g.radius_km == 6378.135) ? AZ_WGS72 : AZ_WGS84;
+    return build(cols, n, grav, device < 0 ? c->device : device, out);
 }
 
 void azh_constellation_free(azh_constellation *c) { destroy(c); }
@@ -722,6 +782,7 @@ int32_t azh_propagate_device(azh_constellation *c, const double *times, size_t n
 {
     if (!c || !d_pos || (n_times && !times)) return AZ_ERR_NULL_POINTER;
     if (mode < 0 || mode > 2 || layout < 0 || layout > 1) return AZ_ERR_VALUE;
+    if (n_times == 0) return AZ_OK; // an empty grid is valid and produces nothing
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->s_main;
     int32_t rc = stage_inputs(c, times, n_times, offsets, mask, mode, reference_jd, st);
@@ -739,12 +800,23 @@ int32_t azh_propagate_device_cached(azh_constellation *c, double *d_pos, double 
     return launch_all(c, d_pos, d_vel, layout, stride, d_err, stream ? (hipStream_t)stream : c->s_main);
 }
 
+int32_t azh_propagate_device_window(azh_constellation *c, size_t row_lo, size_t row_hi, double *d_pos, double *d_vel,
+                                    int32_t layout, size_t stride, uint8_t *d_err, void *stream)
+{
+    if (!c || !d_pos) return AZ_ERR_NULL_POINTER;
+    if (layout < 0 || layout > 1) return AZ_ERR_VALUE;
+    if (c->cached_n_times == 0) return AZ_ERR_NOT_INITIALIZED;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    return launch_all(c, d_pos, d_vel, layout, stride, d_err, stream ? (hipStream_t)stream : c->s_main, 0, row_lo, row_hi);
+}
+
 int32_t azh_propagate_device_f32(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
                                  float *d_pos, float *d_vel, int32_t mode, double reference_jd, const uint8_t *mask,
                                  int32_t layout, size_t stride, uint8_t *d_err, void *stream)
 {
     if (!c || !d_pos || (n_times && !times)) return AZ_ERR_NULL_POINTER;
     if (mode < 0 || mode > 2 || layout < 0 || layout > 1) return AZ_ERR_VALUE;
+    if (n_times == 0) return AZ_OK;
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->s_main;
     int32_t rc = stage_inputs(c, times, n_times, offsets, mask, mode, reference_jd, st);
@@ -774,8 +846,8 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
     if (target >= c->n) return AZ_ERR_VALUE;
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->s_main;
-    int32_t rc = stage_inputs(c, times, n_times, offsets, nullptr, AZ_OUT_TEME, 0.0, st);
-    if (rc != AZ_OK) return rc;
+    int32_t rc = AZ_OK;
+    if (n_times > 0 && (rc = stage_inputs(c, times, n_times, offsets, nullptr, AZ_OUT_TEME, 0.0, st)) != AZ_OK) return rc;
     const unsigned nt = (unsigned)n_times;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
     hipLaunchKernelGGL(k_screen_fill, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, st, (unsigned)c->n, threshold_km,
@@ -799,6 +871,8 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
         a.g = c->g;
         a.uniform_step = c->fast_path ? c->uniform_step : 0.0;
         a.inc = (a.uniform_step != 0.0) ? c->d_inc.p : nullptr;
+        a.row_lo = 0;
+        a.row_hi = 0xffffffffu;
         a.screen_target = c->d_tgt.p;
         PropArgs near = a, deep = a;
         unsigned parts_near = 0, parts_deep = 0;
@@ -873,6 +947,9 @@ int32_t coarse_screen(const double *d_pos, size_t n_sats, size_t n_times, int32_
     if (n_sats > 0x7fffffffu || n_times > 0xffffffffu) return AZ_ERR_VALUE;
     if (stride == 0) stride = n_sats;
     hipStream_t st = (hipStream_t)stream;
+    // stream == NULL: the positions may still be being written by launches on a constellation's own
+    // (non-blocking) streams, which the null stream does not order against -- wait for the device
+    if (st == nullptr) HIP_TRY(hipDeviceSynchronize());
     // one bucket table per time step of a chunk; >= 2 buckets per satellite, at least the reference's 2^16
     unsigned bits = 16;
     while (bits < 24 && ((size_t)1 << bits) < 2 * n_sats) ++bits;
@@ -1029,13 +1106,16 @@ int32_t azh_propagate_host(azh_constellation *c, const double *times, size_t n_t
     if (stride == 0) stride = c->n;
     const size_t rows = (layout == AZ_LAYOUT_TIME_MAJOR) ? stride : c->n;
     const size_t bytes = rows * n_times * 3 * sizeof(double);
-    double *d_pos = nullptr, *d_vel = nullptr;
-    uint8_t *d_err = nullptr;
+    // device-side result buffers live in the handle and only ever grow: repeated calls (the Python propagate(),
+    // SatrecArray.sgp4) do not pay a hipMalloc/hipFree pair of hundreds of megabytes each time
+    const size_t words = bytes / sizeof(double);
+    if (c->d_host_pos.ensure(words) != AZ_OK || (vel && c->d_host_vel.ensure(words) != AZ_OK) ||
+        (err && c->d_host_err.ensure(c->n * n_times) != AZ_OK))
+        return AZ_ERR_HIP;
+    double *d_pos = c->d_host_pos.p, *d_vel = vel ? c->d_host_vel.p : nullptr;
+    uint8_t *d_err = err ? c->d_host_err.p : nullptr;
     int32_t rc = AZ_OK;
     do {
-        if (!hip_ok(hipMalloc((void **)&d_pos, bytes), "hipMalloc(pos)")) { rc = AZ_ERR_HIP; break; }
-        if (vel && !hip_ok(hipMalloc((void **)&d_vel, bytes), "hipMalloc(vel)")) { rc = AZ_ERR_HIP; break; }
-        if (err && !hip_ok(hipMalloc((void **)&d_err, c->n * n_times), "hipMalloc(err)")) { rc = AZ_ERR_HIP; break; }
         // rows the kernels do not touch (masked satellites, stride padding) must come back unchanged
         const bool partial = mask != nullptr || (layout == AZ_LAYOUT_TIME_MAJOR && stride > c->n);
         if (partial) {
@@ -1050,9 +1130,6 @@ int32_t azh_propagate_host(azh_constellation *c, const double *times, size_t n_t
         if (!hip_ok(hipStreamSynchronize(c->s_main), "sync")) { rc = AZ_ERR_HIP; break; }
     } while (0);
     if (rc != AZ_OK) (void)hipStreamSynchronize(c->s_main);
-    if (d_pos) (void)hipFree(d_pos);
-    if (d_vel) (void)hipFree(d_vel);
-    if (d_err) (void)hipFree(d_err);
     return rc;
 }
 
@@ -1062,7 +1139,11 @@ int32_t azh_propagate_jd_host(azh_constellation *c, const double *jd, const doub
     if (!c || !jd || !fr || !pos) return AZ_ERR_NULL_POINTER;
     // Constellation.propagate (src/Constellation.zig L266-269): tsinceBase = (jd+fr - refEpoch)*1440,
     // offsets = (refEpoch - epoch)*1440 (L153); GMST at jd+fr
-    const double ref = c->h_epoch.empty() ? 0.0 : c->h_epoch[0];
+    // reference epoch: the first near-earth member's (Constellation.zig L139-140); a constellation without one
+    // uses its first member's
+    double ref = c->h_epoch.empty() ? 0.0 : c->h_epoch[0];
+    for (size_t s = 0; s < c->n; ++s)
+        if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && !(c->h_flags[s] & AZ_FLAG_DEEP)) { ref = c->h_epoch[s]; break; }
     std::vector<double> times(n_times), offs(c->n);
     for (size_t t = 0; t < n_times; ++t) times[t] = ((jd[t] + fr[t]) - ref) * 1440.0;
     for (size_t s = 0; s < c->n; ++s) offs[s] = (ref - c->h_epoch[s]) * 1440.0;
@@ -1096,6 +1177,46 @@ int32_t azh_propagate_one_host(azh_constellation *c, size_t sat, const double *t
     if (sat >= c->n) return AZ_ERR_VALUE;
     if (n == 0) return AZ_OK;
     return run_one_satellite(c, sat, tsince, n, 0, nullptr, pos, vel, err);
+}
+
+int32_t azh_propagate_one_device(azh_constellation *c, size_t sat, const double *d_tsince, size_t n, double *d_pos,
+                                 double *d_vel, uint8_t *d_err, void *stream)
+{
+    if (!c || !d_tsince || !d_pos) return AZ_ERR_NULL_POINTER;
+    if (sat >= c->n || n > 0xffffffffu) return AZ_ERR_VALUE;
+    if (n == 0) return AZ_OK;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    hipStream_t st = stream ? (hipStream_t)stream : c->s_main;
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
+    hipLaunchKernelGGL(k_one_satellite, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
+                       (unsigned)sat, d_tsince, (unsigned)n, d_pos, d_vel, d_err, 0, c->g, (const double *)nullptr, 0);
+    HIP_TRY(hipGetLastError());
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(c->ev_t1, st));
+        c->timed = true;
+    }
+    return AZ_OK;
+}
+
+// device-side known-answer hook for the element math of the kernels (devmath.h): out[0..n) sin, [n..2n) cos,
+// [2n..3n) x * az_rcp(x), [3n..4n) x * az_rsqrt(x)^2, [4n..6n) (sin,cos)(0.7321 + x) by az_rotate from (sin,cos)(0.7321)
+int32_t azh_selftest_math(const double *x, size_t n, double *out6n, int32_t device)
+{
+    if (!x || !out6n) return AZ_ERR_NULL_POINTER;
+    if (n == 0) return AZ_OK;
+    HIP_TRY(hipSetDevice(device));
+    double *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, sizeof(double) * 7 * n));
+    int32_t rc = AZ_OK;
+    if (!hip_ok(hipMemcpy(d, x, sizeof(double) * n, hipMemcpyHostToDevice), "H2D")) rc = AZ_ERR_HIP;
+    if (rc == AZ_OK) {
+        hipLaunchKernelGGL(k_math_kat, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, d, (unsigned)n, d + n);
+        if (!hip_ok(hipGetLastError(), "k_math_kat") ||
+            !hip_ok(hipMemcpy(out6n, d + n, sizeof(double) * 6 * n, hipMemcpyDeviceToHost), "D2H"))
+            rc = AZ_ERR_HIP;
+    }
+    (void)hipFree(d);
+    return rc;
 }
 
 // ======================================================================================= (A)
@@ -1180,6 +1301,50 @@ int32_t sgp4_propagate_batch(void *h, const double *times, double *results, uint
     if (!h || !times || !results) return AZ_ERR_NULL_POINTER;
     if (count == 0) return AZ_OK;
     return run_one_satellite(static_cast<Sgp4Handle *>(h)->c, 0, times, count, 1, results, nullptr, nullptr, nullptr);
+}
+
+// root.zig L73-81 / src/c_api/coordinates.zig: the output-mode math of the constellation path as scalar calls.
+// One tiny launch each, on device 0, using the very device functions of the kernels' epilogue (k_gmst,
+// az_to_ecef, az_ecef_to_geodetic) -- no host-side floating point.  A round trip to the GPU per call (~25 us):
+// loops belong in azh_propagate_*'s output modes.  Without a device the outputs are NaN.
+namespace {
+int32_t coords_call(int op, const double in[4], double out[3])
+{
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    static double *d_buf = nullptr;
+    const double nan = std::nan("");
+    out[0] = out[1] = out[2] = nan;
+    if (!hip_ok(hipSetDevice(0), "hipSetDevice")) return AZ_ERR_HIP;
+    if (!d_buf && !hip_ok(hipMalloc((void **)&d_buf, sizeof(double) * 8), "hipMalloc")) return AZ_ERR_HIP;
+    HIP_TRY(hipMemcpy(d_buf, in, sizeof(double) * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_coords, dim3(1), dim3(64), 0, nullptr, op, d_buf, d_buf + 4);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_buf + 4, sizeof(double) * 3, hipMemcpyDeviceToHost));
+    return AZ_OK;
+}
+} // namespace
+
+double coords_julian_to_gmst(double jd)
+{
+    const double in[4] = {jd, 0, 0, 0};
+    double out[3];
+    (void)coords_call(0, in, out);
+    return out[0];
+}
+
+void coords_eci_to_ecef(const double eci[3], double gmst, double ecef[3])
+{
+    if (!eci || !ecef) return;
+    const double in[4] = {eci[0], eci[1], eci[2], gmst};
+    (void)coords_call(1, in, ecef);
+}
+
+void coords_ecef_to_geodetic(const double ecef[3], double lla[3])
+{
+    if (!ecef || !lla) return;
+    const double in[4] = {ecef[0], ecef[1], ecef[2], 0};
+    (void)coords_call(2, in, lla);
 }
 
 } // extern "C"

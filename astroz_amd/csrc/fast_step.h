@@ -18,18 +18,42 @@
 
 // per-satellite constants of the fast step (wave-uniform in the lane = time kernel, per lane in the
 // lane = satellite kernel).  Folded products differ from the table rows by one rounding at most.
+// Names of the constants; the step reads them through accessor methods so that a kernel can decide where
+// each one lives (registers, or one LDS word read by all lanes at once).
+#define AZ_FASTK_COLD(X)                                                                                     \
+    X(cc1) X(d2) X(d3) X(d4) X(nl2) X(nl3) X(nl4) X(nl5) X(eta) X(omgcof) X(xmcof) X(xd) X(bc4) X(bc5) X(ecb) X(sab)
+#define AZ_FASTK_HOT(X)                                                                                      \
+    X(aycof) X(xlcof) X(xnodcf) X(sinio) X(cosio) X(k_mrt) X(k_c2u) X(k_su) X(k_node) X(k_inc) X(x1mth2) X(k_rv) \
+    X(sdA) X(cdA) X(sdW) X(cdW) X(sdO) X(cdO)
+enum FastCold {
+#define X(n) FC_##n,
+    AZ_FASTK_COLD(X)
+#undef X
+    FC_NUM
+};
+// everything in registers (lane = satellite kernels, host emulation)
 struct FastK {
-    // drag polynomials (Horner): tempa = 1 - t (cc1 + t (d2 + t (d3 + t d4)));
-    // no_unkozai * templ = t^2 (nl2 + t (nl3 + t (nl4 + t nl5)))
-    double cc1, d2, d3, d4, nl2, nl3, nl4, nl5;
-    double eta, omgcof, xmcof, xd; // th = omgcof t + xmcof (1 + eta cos M)^3 - xd,  xd = xmcof delmo
-    double bc4, bc5, ecb;          // em = ecb - bc4 t - bc5 sin(mm),  ecb = ecco + bc5 sinmao
-    double sab;                    // sqrt(a_base)
-    double aycof, xlcof, xnodcf;
-    double sinio, cosio;
-    double k_mrt, k_c2u, k_su, k_node, k_inc, x1mth2, k_rv;
-    // (sin,cos) of the per-step increments of M, argp, node (linear part)
-    double sdA, cdA, sdW, cdW, sdO, cdO;
+#define X(n) double n##_;
+    AZ_FASTK_COLD(X) AZ_FASTK_HOT(X)
+#undef X
+#define X(n) AZ_MEMBER double n() const { return n##_; }
+    AZ_FASTK_COLD(X) AZ_FASTK_HOT(X)
+#undef X
+};
+// lane = time kernels (one satellite per wave): the 18 constants used several times per step or sitting
+// on the critical path stay in (scalar) registers, the 16 once-per-step ones are LDS words read by all
+// lanes at once (broadcast ds_read: no VALU slot, no register residency)
+struct FastKBcast {
+    const double *cold;
+#define X(n) double n##_;
+    AZ_FASTK_HOT(X)
+#undef X
+#define X(n) AZ_MEMBER double n() const { return n##_; }
+    AZ_FASTK_HOT(X)
+#undef X
+#define X(n) AZ_MEMBER double n() const { return cold[FC_##n]; }
+    AZ_FASTK_COLD(X)
+#undef X
 };
 
 // carried (sin,cos) pairs: M = mo + mdot t, W = argpo + argpdot t, O = nodeo + nodedot t (the
@@ -42,32 +66,31 @@ struct FastCarry {
 // which = 0: dt = 64 grid steps (lane = time kernels), 1: dt = one grid step (lane = satellite kernels)
 enum { AZ_INC_sdA, AZ_INC_cdA, AZ_INC_sdW, AZ_INC_cdW, AZ_INC_sdO, AZ_INC_cdO, AZ_INC_NUM };
 
-template <class K>
 AZ_DEVICE void az_load_fast(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags,
-                            const double *__restrict__ inc, int which, K &k)
+                            const double *__restrict__ inc, int which, FastK &k)
 {
 #define L(f) el[(size_t)F_##f * n_pad + i]
     const bool ho = !(flags & AZ_FLAG_ISIMP);
     const double no = L(no_unkozai);
-    k.cc1 = L(cc1); k.d2 = L(d2); k.d3 = L(d3); k.d4 = L(d4);
-    k.nl2 = no * L(t2cof); k.nl3 = no * L(t3cof); k.nl4 = no * L(t4cof); k.nl5 = no * L(t5cof);
-    k.eta = L(eta);
-    k.omgcof = ho ? L(omgcof) : 0.0;
-    k.xmcof = ho ? L(xmcof) : 0.0;
-    k.xd = k.xmcof * L(delmo);
-    k.bc4 = L(bc4);
-    k.bc5 = ho ? L(bc5) : 0.0;
-    k.ecb = fma(k.bc5, L(sinmao), L(ecco));
-    k.sab = L(sqrt_a_base);
-    k.aycof = L(aycof); k.xlcof = L(xlcof); k.xnodcf = L(xnodcf);
-    k.sinio = L(sinio); k.cosio = L(cosio);
-    az_j2_factors(L(con41), L(x1mth2), L(x7thm1), k.sinio, k.cosio, k.k_mrt, k.k_c2u, k.k_su, k.k_node, k.k_inc,
-                  k.k_rv);
-    k.x1mth2 = L(x1mth2);
+    k.cc1_ = L(cc1); k.d2_ = L(d2); k.d3_ = L(d3); k.d4_ = L(d4);
+    k.nl2_ = no * L(t2cof); k.nl3_ = no * L(t3cof); k.nl4_ = no * L(t4cof); k.nl5_ = no * L(t5cof);
+    k.eta_ = L(eta);
+    k.omgcof_ = ho ? L(omgcof) : 0.0;
+    k.xmcof_ = ho ? L(xmcof) : 0.0;
+    k.xd_ = k.xmcof_ * L(delmo);
+    k.bc4_ = L(bc4);
+    k.bc5_ = ho ? L(bc5) : 0.0;
+    k.ecb_ = fma(k.bc5_, L(sinmao), L(ecco));
+    k.sab_ = L(sqrt_a_base);
+    k.aycof_ = L(aycof); k.xlcof_ = L(xlcof); k.xnodcf_ = L(xnodcf);
+    k.sinio_ = L(sinio); k.cosio_ = L(cosio);
+    az_j2_factors(L(con41), L(x1mth2), L(x7thm1), k.sinio_, k.cosio_, k.k_mrt_, k.k_c2u_, k.k_su_, k.k_node_,
+                  k.k_inc_, k.k_rv_);
+    k.x1mth2_ = L(x1mth2);
     const double *q = inc + (size_t)(6 * which) * n_pad + i;
-    k.sdA = q[(size_t)AZ_INC_sdA * n_pad]; k.cdA = q[(size_t)AZ_INC_cdA * n_pad];
-    k.sdW = q[(size_t)AZ_INC_sdW * n_pad]; k.cdW = q[(size_t)AZ_INC_cdW * n_pad];
-    k.sdO = q[(size_t)AZ_INC_sdO * n_pad]; k.cdO = q[(size_t)AZ_INC_cdO * n_pad];
+    k.sdA_ = q[(size_t)AZ_INC_sdA * n_pad]; k.cdA_ = q[(size_t)AZ_INC_cdA * n_pad];
+    k.sdW_ = q[(size_t)AZ_INC_sdW * n_pad]; k.cdW_ = q[(size_t)AZ_INC_cdW * n_pad];
+    k.sdO_ = q[(size_t)AZ_INC_sdO * n_pad]; k.cdO_ = q[(size_t)AZ_INC_cdO * n_pad];
 #undef L
 }
 
@@ -122,34 +145,34 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, do
 {
     // advance the carried pairs by their constant increments
     {
-        const double nsA = fma(st.sA, k.cdA, st.cA * k.sdA);
-        st.cA = fma(st.cA, k.cdA, -(st.sA * k.sdA));
+        const double nsA = fma(st.sA, k.cdA(), st.cA * k.sdA());
+        st.cA = fma(st.cA, k.cdA(), -(st.sA * k.sdA()));
         st.sA = nsA;
-        const double nsW = fma(st.sW, k.cdW, st.cW * k.sdW);
-        st.cW = fma(st.cW, k.cdW, -(st.sW * k.sdW));
+        const double nsW = fma(st.sW, k.cdW(), st.cW * k.sdW());
+        st.cW = fma(st.cW, k.cdW(), -(st.sW * k.sdW()));
         st.sW = nsW;
-        const double nsO = fma(st.sO, k.cdO, st.cO * k.sdO);
-        st.cO = fma(st.cO, k.cdO, -(st.sO * k.sdO));
+        const double nsO = fma(st.sO, k.cdO(), st.cO * k.sdO());
+        st.cO = fma(st.cO, k.cdO(), -(st.sO * k.sdO()));
         st.sO = nsO;
     }
     const double sA = st.sA, cA = st.cA;
     const double t2 = t * t;
 
     // secular gravity + drag (Sgp4Batch.zig L121-154)
-    const double dm = fma(k.eta, cA, 1.0);
-    const double th = fma(k.xmcof, dm * dm * dm, fma(k.omgcof, t, -k.xd)); // delomg + delm
-    const double tempa = fma(-t, fma(t, fma(t, fma(t, k.d4, k.d3), k.d2), k.cc1), 1.0);
-    const double nl = t2 * fma(t, fma(t, fma(t, k.nl5, k.nl4), k.nl3), k.nl2); // no_unkozai * templ
+    const double dm = fma(k.eta(), cA, 1.0);
+    const double th = fma(k.xmcof(), dm * dm * dm, fma(k.omgcof(), t, -k.xd())); // delomg + delm
+    const double tempa = fma(-t, fma(t, fma(t, fma(t, k.d4(), k.d3()), k.d2()), k.cc1()), 1.0);
+    const double nl = t2 * fma(t, fma(t, fma(t, k.nl5(), k.nl4()), k.nl3()), k.nl2()); // no_unkozai * templ
     bool bad = !(fabs(th) <= AZ_ROT_SMALL);
     double p, q;
     az_pq_small(th, rk, p, q);
     const double smm = fma(cA, p, fma(sA, q, sA));            // sin(M + th)
     const double sw = fma(-st.cW, p, fma(st.sW, q, st.sW));   // (sin,cos)(W - th)
     const double cw = fma(st.sW, p, fma(st.cW, q, st.cW));
-    const double em = fmax(fma(-k.bc5, smm, fma(-k.bc4, t, k.ecb)), 1.0e-6);
+    const double em = fmax(fma(-k.bc5(), smm, fma(-k.bc4(), t, k.ecb())), 1.0e-6);
 
     // am = a_base tempa^2: one reciprocal gives 1/sqrt(am) and 1/(am (1 - em^2))
-    const double sqrt_am = k.sab * fabs(tempa);
+    const double sqrt_am = k.sab() * fabs(tempa);
     const double am = sqrt_am * sqrt_am;
     const double omem2 = fma(-em, em, 1.0);
     const double R = az_rcp(sqrt_am * omem2);
@@ -157,12 +180,12 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, do
     const double temp = ra * R;
 
     const double axnl = em * cw;
-    const double aynl = fma(em, sw, temp * k.aycof);
+    const double aynl = fma(em, sw, temp * k.aycof());
     // u0 = M + W + no*templ + temp*xlcof*axnl
     double s = fma(sA, st.cW, cA * st.sW);
     double c = fma(cA, st.cW, -(sA * st.sW));
     {
-        const double eps = fma(temp * k.xlcof, axnl, nl);
+        const double eps = fma(temp * k.xlcof(), axnl, nl);
         bad |= !(fabs(eps) <= AZ_ROT_16TH);
         az_pq_16th(eps, rk, p, q);
         az_rot_apply2(s, c, p, q);
@@ -204,16 +227,16 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, do
     const double temp2 = temp1 * inv_pl;
     bad |= !(temp2 <= AZ_FAST_TEMP2);
 
-    const double mrt = fma(rl, fma(k.k_mrt * temp2, betal, 1.0), k.k_c2u * temp1 * cos2u);
+    const double mrt = fma(rl, fma(k.k_mrt() * temp2, betal, 1.0), k.k_c2u() * temp1 * cos2u);
     const double t2s = temp2 * sin2u;
     // J2 short-period corrections as tiny rotations (each bounded by 1.5 temp2 <= 9e-4); the secular
     // xnodcf t^2 part of the node rides on the node correction
-    const double a_nd = fma(k.k_node, t2s, k.xnodcf * t2);
+    const double a_nd = fma(k.k_node(), t2s, k.xnodcf() * t2);
     bad |= !(fabs(a_nd) <= AZ_ROT_MILLI);
-    double ssu = sinu, csu = cosu, sn = st.sO, cn = st.cO, si = k.sinio, ci = k.cosio;
-    az_rotate_tiny2(ssu, csu, k.k_su * t2s, rk);
+    double ssu = sinu, csu = cosu, sn = st.sO, cn = st.cO, si = k.sinio(), ci = k.cosio();
+    az_rotate_tiny2(ssu, csu, k.k_su() * t2s, rk);
     az_rotate_tiny2(sn, cn, a_nd, rk);
-    az_rotate_tiny2(si, ci, k.k_inc * temp2 * cos2u, rk);
+    az_rotate_tiny2(si, ci, k.k_inc() * temp2 * cos2u, rk);
 
     const double xmx = -sn * ci, xmy = cn * ci;
     const double ux = fma(xmx, ssu, cn * csu);
@@ -227,8 +250,8 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, do
         const double rv = ra * g.vkmpersec;         // vkmpersec / sqrt(am)
         const double vk = rv * inv_ome;             // common factor of rdotl, rvdotl (km/s)
         const double nxt = rv * inv_am * temp1;     // (nm/xke) temp1, km/s
-        const double mvt = fma(-nxt * k.x1mth2, sin2u, vk * esine);
-        const double rvdot = fma(nxt, fma(k.x1mth2, cos2u, k.k_rv), vk * betal);
+        const double mvt = fma(-nxt * k.x1mth2(), sin2u, vk * esine);
+        const double rvdot = fma(nxt, fma(k.x1mth2(), cos2u, k.k_rv()), vk * betal);
         const double vx = fma(xmx, csu, -(cn * ssu));
         const double vy = fma(xmy, csu, -(sn * ssu));
         const double vz = si * csu;

@@ -77,6 +77,13 @@ struct PropArgs {
     // rotation increments k_prep_inc prepared for it (fast_step.h); null = generic path only
     double uniform_step;
     const double *inc;
+    // row window: only satellites with row_lo <= table index < row_hi are produced by this launch (chunked
+    // launches whose results feed a collective while the next chunk is still being computed)
+    unsigned row_lo, row_hi;
+    // k_rows_fast -> k_rows hand-over: (list slot, first grid point, end) of every segment remainder the fast
+    // step rejected
+    unsigned *redo_count;
+    unsigned *redo_items;
     AzGrav g;
 };
 
@@ -201,7 +208,8 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
     // Constellation.zig L145-147) so the wave stays convergent; they never store
     const unsigned s = p.list[in_range ? li : p.n_list - 1];
     const unsigned fl = p.flags[s];
-    const bool wr = in_range && (p.mask == nullptr || p.mask[s] != 0);
+    const bool wr = in_range && (p.mask == nullptr || p.mask[s] != 0) && s >= p.row_lo && s < p.row_hi;
+    if (!SCREEN && !az_any(wr)) return; // nothing to write (masked out / outside the row window)
     const double off = p.offsets ? p.offsets[s] : 0.0;
     const unsigned t0 = blockIdx.y * p.tile;
     const unsigned t1 = min(t0 + p.tile, p.n_times);
@@ -210,7 +218,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
     // orders every 256-slot group of the list by eccentricity class, so a wave that straddles a class boundary
     // holds a permutation of -- or not even -- a run of rows: the vote looks at the real mapping)
     const unsigned s_first = p.list[li0];
-    const bool dense = (LAYOUT == 1) && !DEEP && (p.mask == nullptr) && !p.f32 && !az_any(!(in_range && s == s_first + lane));
+    const bool dense = (LAYOUT == 1) && !DEEP && (p.mask == nullptr) && !p.f32 && !az_any(!(wr && s == s_first + lane));
 
     double tcache = 0.0;
     const RotK rk = az_rotk();
@@ -549,8 +557,8 @@ struct ColdBroadcast {
     __device__ __forceinline__ double operator()(int k) const { return p[k]; }
     __device__ __forceinline__ void set(int k, double v) const { p[k] = v; }
 };
-#ifndef AZ_ROWS_FAST
-#define AZ_ROWS_FAST 1 /* k_rows: try the branch-free fast step first (fast_step.h) */
+#ifndef AZ_ROWSF_WAVES
+#define AZ_ROWSF_WAVES 6 /* k_rows_fast: 74 VGPRs */
 #endif
 #ifndef AZ_ROWS_TLDS
 #define AZ_ROWS_TLDS 1024 /* k_rows: time values staged in LDS per refill (a power of two >= 64) */
@@ -576,25 +584,176 @@ __device__ __forceinline__ void az_wave_argmin(double &d2, unsigned &t)
     }
 }
 
+
+// Row stores of the lane = time kernels through a wave-private LDS transpose: a wave's 64 results of one
+// array are 64 x 24 (12) contiguous bytes of a satellite-major row; written as they sit in the lanes (a
+// 16-byte and an 8-byte piece per lane at a 24-byte stride) every store instruction leaves holes that
+// only close when its sibling instruction reaches the same L2 lines -- fine while the arithmetic paces the
+// stores, but a store-bound kernel collapses to ~2.5 TB/s that way (measured: stores-only 0.377 ms for
+// 932 MB).  Through LDS every lane stores 16 ALIGNED bytes and one instruction covers 1,024 contiguous
+// bytes = 8 full 128-byte lines.  ds_write_b64 at a 24-byte lane stride is conflict-free (banks 6k mod 32).
+#ifndef AZ_ROWS_LDS_STORE
+#define AZ_ROWS_LDS_STORE 1
+#endif
+typedef float az_f4 __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ __forceinline__ void az_stage3(T *stage, unsigned lane, const double r[3])
+{
+    stage[lane * 3 + 0] = (T)r[0];
+    stage[lane * 3 + 1] = (T)r[1];
+    stage[lane * 3 + 2] = (T)r[2];
+}
+// 64 lanes x 3 components of type T staged at `stage` -> 16-byte pieces at `out` (16-byte aligned)
+template <class T>
+__device__ __forceinline__ void az_flush_stage(const T *stage, T *out, unsigned lane)
+{
+    constexpr unsigned PIECES = 64 * 3 * sizeof(T) / 16; // 96 (fp64) / 48 (fp32)
+    const az_f4 *src = reinterpret_cast<const az_f4 *>(stage);
+    az_f4 *dst = reinterpret_cast<az_f4 *>(out);
+#if AZ_ROWS_NT
+    if (lane < PIECES) __builtin_nontemporal_store(src[lane], dst + lane);
+    if (PIECES > 64 && lane + 64 < PIECES) __builtin_nontemporal_store(src[lane + 64], dst + lane + 64);
+#else
+    if (lane < PIECES) dst[lane] = src[lane];
+    if (PIECES > 64 && lane + 64 < PIECES) dst[lane + 64] = src[lane + 64];
+#endif
+}
+// one wave's work on a row segment, shared by the two row kernels: where a finished iteration goes
+template <bool VEL, class out_t>
+__device__ __forceinline__ void az_rows_store(bool staged, bool full, bool live, unsigned lane, out_t *stage, out_t *prow,
+                                              out_t *vrow, unsigned base, const double r[3], const double v[3])
+{
+    if (staged && full) {
+        az_stage3(stage, lane, r);
+        if (VEL) az_stage3(stage + 192, lane, v);
+        az_wave_lds_fence();
+        az_flush_stage(stage, prow + (size_t)base * 3, lane);
+        if (VEL) az_flush_stage(stage + 192, vrow + (size_t)base * 3, lane);
+        az_wave_lds_fence();
+    } else if (live) {
+        // partial iteration / unaligned row: direct 24-byte (12-byte) pieces per lane
+        az_put3_stream(prow + (size_t)(base + lane) * 3, r);
+        if (VEL) az_put3_stream(vrow + (size_t)(base + lane) * 3, v);
+    }
+}
+
+// Near-earth rows on a UNIFORM grid: the branch-free step of fast_step.h, one wave per (satellite row, time
+// segment), lane = time.  74 VGPRs (6 waves/SIMD; the generic k_rows needs 135 = 3): the 18 hot constants sit in
+// SGPRs, the 16 once-per-step ones in LDS (broadcast reads), time is t0 + i*step (no staging, no loads in the
+// loop).  A wave whose validation vote fails -- eccentric orbit, an angle outside its tier -- appends the rest of
+// its segment to the redo list and exits; the generic kernel runs that list afterwards.
 template <bool VEL, bool FRAME, int SINK>
-__global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
+__global__ void __launch_bounds__(64, AZ_ROWSF_WAVES) k_rows_fast(PropArgs p)
 {
     typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
     const unsigned lane = threadIdx.x;
-    // XCD-aware row assignment: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the
-    // rows are dealt out in eight contiguous ranges -- every XCD then reads one eighth of the SoA
-    // element table (8 satellites share each 64-B line) instead of all of it
-    const unsigned per_xcd = gridDim.x >> 3; // gridDim.x is a multiple of 8
+    const unsigned per_xcd = gridDim.x >> 3; // XCD-aware row assignment, see k_rows
     const unsigned row = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (row >= p.n_list) return;
     const unsigned s = p.list[row]; // wave-uniform
     const unsigned fl = p.flags[s];
-    if (SINK != AZ_SINK_SCREEN && p.mask != nullptr && p.mask[s] == 0) return;
-    // blockIdx.y: time segment of p.tile grid points (a multiple of 64) -- splits long rows so that
-    // the grid has enough waves to fill the chip several times over
+    if ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi) return;
     const unsigned t_lo = blockIdx.y * p.tile;
     const unsigned t_hi = min(t_lo + p.tile, p.n_times);
+    unsigned base = t_lo;
+    if (AZ_FLAG_ECLASS(fl) == 0) {
+        __shared__ __attribute__((aligned(16))) double cold_lds[FC_NUM];
+        __shared__ __attribute__((aligned(16))) out_t rows_stage[AZ_ROWS_LDS_STORE ? 2 * 64 * 3 : 4];
+        const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
+        const RotK rk = az_rotk();
+        out_t *prow = reinterpret_cast<out_t *>(p.pos) + (size_t)s * p.n_times * 3;
+        out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + (size_t)s * p.n_times * 3 : nullptr;
+        const bool staged = AZ_ROWS_LDS_STORE &&
+                            (((reinterpret_cast<size_t>(prow) | (VEL ? reinterpret_cast<size_t>(vrow) : 0)) & 15u) == 0);
+        FastKBcast k;
+        {
+            FastK k0;
+            az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k0);
+#define X(n) if (lane == 0) cold_lds[FC_##n] = k0.n##_;
+            AZ_FASTK_COLD(X)
+#undef X
+#define X(n) k.n##_ = az_uniform(k0.n##_);
+            AZ_FASTK_HOT(X)
+#undef X
+            az_wave_lds_fence();
+        }
+        const double step = p.uniform_step;
+        const double t_first = p.times[0] + off; // tsince of grid point 0; grid point i is t_first + i*step
+        FastCarry fc;
+        // seed one increment (64 grid steps) BEFORE this lane's first grid point
+        az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + lane) - 64.0, step, t_first), fc);
+#pragma unroll 1
+        for (; base < t_hi; base += 64) {
+            const unsigned i = base + lane;
+            const bool live = i < t_hi;
+            const double t = fma((double)i, step, t_first);
+            // the cold constants are re-read from LDS where they are used: an opaque zero in the address keeps
+            // the compiler from hoisting 16 loop-invariant loads into 32 VGPRs
+            unsigned zero = 0;
+            asm volatile("" : "+s"(zero));
+            k.cold = cold_lds + zero;
+            double r[3], v[3];
+#if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
+            r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
+#else
+            const bool bad = az_sgp4_fast_step<VEL>(k, p.g, rk, t, fc, r, v);
+            if (az_any(bad && live)) break;
+#endif
+            if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
+#if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only (every component stays live) */
+            if (!(live && (r[0] + r[1] + r[2] + (VEL ? v[0] + v[1] + v[2] : 0.0)) == 1.2345e300)) continue;
+#endif
+            az_rows_store<VEL>(staged, base + 64 <= t_hi, live, lane, rows_stage, prow, vrow, base, r, v);
+        }
+    }
+    if (base < t_hi && lane == 0) {
+        // rest of the segment -> generic kernel (one item: list slot, first grid point, end)
+        const unsigned k = atomicAdd(p.redo_count, 1u);
+        p.redo_items[3 * (size_t)k + 0] = row;
+        p.redo_items[3 * (size_t)k + 1] = base;
+        p.redo_items[3 * (size_t)k + 2] = t_hi;
+    }
+}
+
+// Near-earth rows, any grid, any eccentricity: tier votes inside the step (az_sgp4_step).  Two ways in:
+//   grid (rows padded to 8, time segments)  -- the whole list, when no fast path applies (irregular grid, fused
+//                                               screen, fast path switched off);
+//   REDO: grid (N, 4)                       -- the items k_rows_fast rejected; every workgroup takes items
+//                                               blockIdx.x, +gridDim.x, ... and a quarter (blockIdx.y) of each,
+//                                               so that the few items are spread over the whole chip.
+template <bool VEL, bool FRAME, int SINK, bool REDO = false>
+__global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
+{
+    typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
+    const unsigned lane = threadIdx.x;
     __shared__ __attribute__((aligned(16))) double rows_lds[AZ_ROWS_TLDS + C_NUM_MAX + 2];
+    constexpr bool redo = REDO; // a separate instantiation: the item loop costs the whole-list form ~100 spilled SGPRs
+    const unsigned n_items = redo ? *p.redo_count : 1u;
+#pragma unroll 1
+    for (unsigned item = redo ? blockIdx.x : 0u; item < n_items; item += redo ? gridDim.x : 1u) {
+    unsigned row, t_lo, t_hi;
+    if (redo) {
+        row = p.redo_items[3 * (size_t)item];
+        const unsigned b0 = p.redo_items[3 * (size_t)item + 1], b1 = p.redo_items[3 * (size_t)item + 2];
+        const unsigned quarter = (((b1 - b0 + 63) / 64 + gridDim.y - 1) / gridDim.y) * 64; // whole iterations
+        t_lo = b0 + blockIdx.y * quarter;
+        t_hi = min(t_lo + quarter, b1);
+        if (t_lo >= b1) continue;
+    } else {
+        // XCD-aware row assignment: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the
+        // rows are dealt out in eight contiguous ranges -- every XCD then reads one eighth of the SoA
+        // element table (8 satellites share each 64-B line) instead of all of it
+        const unsigned per_xcd = gridDim.x >> 3; // gridDim.x is a multiple of 8
+        row = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+        if (row >= p.n_list) return;
+        // blockIdx.y: time segment of p.tile grid points (a multiple of 64) -- splits long rows so that
+        // the grid has enough waves to fill the chip several times over
+        t_lo = blockIdx.y * p.tile;
+        t_hi = min(t_lo + p.tile, p.n_times);
+    }
+    const unsigned s = p.list[row]; // wave-uniform
+    const unsigned fl = p.flags[s];
+    if (SINK != AZ_SINK_SCREEN && ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi)) continue;
     const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
     const RotK rk = az_rotk();
 #if defined(AZ_ABLATE) && AZ_ABLATE == 3 /* tuning experiment: all rows alias 64 rows (L2-resident window) */
@@ -606,61 +765,7 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + srow * p.n_times * 3 : nullptr;
     double best_d2 = __builtin_inf();
     unsigned best_t = 0xffffffffu;
-    // Time values go through LDS (AZ_ROWS_TLDS grid points per refill): the loop then holds no
-    // vector-memory LOAD at all.  vmcnt counts loads and stores in issue order, so a load's
-    // s_waitcnt also waits for every output store issued before it -- one load per iteration
-    // serialises the arithmetic against the write stream; ds_read waits on lgkmcnt only.
-    unsigned base = t_lo;
-#if AZ_ROWS_FAST
-    // Optimistic straight-line loop (fast_step.h): uniform grid, near-circular orbit, every small angle
-    // inside its usual tier.  No votes, no branches inside a step; one vote per iteration on the
-    // accumulated `bad` predicate.  On a violation nothing of that iteration has been stored and the
-    // generic loop below takes over from the same grid point.
-    if (p.inc != nullptr && p.uniform_step != 0.0 && AZ_FLAG_ECLASS(fl) == 0) {
-        FastK k;
-        az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k);
-        FastCarry fc;
-        {
-            // seed one increment BEFORE this lane's first grid point
-            const double t0 = p.times[min(t_lo + lane, p.n_times - 1)] + off - 64.0 * p.uniform_step;
-            az_seed_fast(p.el, p.n_pad, s, t0, fc);
-        }
-#pragma unroll 1
-        for (; base < t_hi; base += 64) {
-            const unsigned i = base + lane;
-            const bool live = i < t_hi;
-            const unsigned kk = (base - t_lo) & (AZ_ROWS_TLDS - 1u);
-            if (kk == 0) {
-                az_wave_lds_fence();
-#pragma unroll
-                for (unsigned j = 0; j < AZ_ROWS_TLDS; j += 64) rows_lds[j + lane] = p.times[min(i + j, t_hi - 1)];
-                az_wave_lds_fence();
-            }
-            const double t = rows_lds[kk + lane] + off;
-            double r[3], v[3];
-            const bool bad = az_sgp4_fast_step<VEL>(k, p.g, rk, t, fc, r, v);
-            if (az_any(bad && live)) break;
-            if (SINK == AZ_SINK_SCREEN) {
-                const double *q = p.screen_target + (size_t)(live ? i : t_hi - 1) * 3;
-                const double dx = q[0] - r[0], dy = q[1] - r[1], dz = q[2] - r[2];
-                const double d2 = dx * dx + dy * dy + dz * dz;
-                if (live && d2 < best_d2) { // NaN (failed target step) never wins
-                    best_d2 = d2;
-                    best_t = i;
-                }
-                continue;
-            }
-            if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
-            if (live) {
-                az_put3_stream(prow + (size_t)i * 3, r);
-                if (VEL) az_put3_stream(vrow + (size_t)i * 3, v);
-            }
-        }
-    }
-#endif
-    const unsigned g_lo = base; // first grid point of the generic loop (re-seeds its carried pairs there)
-    if (base < t_hi) {
-    // generic loop: any grid, any eccentricity (tier votes inside the step)
+    az_wave_lds_fence();
     Sgp4Lane e;
     typedef ColdBroadcast ColdT;
     const ColdT cold{rows_lds + AZ_ROWS_TLDS};
@@ -677,22 +782,25 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     c.dt_c = -1.0e300;
     c.sdA = c.pW = c.qW = 0.0;
     c.cdA = 1.0;
+    // Time values go through LDS (AZ_ROWS_TLDS grid points per refill): the loop then holds no
+    // vector-memory LOAD at all.  vmcnt counts loads and stores in issue order, so a load's
+    // s_waitcnt also waits for every output store issued before it -- one load per iteration
+    // serialises the arithmetic against the write stream; ds_read waits on lgkmcnt only.
 #pragma unroll 1
-    for (; base < t_hi; base += 64) {
+    for (unsigned base = t_lo; base < t_hi; base += 64) {
         const unsigned i = base + lane;
         const bool live = i < t_hi;
         const unsigned kk = (base - t_lo) & (AZ_ROWS_TLDS - 1u);
-        if (kk == 0 || base == g_lo) {
+        if (kk == 0) {
             az_wave_lds_fence();
-            const unsigned b0 = base - kk; // start of the staged window
 #pragma unroll
-            for (unsigned j = 0; j < AZ_ROWS_TLDS; j += 64) rows_lds[j + lane] = p.times[min(b0 + lane + j, t_hi - 1)];
+            for (unsigned j = 0; j < AZ_ROWS_TLDS; j += 64) rows_lds[j + lane] = p.times[min(i + j, t_hi - 1)];
             az_wave_lds_fence();
         }
         const double t = rows_lds[kk + lane] + off;
         double r[3], v[3];
         // full re-seed of the carried pairs at the start and every 64 iterations (4,096 grid points)
-        const bool first = ((base - g_lo) & (64u * 64u - 1u)) == 0;
+        const bool first = ((base - t_lo) & (64u * 64u - 1u)) == 0;
 #if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
         r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
         (void)first;
@@ -713,18 +821,15 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
         }
         if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
 #if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only (every component stays live) */
-        if (live && (r[0] + r[1] + r[2] + (VEL ? v[0] + v[1] + v[2] : 0.0)) == 1.2345e300) {
-#else
-        if (live) {
+        if (!(live && (r[0] + r[1] + r[2] + (VEL ? v[0] + v[1] + v[2] : 0.0)) == 1.2345e300)) continue;
 #endif
-            // direct 24-byte (12-byte) pieces per lane: contiguous across the wave.  (Measured: a
-            // transpose through LDS into 16-byte pieces per lane is slower, 0.41 vs 0.36 ms -- the
-            // lgkmcnt round trip in front of the stores costs more than the fragmented requests.)
+        // direct 24-byte (12-byte) pieces per lane, contiguous across the wave: this kernel is paced by its
+        // arithmetic, and for it the LDS transpose of k_rows_fast measures slower (0.269 vs 0.262 ms)
+        if (live) {
             az_put3_stream(prow + (size_t)i * 3, r);
             if (VEL) az_put3_stream(vrow + (size_t)i * 3, v);
         }
     }
-    } // generic loop
     if (SINK == AZ_SINK_SCREEN) {
         az_wave_argmin(best_d2, best_t);
         if (lane == 0) {
@@ -732,6 +837,7 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
             p.part_t[(size_t)blockIdx.y * p.n_list + row] = best_t;
         }
     }
+    } // items
 }
 
 // Deep-space rows, satellite-major output (and the fused screen): ONE WAVE PER SATELLITE, lane = time,
@@ -754,7 +860,7 @@ __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
     if (row >= p.n_list) return;
     const unsigned s = p.list[row];
     const unsigned fl = p.flags[s];
-    if (SINK != AZ_SINK_SCREEN && p.mask != nullptr && p.mask[s] == 0) return;
+    if (SINK != AZ_SINK_SCREEN && ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi)) return;
     const unsigned t_lo = blockIdx.y * p.tile; // p.tile is a multiple of 64
     const unsigned t_hi = min(t_lo + p.tile, p.n_times);
     __shared__ double lds[TL + H_NUM + D_NUM];
@@ -985,13 +1091,13 @@ __global__ void __launch_bounds__(256) k_cells_probe(CellArgs a)
 // rows of satellites whose init failed: zero state + the init error code at every time
 __global__ void k_fill_bad(const unsigned *list, unsigned n_list, const unsigned *flags, unsigned n_times,
                            double *pos, double *vel, unsigned char *err, const unsigned char *mask, int layout,
-                           size_t stride_sats, int f32)
+                           size_t stride_sats, int f32, unsigned row_lo, unsigned row_hi)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x; // time
     const unsigned li = blockIdx.y;
     if (i >= n_times || li >= n_list) return;
     const unsigned s = list[li];
-    if (mask && !mask[s]) return;
+    if ((mask && !mask[s]) || s < row_lo || s >= row_hi) return;
     const size_t ob = (layout == 0) ? ((size_t)s * n_times + i) * 3 : ((size_t)i * stride_sats + s) * 3;
     if (f32) {
         float *p32 = reinterpret_cast<float *>(pos), *v32 = reinterpret_cast<float *>(vel);
@@ -1038,6 +1144,46 @@ __global__ void __launch_bounds__(256) k_prep_inc(const double *el, size_t n, si
             inc[(size_t)(6 * which + 2 * a) * n_pad + s] = sn;
             inc[(size_t)(6 * which + 2 * a + 1) * n_pad + s] = cs;
         }
+    }
+}
+
+// scalar coordinate helpers of the c_api (coords_*, src/c_api/coordinates.zig): op 0 julianToGmst(in[0]),
+// op 1 eciToEcefGmst(in[0..3), gmst = in[3]), op 2 ecefToGeodeticDeg(in[0..3)) [lat deg, lon deg, alt km]
+__global__ void k_coords(int op, const double *in, double *out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (op == 0) {
+        const double d = in[0] - 2451545.0;
+        const double tc = d / 36525.0;
+        double gm = 280.46061837 + 360.98564736629 * d + 0.000387933 * tc * tc - tc * tc * tc / 38710000.0;
+        gm = fmod(gm, 360.0);
+        if (gm < 0) gm += 360.0;
+        out[0] = gm * (AZ_PI / 180.0);
+        out[1] = out[2] = 0.0;
+    } else if (op == 1) {
+        double r[3] = {in[0], in[1], in[2]};
+        az_to_ecef(r, sin(in[3]), cos(in[3]));
+        out[0] = r[0]; out[1] = r[1]; out[2] = r[2];
+    } else {
+        double r[3] = {in[0], in[1], in[2]};
+        az_ecef_to_geodetic(r);
+        out[0] = r[0] * (180.0 / AZ_PI); out[1] = r[1] * (180.0 / AZ_PI); out[2] = r[2];
+    }
+}
+
+// known-answer hook for devmath.h on the device itself (azh_selftest_math)
+__global__ void __launch_bounds__(64) k_math_kat(const double *x, unsigned n, double *out)
+{
+    const unsigned i = blockIdx.x * 64 + threadIdx.x;
+    const double v = x[i < n ? i : n - 1];
+    double sn, cs;
+    az_sincos(v, sn, cs);
+    const double rc = az_rcp(v), rs = az_rsqrt(fabs(v));
+    double s0 = 0.6684330296514408, c0 = 0.7437723340317224; // (sin,cos)(0.7321)
+    az_rotate(s0, c0, v, az_rotk());
+    if (i < n) {
+        out[i] = sn; out[n + i] = cs; out[2 * (size_t)n + i] = v * rc; out[3 * (size_t)n + i] = fabs(v) * rs * rs;
+        out[4 * (size_t)n + i] = s0; out[5 * (size_t)n + i] = c0;
     }
 }
 

@@ -146,4 +146,138 @@ void parse_all(std::string_view text, std::vector<TleRecord> &out)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// OMM JSON.  A deliberately small reader: objects whose values are strings, numbers, true/false/null
+// (anything nested is skipped), which is all an OMM record holds.
+namespace {
+
+struct JsonCursor {
+    std::string_view t;
+    size_t i = 0;
+    void ws() { while (i < t.size() && (t[i] == ' ' || t[i] == '\t' || t[i] == '\n' || t[i] == '\r')) ++i; }
+    bool eat(char c) { ws(); if (i < t.size() && t[i] == c) { ++i; return true; } return false; }
+    bool peek(char c) { ws(); return i < t.size() && t[i] == c; }
+    // string token -> raw contents (escapes are kept verbatim: no OMM field needs them decoded)
+    bool string(std::string_view &out)
+    {
+        ws();
+        if (i >= t.size() || t[i] != '"') return false;
+        size_t a = ++i;
+        while (i < t.size() && t[i] != '"') i += (t[i] == '\\' && i + 1 < t.size()) ? 2 : 1;
+        if (i >= t.size()) return false;
+        out = t.substr(a, i - a);
+        ++i;
+        return true;
+    }
+    // any value; strings and bare tokens (numbers, true, false, null) are returned as text
+    bool value(std::string_view &out, bool &is_string)
+    {
+        ws();
+        if (i >= t.size()) return false;
+        if (t[i] == '"') { is_string = true; return string(out); }
+        is_string = false;
+        if (t[i] == '{' || t[i] == '[') { // nested container: skip it
+            int depth = 0;
+            size_t a = i;
+            do {
+                if (t[i] == '"') { std::string_view dummy; if (!string(dummy)) return false; continue; }
+                if (t[i] == '{' || t[i] == '[') ++depth;
+                if (t[i] == '}' || t[i] == ']') --depth;
+                ++i;
+            } while (i < t.size() && depth > 0);
+            out = t.substr(a, i - a);
+            return depth == 0;
+        }
+        size_t a = i;
+        while (i < t.size() && t[i] != ',' && t[i] != '}' && t[i] != ']' && t[i] != ' ' && t[i] != '\n' && t[i] != '\r' && t[i] != '\t') ++i;
+        out = t.substr(a, i - a);
+        return !out.empty();
+    }
+};
+
+int days_before_month(int year, int month)
+{
+    static const int cum[12] = {0, 31, 59, 90, 120, 151, 181, 212, 243, 273, 304, 334};
+    const bool leap = (year % 4 == 0 && year % 100 != 0) || year % 400 == 0;
+    return cum[month - 1] + ((leap && month > 2) ? 1 : 0);
+}
+
+// "YYYY-MM-DDThh:mm:ss[.ffffff][Z]" -> two-digit year, fractional day of year, JD (Tle.zig L198-238)
+int parse_iso_epoch(std::string_view e, TleRecord &r)
+{
+    if (e.size() < 19) return -1;
+    long year, month, day, hour, minute;
+    double sec;
+    if (!to_long(e.substr(0, 4), year) || !to_long(e.substr(5, 2), month) || !to_long(e.substr(8, 2), day) ||
+        !to_long(e.substr(11, 2), hour) || !to_long(e.substr(14, 2), minute))
+        return -1;
+    std::string_view s = e.substr(17);
+    if (!s.empty() && s.back() == 'Z') s.remove_suffix(1);
+    if (!to_double(s, sec) || month < 1 || month > 12) return -1;
+    const double doy = double(days_before_month(int(year), int(month)) + day) +
+                       (double(hour) + (double(minute) + sec / 60.0) / 60.0) / 24.0;
+    r.epoch_year = int(year % 100);
+    r.epoch_day = doy;
+    r.epoch_jd = year_doy_to_jd(int(year), doy);
+    return 0;
+}
+
+int parse_omm_object(JsonCursor &c, TleRecord &r)
+{
+    if (!c.eat('{')) return -999;
+    r = TleRecord{};
+    enum { K_EPOCH = 1, K_MM = 2, K_ECC = 4, K_INC = 8, K_RAAN = 16, K_ARGP = 32, K_MA = 64, K_ID = 128, K_BSTAR = 256 };
+    unsigned seen = 0;
+    int rc = 0;
+    if (!c.peek('}')) {
+        do {
+            std::string_view key, val;
+            bool is_str = false;
+            if (!c.string(key) || !c.eat(':') || !c.value(val, is_str)) return -999;
+            const bool null = !is_str && val == "null";
+            double d = 0.0;
+            const bool num = !is_str && !null && to_double(val, d);
+            auto want = [&](double &dst, unsigned bit) { if (!num) rc = -999; else { dst = d; seen |= bit; } };
+            if (key == "EPOCH") { if (!is_str) rc = -999; else { int e = parse_iso_epoch(val, r); if (e) rc = e; seen |= K_EPOCH; } }
+            else if (key == "MEAN_MOTION") want(r.mm_revday, K_MM);
+            else if (key == "ECCENTRICITY") want(r.ecc, K_ECC);
+            else if (key == "INCLINATION") want(r.incl_deg, K_INC);
+            else if (key == "RA_OF_ASC_NODE") want(r.raan_deg, K_RAAN);
+            else if (key == "ARG_OF_PERICENTER") want(r.argp_deg, K_ARGP);
+            else if (key == "MEAN_ANOMALY") want(r.ma_deg, K_MA);
+            else if (key == "BSTAR") want(r.bstar, K_BSTAR);
+            else if (key == "NORAD_CAT_ID") { if (!num) rc = -999; else { r.satnum = uint32_t(d); seen |= K_ID; } }
+            else if (key == "MEAN_MOTION_DOT") { if (num) r.ndot = d; }
+            else if (key == "ELEMENT_SET_NO") { if (num) r.elnum = uint32_t(d); }
+            else if (key == "REV_AT_EPOCH") { if (num) r.revnum = uint32_t(d); }
+            else if (key == "CLASSIFICATION_TYPE") { if (is_str && !val.empty()) r.classification = val[0]; }
+        } while (c.eat(','));
+    }
+    if (!c.eat('}')) return -999;
+    if (rc != 0) return rc;
+    const unsigned all = K_EPOCH | K_MM | K_ECC | K_INC | K_RAAN | K_ARGP | K_MA | K_ID | K_BSTAR;
+    return (seen & all) == all ? 0 : -999;
+}
+
+} // namespace
+
+int parse_omm_json(std::string_view text, std::vector<TleRecord> &out)
+{
+    JsonCursor c{text};
+    TleRecord r;
+    if (c.peek('{')) {
+        int rc = parse_omm_object(c, r);
+        if (rc == 0) out.push_back(r);
+        return rc;
+    }
+    if (!c.eat('[')) return -999;
+    if (c.eat(']')) return 0;
+    do {
+        int rc = parse_omm_object(c, r);
+        if (rc != 0) return rc;
+        out.push_back(r);
+    } while (c.eat(','));
+    return c.eat(']') ? 0 : -999;
+}
+
 } // namespace azh

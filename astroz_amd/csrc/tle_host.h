@@ -32,4 +32,11 @@ void parse_all(std::string_view text, std::vector<TleRecord> &out);
 
 double year_doy_to_jd(int full_year, double doy);
 
+// OMM (CCSDS Orbit Mean-elements Message) in its JSON form, one object or an array of objects, as
+// CelesTrak serves it: Tle.parseOmm / parseOmmArray (src/Tle.zig L134-238).  Elements keep their full
+// JSON precision (no detour through 69-column text); unknown keys are ignored, the optional keys default
+// as in the reference's OmmRecord (L164-182).  Returns 0, -1 (EPOCH shorter than 19 characters /
+// malformed record) or -999 (not JSON of that shape, missing mandatory key).
+int parse_omm_json(std::string_view text, std::vector<TleRecord> &out);
+
 } // namespace azh

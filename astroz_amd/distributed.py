@@ -1,16 +1,29 @@
-"""Multi-GPU: one process per GPU, satellites sharded across ranks.
+"""Multi-GPU: one process per GPU, satellites sharded across ranks (BASELINE config 4).
 
-The path shards embarrassingly -- every (satellite, time) result is independent for SGP4, and the
-only dependency of SDP4 runs along time inside one satellite -- so there is NO data-path
-collective: each rank owns a contiguous range of the catalog, builds its own device-resident
-element table and writes its own block of the result.  The reference has no distributed layer
-at all (single process, std.Thread: src/Constellation.zig L327-385).
+The path shards embarrassingly -- every (satellite, time) result is independent for SGP4, and the only
+dependency of SDP4 runs along time inside one satellite -- so the propagation itself needs no collective:
+each rank owns part of the catalog, builds its own device-resident element table and writes its own
+block of the result.  The reference has no distributed layer at all (single process, std.Thread:
+src/Constellation.zig L327-385).
 
-The one optional exchange is re-assembling the full ``(n_sats, n_times, 3)`` array on every rank
-(``gather_sat_major``): a single RCCL all-gather over xGMI of blocks that are contiguous in a
-satellite-major layout.  Payload at 13,478 x 1,440 fp64 pos+vel is 931.6 MB per rank in total
-(116.4 MB contributed per rank at 8 GPUs), ~5 ms on a ring -- 10x the kernel -- so consumers that
-can work on their own shard (conjunction screening, ground-track products) should skip it.
+The one exchange is re-assembling the full ``(n_sats, n_times, 3)`` array on every rank: RCCL
+all-gathers over xGMI (``torch.distributed`` backend "nccl" on ROCm).  Two things shape it:
+
+* **Block-cyclic ownership** (:class:`ShardPlan`).  The catalog is cut into ``n_chunks`` super-blocks of
+  ``world * rows`` consecutive satellites; inside every super-block rank r owns rows
+  ``[r*rows, (r+1)*rows)``.  A rank's shard is then ``n_chunks`` runs of consecutive satellites, and the
+  all-gather of chunk c lands in ``out[c*world*rows : (c+1)*world*rows]`` -- contiguous, already in
+  catalog order, no repacking pass.  Because every super-block is spread over all ranks, a catalog
+  that is sorted by orbit regime (all deep-space members at the end: 2-3x the cost per propagation)
+  still loads every rank evenly, which plain contiguous ranges do not.
+* **Chunk pipeline** (:class:`ShardedPropagator`).  Chunk c+1 is computed
+  (``azh_propagate_device_window``) while chunk c is in flight on the communication stream.
+
+Cost model: the gather moves ``(world-1)/world`` of the 931.6 MB result into every GPU; an
+MI355X ingests at most 7 x ~75 GB/s over xGMI, so t_allgather >= 1.6 ms at 8 GPUs (>= 6 ms at 2, one
+link) against 0.26 ms to compute the WHOLE result on one GPU.  Consumers that can work on their own shard
+(conjunction screening, ground tracks) should skip the gather; consumers that need everything everywhere
+are better served by every GPU propagating the full catalog (``replicate=True`` below) -- no bytes move at all.
 """
 import os
 
@@ -19,6 +32,8 @@ import numpy as np
 SHARD_ALIGN = 64  # one wave of satellites
 
 
+# ----------------------------------------------------------------------------------------------
+# contiguous ranges (kept for callers that want plain [lo, hi) shards and no gather pipeline)
 def shard_bounds(n_sats, world_size, rank, align=SHARD_ALIGN):
     """Contiguous [lo, hi) of the catalog owned by `rank`: ceil(n/world) rounded up to `align`
     satellites per rank, last ranks possibly short or empty."""
@@ -40,13 +55,59 @@ def env_rank():
             int(os.environ.get("LOCAL_RANK", "0")))
 
 
+# ----------------------------------------------------------------------------------------------
+class ShardPlan:
+    """Block-cyclic assignment of `n_sats` catalog rows to `world` ranks in `n_chunks` super-blocks.
+
+    rows   : satellites per (chunk, rank) cell, a multiple of `align`
+    padded : n_chunks * world * rows >= n_sats -- the row count of the gathered buffer; rows
+             ``[n_sats, padded)`` are padding
+    catalog row g  ->  chunk g // (world*rows), rank (g % (world*rows)) // rows, slot g % rows
+    A rank's members, in ascending catalog order, fill its local block chunk after chunk: full cells
+    first, then at most one partial cell, then empty ones -- so local index l = chunk*rows + slot always.
+    """
+
+    def __init__(self, n_sats, world, n_chunks=1, align=SHARD_ALIGN):
+        if n_sats < 0 or world < 1 or n_chunks < 1:
+            raise ValueError("bad shard plan arguments")
+        self.n_sats, self.world = int(n_sats), int(world)
+        cells = self.world * int(n_chunks)
+        rows = -(-max(self.n_sats, 1) // cells)
+        self.rows = -(-rows // align) * align
+        # no point in chunks that are entirely padding
+        self.n_chunks = max(1, min(int(n_chunks), -(-max(self.n_sats, 1) // (self.world * self.rows))))
+        self.padded = self.n_chunks * self.world * self.rows
+
+    def cell(self, chunk, rank):
+        """[lo, hi) catalog rows of (chunk, rank), clipped to the catalog."""
+        lo = (chunk * self.world + rank) * self.rows
+        return min(lo, self.n_sats), min(lo + self.rows, self.n_sats)
+
+    def local_rows(self, rank):
+        """catalog indices owned by `rank`, ascending (== local order)."""
+        parts = [np.arange(*self.cell(c, rank), dtype=np.int64) for c in range(self.n_chunks)]
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
+
+    def n_local(self, rank):
+        return sum(hi - lo for lo, hi in (self.cell(c, rank) for c in range(self.n_chunks)))
+
+    def chunk_window(self, chunk, rank):
+        """[lo, hi) LOCAL rows of `rank` that belong to `chunk`."""
+        lo, hi = self.cell(chunk, rank)
+        return chunk * self.rows, chunk * self.rows + (hi - lo)
+
+    def local_capacity(self):
+        """rows of a rank's local block buffer (cells are padded to `rows`)."""
+        return self.n_chunks * self.rows
+
+
 class ShardedConstellation:
-    """The rank's slice of a TLE catalog on the rank's GPU.
+    """The rank's block-cyclic shard of a TLE catalog on the rank's GPU.
 
-    `pairs` is the FULL catalog (every rank passes the same list); only the rank's contiguous
-    range is parsed, uploaded and initialised."""
+    `pairs` is the FULL catalog (every rank passes the same list); only the rank's members are
+    parsed, uploaded and initialised."""
 
-    def __init__(self, pairs, grav=1, rank=None, world_size=None, local_rank=None):
+    def __init__(self, pairs, grav=1, rank=None, world_size=None, local_rank=None, n_chunks=1):
         from . import _native
 
         r, w, lr = env_rank()
@@ -54,23 +115,106 @@ class ShardedConstellation:
         self.world_size = w if world_size is None else world_size
         self.local_rank = lr if local_rank is None else local_rank
         self.n_total = len(pairs)
-        self.lo, self.hi = shard_bounds(self.n_total, self.world_size, self.rank)
+        self.plan = ShardPlan(self.n_total, self.world_size, n_chunks)
+        self.rows = self.plan.local_rows(self.rank)
         self.dev = None
-        if self.hi > self.lo:
-            self.dev = _native.DeviceConstellation.from_tle_lines(pairs[self.lo:self.hi], grav, self.local_rank)
+        if len(self.rows):
+            self.dev = _native.DeviceConstellation.from_tle_lines([pairs[i] for i in self.rows], grav, self.local_rank)
 
     @property
     def n_local(self):
-        return self.hi - self.lo
+        return len(self.rows)
 
 
+class ShardedPropagator:
+    """Config 4: every rank propagates its shard and all ranks end up with the full satellite-major
+    ``(n_sats, n_times, 3)`` arrays, chunk-pipelined (compute of chunk c+1 overlaps the gather of chunk c).
+
+    `dev` is anything with ``propagate_device_window(row_lo, row_hi, d_pos, d_vel, layout=, stream=)``
+    writing rows [row_lo, row_hi) of satellite-major local blocks -- a
+    :class:`astroz_amd._native.DeviceConstellation` whose inputs have been staged by one
+    ``propagate_device`` call, or a stand-in in the CPU tests.  Works on CUDA tensors (backend nccl =
+    RCCL) and on CPU tensors (gloo; no streams, chunks run back to back)."""
+
+    def __init__(self, dev, plan, rank, n_times, velocities=True, device=None, dtype=None, group=None):
+        import torch
+
+        self.torch = torch
+        self.dev, self.plan, self.rank, self.n_times = dev, plan, int(rank), int(n_times)
+        self.group = group
+        self.device = torch.device("cpu") if device is None else device
+        self.cuda = self.device.type == "cuda"
+        dtype = torch.float64 if dtype is None else dtype
+        n_arr = 2 if velocities else 1
+        cap = plan.local_capacity()
+        # local blocks (what the kernels write) and the gathered, catalog-ordered result
+        self.local = [torch.zeros((cap, n_times, 3), dtype=dtype, device=self.device) for _ in range(n_arr)]
+        self.full = [torch.empty((plan.padded, n_times, 3), dtype=dtype, device=self.device) for _ in range(n_arr)]
+        if self.cuda:
+            self.compute = torch.cuda.Stream(device=self.device)
+            self.comm = torch.cuda.Stream(device=self.device)
+            self.ev_chunk = [torch.cuda.Event() for _ in range(plan.n_chunks)]
+
+    # -- pieces ---------------------------------------------------------------------------------
+    def _launch_chunk(self, c):
+        lo, hi = self.plan.chunk_window(c, self.rank)
+        if hi <= lo or self.dev is None:
+            return
+        p = self.local[0].data_ptr()
+        v = self.local[1].data_ptr() if len(self.local) > 1 else None
+        stream = self.compute.cuda_stream if self.cuda else None
+        self.dev.propagate_device_window(lo, hi, p, v, layout=0, stream=stream)
+
+    def _gather_chunk(self, c):
+        import torch.distributed as dist
+
+        rows, w = self.plan.rows, self.plan.world
+        for loc, full in zip(self.local, self.full):
+            dist.all_gather_into_tensor(full[c * w * rows:(c + 1) * w * rows], loc[c * rows:(c + 1) * rows],
+                                        group=self.group)
+
+    # -- one step --------------------------------------------------------------------------------
+    def step(self, gather=True):
+        """Propagate the shard (all chunks) and, if `gather`, all-gather every chunk.  Asynchronous on
+        CUDA: call :meth:`wait` (or synchronize) before reading ``results()``."""
+        torch = self.torch
+        if self.cuda:
+            # the next step's kernels must not overwrite local blocks the previous gathers still read
+            self.compute.wait_stream(self.comm)
+        for c in range(self.plan.n_chunks):
+            self._launch_chunk(c)
+            if not gather:
+                continue
+            if self.cuda:
+                self.ev_chunk[c].record(self.compute)
+                self.comm.wait_event(self.ev_chunk[c])
+                with torch.cuda.stream(self.comm):
+                    self._gather_chunk(c)
+            else:
+                self._gather_chunk(c)
+
+    def wait(self):
+        if self.cuda:
+            self.torch.cuda.current_stream(self.device).wait_stream(self.comm)
+            self.torch.cuda.current_stream(self.device).wait_stream(self.compute)
+
+    def results(self):
+        """Catalog-ordered views ``(n_sats, n_times, 3)`` of the gathered arrays (pos[, vel])."""
+        return [f[: self.plan.n_sats] for f in self.full]
+
+    def local_results(self):
+        """(catalog rows of this rank, local blocks trimmed to them)."""
+        rows = self.plan.local_rows(self.rank)
+        return rows, [l[: len(rows)] for l in self.local]
+
+
+# ----------------------------------------------------------------------------------------------
+# one-shot gathers of contiguous-range shards (shard_bounds), kept for API users
 def gather_sat_major(local_block, n_total, world_size=None, group=None):
-    """All-gather satellite-major blocks ``(n_local, n_times, 3)`` into ``(n_total, n_times, 3)``.
-
-    Works for CPU tensors (gloo) and GPU tensors (nccl = RCCL).  Ranks may own different numbers
-    of satellites (the tail ranks are short), so blocks are padded to the common shard size for
-    the collective and trimmed afterwards; with equal shards this is a single
-    all_gather_into_tensor straight into the output."""
+    """All-gather satellite-major blocks ``(n_local, n_times, 3)`` of `shard_bounds` shards into
+    ``(n_total, n_times, 3)``.  Works for CPU tensors (gloo) and GPU tensors (nccl = RCCL).  The
+    blocks are padded to the common shard size for the collective; only the last ranks are short, so
+    the gathered buffer trimmed to `n_total` rows is already the catalog-ordered result."""
     import torch
     import torch.distributed as dist
 
@@ -78,16 +222,13 @@ def gather_sat_major(local_block, n_total, world_size=None, group=None):
     sizes = shard_sizes(n_total, world)
     per = max(sizes)
     n_times = local_block.shape[1]
-    if all(s == per for s in sizes):
-        out = torch.empty((world * per, n_times, 3), dtype=local_block.dtype, device=local_block.device)
-        dist.all_gather_into_tensor(out, local_block.contiguous(), group=group)
-        return out
-    padded = torch.zeros((per, n_times, 3), dtype=local_block.dtype, device=local_block.device)
-    padded[: local_block.shape[0]] = local_block
+    block = local_block.contiguous()
+    if block.shape[0] != per:
+        block = torch.zeros((per, n_times, 3), dtype=local_block.dtype, device=local_block.device)
+        block[: local_block.shape[0]] = local_block
     flat = torch.empty((world * per, n_times, 3), dtype=local_block.dtype, device=local_block.device)
-    dist.all_gather_into_tensor(flat, padded, group=group)
-    buf = flat.view(world, per, n_times, 3)
-    return torch.cat([buf[r, : sizes[r]] for r in range(world)], dim=0)
+    dist.all_gather_into_tensor(flat, block, group=group)
+    return flat[:n_total]
 
 
 def gather_time_major(local_block, n_total, world_size=None, group=None):

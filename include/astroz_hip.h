@@ -80,6 +80,15 @@ int32_t sgp4_propagate(void *handle, double tsince_min, double pos[3], double ve
 /* results: count x [x,y,z,vx,vy,vz].  One kernel launch, lane = time. */
 int32_t sgp4_propagate_batch(void *handle, const double *times_min, double *results, uint32_t count);
 
+/* root.zig L73-81 / src/c_api/coordinates.zig: the output-mode math of this path (WorldCoordinateSystem.zig
+ * L87-154) as scalar calls.  gmst in radians; lla = (lat deg, lon deg, alt km), degrees like the reference's
+ * ecefToGeodeticDeg.  Each call is one tiny launch on device 0 (the same device functions as the kernels'
+ * ECEF / geodetic epilogue); without a device the outputs are NaN.  orbital_* (root.zig L60-71: Hohmann,
+ * vis-viva helpers) are not on the propagation path and are not exported. */
+double coords_julian_to_gmst(double jd);
+void coords_eci_to_ecef(const double eci[3], double gmst, double ecef[3]);
+void coords_ecef_to_geodetic(const double ecef[3], double lla[3]);
+
 /* =====================================================================================
  * (B) constellation boundary
  * ===================================================================================== */
@@ -109,6 +118,11 @@ const char *azh_last_error(void);
  */
 int32_t azh_constellation_from_tle_text(const char *text, size_t len, int32_t grav, int32_t device,
                                         azh_constellation **out);
+/* OMM JSON (one object or an array, CelesTrak's FORMAT=JSON): Tle.parseOmm / parseOmmArray
+ * (src/Tle.zig L134-238).  Elements keep their full JSON precision.  AZ_ERR_BAD_TLE_LENGTH for an EPOCH
+ * shorter than 19 characters or an empty array, AZ_ERR_VALUE for anything that is not OMM JSON. */
+int32_t azh_constellation_from_omm_json(const char *text, size_t len, int32_t grav, int32_t device,
+                                        azh_constellation **out);
 /* n pairs of NUL-terminated lines */
 int32_t azh_constellation_from_tle_lines(const char *const *line1, const char *const *line2, size_t n,
                                          int32_t grav, int32_t device, azh_constellation **out);
@@ -119,6 +133,11 @@ int32_t azh_constellation_from_elements(size_t n, const double *epoch_jd, const 
                                         const double *argp_deg, const double *mean_anom_deg,
                                         const double *bstar, int32_t grav, int32_t device,
                                         azh_constellation **out);
+/* a new constellation holding members indices[0..n) of an existing one, in that order, on `device`
+ * (-1 = the same device): the shard of a multi-GPU job, or the reference's near-earth-first ordering
+ * (bindings/python/astroz/__init__.py L374-393) without re-parsing any text */
+int32_t azh_constellation_subset(const azh_constellation *c, const uint32_t *indices, size_t n, int32_t device,
+                                 azh_constellation **out);
 void azh_constellation_free(azh_constellation *c);
 
 size_t azh_num_satellites(const azh_constellation *c);
@@ -162,6 +181,11 @@ int32_t azh_propagate_device(azh_constellation *c, const double *times_min /*hos
  * the steady-state form used when the same grid is propagated repeatedly */
 int32_t azh_propagate_device_cached(azh_constellation *c, double *d_pos, double *d_vel, int32_t layout,
                                     size_t out_stride_sats, uint8_t *d_err, void *stream);
+/* the cached launch restricted to the satellites row_lo <= index < row_hi (other rows are left untouched):
+ * lets a multi-GPU host pipeline its shard in chunks -- chunk k+1 is computed while chunk k is in the
+ * all-gather (astroz_amd/distributed.py).  No reference counterpart (single process). */
+int32_t azh_propagate_device_window(azh_constellation *c, size_t row_lo, size_t row_hi, double *d_pos, double *d_vel,
+                                    int32_t layout, size_t out_stride_sats, uint8_t *d_err, void *stream);
 /* fp32 OUTPUT variants (BASELINE config 5: 1M satellites x 10,000 steps would be 480 GB in fp64):
  * identical fp64 arithmetic, every component rounded once when it is stored; d_pos/d_vel are
  * float arrays of the same shapes.  No reference counterpart (astroz is fp64 only). */
@@ -220,6 +244,16 @@ int32_t azh_synchronize(azh_constellation *c);
  * pos/vel: n x 3 each (host); err: n bytes (optional). */
 int32_t azh_propagate_one_host(azh_constellation *c, size_t sat_index, const double *tsince_min, size_t n,
                                double *pos, double *vel, uint8_t *err);
+
+/* the same with device pointers (tsince, pos, vel, err all in HBM; asynchronous on `stream`, NULL = the
+ * constellation's own): the kernel rate without the PCIe copies */
+int32_t azh_propagate_one_device(azh_constellation *c, size_t sat_index, const double *d_tsince_min, size_t n,
+                                 double *d_pos, double *d_vel, uint8_t *d_err, void *stream);
+/* known-answer hook for the kernels' element math ON THE DEVICE (devmath.h: az_sincos, az_rcp, az_rsqrt,
+ * az_rotate; the reference's KATs are src/simdMath.zig L214-286).  x: n host values; out6n (host):
+ * [0,n) sin x, [n,2n) cos x, [2n,3n) x*rcp(x), [3n,4n) |x|*rsqrt(|x|)^2, [4n,6n) (sin,cos)(0.7321 + x) obtained
+ * by rotating (sin,cos)(0.7321).  Test infrastructure; not part of the reference surface. */
+int32_t azh_selftest_math(const double *x, size_t n, double *out6n, int32_t device);
 
 /* tuning knobs (kernel time-tile length; 0 = automatic).  Not part of the reference surface. */
 int32_t azh_set_time_tile(azh_constellation *c, uint32_t sgp4_tile, uint32_t sdp4_tile);
