@@ -1,134 +1,54 @@
 """astroz_amd -- MI355X-native batched SGP4/SDP4 constellation propagation.
 
-Drop-in for the batched-propagation path of ATTron/astroz's Python package
-(bindings/python/astroz/__init__.py L305-532): :class:`Constellation` and :func:`propagate`
-with the same arguments, shapes and defaults; the python-sgp4 compatible layer is
-:mod:`astroz_amd.api`.  All arithmetic runs in hand-written gfx950 HIP kernels behind
-``libastroz_hip.so`` (C ABI in ``include/astroz_hip.h``); there is no CPU fallback.
+Drop-in for the batched-propagation path of ATTron/astroz's Python package: :class:`Constellation`,
+:func:`propagate`, :func:`screen` (bindings/python/astroz/__init__.py L305-658) and the extension type
+:class:`Sgp4Constellation` (bindings/python/astroz/_astroz.pyi L501-630) with the same arguments, shapes and
+defaults; the python-sgp4 compatible layer is :mod:`astroz_amd.api`.  All arithmetic runs in hand-written
+gfx950 HIP kernels behind ``libastroz_hip.so`` (C ABI in ``include/astroz_hip.h``); there is no CPU fallback.
+
+Element text goes to the library as it is: TLE text is read by the library's fixed-column reader, OMM JSON by
+its OMM reader (full JSON precision; the reference's Python layer re-renders OMM as 69-column text first and
+loses digits there).  This package never opens a network connection: ``source`` is text or a local path
+(the reference also resolves CelesTrak group names and URLs -- fetch the text yourself and pass it in).
 """
-import json
-import math
+import os
 from datetime import datetime, timezone
-from pathlib import Path
 
 import numpy as np
 
 from . import _native
 from ._native import WGS72, WGS84  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
-_CELESTRAK_ALIASES = {"all": "active", "iss": "stations", "gps": "gps-ops", "glonass": "glo-ops"}
-DAY_SECONDS = 86400.0
-
-
-def _fetch_url(url):
-    import urllib.request
-
-    req = urllib.request.Request(url, headers={"User-Agent": "astroz"})
-    return urllib.request.urlopen(req, timeout=60).read().decode("utf-8")
+_UNIX_EPOCH_JD = 2440587.5
 
 
-def _celestrak_url(group=None, norad_id=None, fmt="tle"):
-    if norad_id is not None:
-        ids = ",".join(str(i) for i in norad_id) if isinstance(norad_id, (list, tuple)) else str(norad_id)
-        return "https://celestrak.org/NORAD/elements/gp.php?CATNR=%s&FORMAT=%s" % (ids, fmt.upper())
-    name = _CELESTRAK_ALIASES.get(group.lower(), group)
-    return "https://celestrak.org/NORAD/elements/gp.php?GROUP=%s&FORMAT=%s" % (name, fmt.upper())
+def _as_text(source):
+    """The element text behind `source`: the string itself when it already is element data, else the
+    contents of the local file it names."""
+    if not isinstance(source, str):
+        raise TypeError("source must be a string: TLE text, OMM JSON text, or a local file path")
+    head = source.lstrip()[:1]
+    if head in ("{", "["):
+        return source
+    if "\n" not in source and len(source) < 4096 and os.path.isfile(source):
+        with open(source, "r", encoding="utf-8") as fh:
+            return fh.read()
+    if any(ln.lstrip().startswith("1 ") for ln in source.splitlines()):
+        return source
+    raise ValueError("source is neither TLE text, OMM JSON, nor an existing local file "
+                     "(astroz_amd does not fetch CelesTrak groups or URLs)")
 
 
-def _sniff(text):
-    return "json" if text.lstrip().startswith(("[", "{")) else "tle"
+def _is_json(text):
+    return text.lstrip()[:1] in ("{", "[")
 
 
-def _load_tle_text(source, norad_id=None):
-    """(text, 'tle'|'json') from a group name, URL, path, raw TLE text or raw OMM JSON
-    (reference __init__.py L163-181)."""
-    if norad_id is not None:
-        return _fetch_url(_celestrak_url(norad_id=norad_id)), "tle"
-    if source is None:
-        raise ValueError("Must specify 'source' or 'norad_id'")
-    if source.startswith(("http://", "https://")):
-        text = _fetch_url(source)
-        return text, _sniff(text)
-    if "1 " in source and "2 " in source:
-        return source, "tle"
-    if source.lstrip().startswith(("[", "{")):
-        return source, "json"
-    if len(source) < 4096 and Path(source).exists():
-        text = Path(source).read_text()
-        return text, _sniff(text)
-    return _fetch_url(_celestrak_url(group=source)), "tle"
-
-
-def _parse_tle_pairs(tle_text):
-    """[(line1, line2)] from 2- or 3-line TLE text (reference __init__.py L184-200)."""
-    lines = [ln.strip() for ln in tle_text.strip().splitlines() if ln.strip()]
-    pairs, i = [], 0
-    while i < len(lines):
-        if lines[i].startswith("1 ") and i + 1 < len(lines) and lines[i + 1].startswith("2 "):
-            pairs.append((lines[i], lines[i + 1]))
-            i += 2
-        else:
-            i += 1
-    return pairs
-
-
-def _tle_checksum(line68):
-    return sum(int(c) if c.isdigit() else (1 if c == "-" else 0) for c in line68) % 10
-
-
-def _exp_field(val):
-    if val == 0:
-        return " 00000+0"
-    av = abs(val)
-    exp = math.floor(math.log10(av)) + 1
-    mant = round(av * 10 ** (5 - exp))
-    return "%s%05d%+d" % ("-" if val < 0 else " ", int(mant), exp)
-
-
-def _omm_to_tle_pairs(json_text):
-    """OMM JSON (object or array) -> [(line1, line2)] (reference __init__.py L203-279)."""
-    data = json.loads(json_text)
-    if isinstance(data, dict):
-        data = [data]
-    pairs = []
-    for rec in data:
-        norad = rec["NORAD_CAT_ID"]
-        cls = (rec.get("CLASSIFICATION_TYPE", "U") or "U")[0]
-        intl = rec.get("OBJECT_ID", "00000A") or "00000A"
-        ndot = rec.get("MEAN_MOTION_DOT", 0) or 0
-        nddot = rec.get("MEAN_MOTION_DDOT", 0) or 0
-        etype = rec.get("EPHEMERIS_TYPE", 0) or 0
-        elset = rec.get("ELEMENT_SET_NO", 0) or 0
-        revnum = rec.get("REV_AT_EPOCH", 0) or 0
-        dt = datetime.fromisoformat(rec["EPOCH"]).replace(tzinfo=None)
-        doy = (dt - datetime(dt.year, 1, 1)).total_seconds() / DAY_SECONDS + 1.0
-        if "-" in intl:
-            yr, rest = intl.split("-", 1)
-            intl_tle = "%s%-6s" % (yr[-2:], rest)
-        else:
-            intl_tle = "%-8s" % intl
-        ndot_s = ("-" if ndot < 0 else " ") + ("%.8f" % abs(ndot))[1:]
-        l1 = "1 %05d%s %s %02d%012.8f %s %s %s %s %4d" % (
-            norad, cls, intl_tle, dt.year % 100, doy, ndot_s, _exp_field(nddot), _exp_field(rec["BSTAR"]),
-            etype, elset)
-        l1 = l1[:68].ljust(68)
-        l1 += str(_tle_checksum(l1))
-        l2 = "2 %05d %8.4f %8.4f %s %8.4f %8.4f %11.8f%5d" % (
-            norad, rec["INCLINATION"], rec["RA_OF_ASC_NODE"], ("%.7f" % rec["ECCENTRICITY"])[2:],
-            rec["ARG_OF_PERICENTER"], rec["MEAN_ANOMALY"], rec["MEAN_MOTION"], revnum)
-        l2 = l2[:68].ljust(68)
-        l2 += str(_tle_checksum(l2))
-        pairs.append((l1, l2))
-    return pairs
-
-
-def _start_jd(start_time):
-    """datetime -> Julian date, default now (reference __init__.py L282-286)."""
-    if start_time is None:
-        start_time = datetime.now(timezone.utc)
-    return 2440587.5 + (start_time.timestamp() / 86400.0)
+def _jd_of(start_time):
+    """Julian date of a datetime; None means now (UTC)."""
+    when = datetime.now(timezone.utc) if start_time is None else start_time
+    return _UNIX_EPOCH_JD + when.timestamp() / 86400.0
 
 
 class Tle:
@@ -158,36 +78,86 @@ class Tle:
     mean_motion = property(lambda self: float(_native.lib().tle_get_mean_motion(self._h)), doc="Mean motion (rev/day)")
 
 
-class Constellation:
-    """Pre-parsed, device-resident orbital elements for repeated propagation.
+class Sgp4Constellation:
+    """``_astroz.Sgp4Constellation`` (bindings/python/astroz/_astroz.pyi L501-630): the extension type behind the
+    reference's high-level functions, same method names and keywords, device-resident elements.
 
-    ``source``: CelesTrak group name, URL, file path, raw TLE text or raw OMM JSON;
-    ``norad_id``: catalog id(s) to fetch.  Output ordering follows the reference: near-earth
-    satellites first ``[0, n_sgp4)``, deep-space after (reference __init__.py L374-393) -- but the
-    deep-space rows ARE propagated here (the reference leaves them unwritten, L509-530).
-    The gravity model is WGS84, the default of the reference's ``from_tle_text``
-    (bindings/python/src/sgp4.zig L293-300)."""
+    Differences that are deliberate: deep-space members are accepted and propagated (the reference's type
+    rejects them); ``satellite_mask`` may be bool or uint8."""
+
+    def __init__(self, dev):
+        self._dev = dev
+
+    @staticmethod
+    def from_tle_text(tle_text, gravity_model=WGS84, device=0):
+        """WGS84 is the reference's default for this constructor (bindings/python/src/sgp4.zig L293-300)."""
+        return Sgp4Constellation(_native.DeviceConstellation.from_tle_text(tle_text, gravity_model, device))
+
+    @staticmethod
+    def from_omm_json(json_text, gravity_model=WGS84, device=0):
+        return Sgp4Constellation(_native.DeviceConstellation.from_omm_json(json_text, gravity_model, device))
+
+    @property
+    def num_satellites(self):
+        return int(self._dev.n)
+
+    @property
+    def epochs(self):
+        return [float(x) for x in self._dev.epochs]
+
+    def propagate_into(self, times, positions, velocities=None, *, epoch_offsets=None, satellite_mask=None,
+                       output="ecef", reference_jd=0.0, time_major=True, output_stride=-1):
+        """Propagate into caller-owned arrays (sgp4.zig L170-262): ``(n_times, stride, 3)`` if `time_major`
+        else ``(n_sats, n_times, 3)``; ``output_stride`` > 0 overrides the row length of the time-major
+        layout; raises ValueError when an array is too small."""
+        if output not in _native.OUTPUT_MODES:
+            raise ValueError("output must be 'ecef', 'teme', or 'geodetic'")
+        mask = None if satellite_mask is None else np.ascontiguousarray(satellite_mask).astype(np.uint8)
+        self._dev.propagate_host(times, epoch_offsets, pos=positions, vel=velocities,
+                                 mode=_native.OUTPUT_MODES[output], reference_jd=float(reference_jd), mask=mask,
+                                 layout=_native.TIME_MAJOR if time_major else _native.SAT_MAJOR,
+                                 stride=int(output_stride) if output_stride and output_stride > 0 else 0)
+
+    def screen_conjunction(self, times, target, threshold, *, epoch_offsets=None, reference_jd=0.0):
+        """Fused propagate + single-target screen: ``(min_distances, min_t_indices)`` as lists."""
+        d, ti = self._dev.screen_target(times, int(target), float(threshold), epoch_offsets, reference_jd=reference_jd)
+        return [float(x) for x in d], [int(x) for x in ti]
+
+
+class Constellation:
+    """Pre-parsed, device-resident orbital elements for repeated propagation and screening.
+
+    ``source``: raw TLE text, raw OMM JSON (object or array), or a local file holding either.
+    Output ordering follows the reference: near-earth satellites first ``[0, n_sgp4)``, deep-space after
+    (reference __init__.py L374-393) -- but the deep-space rows ARE propagated here (the reference leaves them
+    unwritten, L509-530).  The gravity model is WGS84, the default of the reference's ``from_tle_text``."""
 
     def __init__(self, source=None, *, norad_id=None, gravity_model=WGS84, device=0):
-        text, fmt = _load_tle_text(source, norad_id)
-        pairs = _omm_to_tle_pairs(text) if fmt == "json" else _parse_tle_pairs(text)
-        if not pairs:
-            raise ValueError("no TLE records found")
-        dev = _native.DeviceConstellation.from_tle_lines(pairs, gravity_model, device)
-        err, deep, _ = dev.status
+        if norad_id is not None:
+            raise ValueError("norad_id lookups need a CelesTrak download: fetch the elements and pass the text")
+        if source is None:
+            raise ValueError("Must specify 'source'")
+        text = _as_text(source)
+        build = _native.DeviceConstellation.from_omm_json if _is_json(text) else _native.DeviceConstellation.from_tle_text
+        try:
+            full = build(text, gravity_model, device)
+        except _native.NativeError as exc:
+            if exc.code == _native.AZ_ERR_HIP:
+                raise
+            raise ValueError("no usable element sets found in source") from exc
+        err, deep, _ = full.status
         if err.any():
             bad = int(np.flatnonzero(err)[0])
             raise ValueError("%s (record %d)" % ("Invalid eccentricity" if err[bad] == 1 else "Satellite decayed", bad))
-        if deep.any() and not deep.all():
-            order = np.concatenate([np.flatnonzero(~deep), np.flatnonzero(deep)])
-            if not np.array_equal(order, np.arange(len(pairs))):
-                pairs = [pairs[i] for i in order]
-                dev.close()
-                dev = _native.DeviceConstellation.from_tle_lines(pairs, gravity_model, device)
-        self._dev = dev
-        self._pairs = pairs
-        self._total_sats = len(pairs)
-        self._n_sgp4 = int(dev.n_sgp4)
+        # catalog index of every output row: near-earth members first, deep-space members after
+        self._catalog_index = np.concatenate([np.flatnonzero(~deep), np.flatnonzero(deep)]).astype(np.uint32)
+        if np.array_equal(self._catalog_index, np.arange(full.n, dtype=np.uint32)):
+            self._dev = full
+        else:
+            self._dev = full.subset(self._catalog_index)  # device-side re-order: no second parse
+            full.close()
+        self._n_sgp4 = int((~deep).sum())
+        self._total_sats = int(self._dev.n)
 
     @property
     def num_satellites(self):
@@ -195,27 +165,35 @@ class Constellation:
 
     @property
     def epochs(self):
-        """TLE epoch of each satellite as a Julian date."""
-        return list(self._dev.epochs)
+        """TLE epoch of each satellite (output order) as a Julian date."""
+        return [float(x) for x in self._dev.epochs]
+
+    @property
+    def catalog_index(self):
+        """Position in the source text of every output row (near-earth first reorders mixed catalogs)."""
+        return self._catalog_index.copy()
+
+
+def _minutes_and_offsets(const, times, start_time):
+    minutes = np.ascontiguousarray(times, dtype=np.float64)
+    start = _jd_of(start_time)
+    return minutes, (start - const._dev.epochs) * 1440.0, start
 
 
 def propagate(source, times, *, start_time=None, output="ecef", velocities=False, norad_id=None):
-    """Propagate satellites to ``times`` (minutes from ``start_time``).
+    """Propagate satellites to ``times`` (minutes from ``start_time``, default now).
 
     Returns positions ``(n_times, n_satellites, 3)`` [km; or (lat rad, lon rad, alt km) for
-    ``output="geodetic"`` -- radians, as the reference's kernel emits (Constellation.zig L497)],
-    plus velocities ``(n_times, n_satellites, 3)`` km/s if ``velocities=True``.
-    Reference: __init__.py L411-532."""
+    ``output="geodetic"`` -- radians, as the reference's kernel emits (Constellation.zig L497)], plus
+    velocities ``(n_times, n_satellites, 3)`` km/s if ``velocities=True``.  Reference: __init__.py L411-532."""
     const = source if isinstance(source, Constellation) else Constellation(source, norad_id=norad_id)
     if output not in _native.OUTPUT_MODES:
         raise ValueError("output must be 'ecef', 'teme', or 'geodetic'")
-    times = np.ascontiguousarray(times, dtype=np.float64)
-    n_sats, n_times = const.num_satellites, len(times)
-    start = _start_jd(start_time)
-    pos = np.empty((n_times, n_sats, 3), dtype=np.float64)
-    vel = np.empty((n_times, n_sats, 3), dtype=np.float64) if velocities else None
-    offsets = (start - const._dev.epochs) * 1440.0
-    const._dev.propagate_host(times, offsets, pos=pos, vel=vel, mode=_native.OUTPUT_MODES[output],
+    minutes, offsets, start = _minutes_and_offsets(const, times, start_time)
+    shape = (len(minutes), const.num_satellites, 3)
+    pos = np.empty(shape, dtype=np.float64)
+    vel = np.empty(shape, dtype=np.float64) if velocities else None
+    const._dev.propagate_host(minutes, offsets, pos=pos, vel=vel, mode=_native.OUTPUT_MODES[output],
                               reference_jd=start, layout=_native.TIME_MAJOR)
     return (pos, vel) if velocities else pos
 
@@ -231,13 +209,10 @@ def screen(source, times, threshold=10.0, *, target=None, start_time=None, norad
     Deep-space members take part in both modes (the reference's fused routine covers pure-SGP4
     constellations only and falls back to propagate-then-screen otherwise, L655-658)."""
     const = source if isinstance(source, Constellation) else Constellation(source, norad_id=norad_id)
-    times = np.ascontiguousarray(times, dtype=np.float64)
-    start = _start_jd(start_time)
-    offsets = (start - const._dev.epochs) * 1440.0
+    minutes, offsets, start = _minutes_and_offsets(const, times, start_time)
     if target is not None:
-        d, ti = const._dev.screen_target(times, int(target), float(threshold), offsets, reference_jd=start)
-        return d, ti
-    return const._dev.screen_all(times, float(threshold), offsets)
+        return const._dev.screen_target(minutes, int(target), float(threshold), offsets, reference_jd=start)
+    return const._dev.screen_all(minutes, float(threshold), offsets)
 
 
 def coarse_screen(positions, num_sats, threshold, valid_mask=None):
@@ -253,4 +228,5 @@ def coarse_screen(positions, num_sats, threshold, valid_mask=None):
     return [tuple(int(x) for x in p) for p in pairs], [int(x) for x in tt]
 
 
-__all__ = ["__version__", "Tle", "Constellation", "propagate", "screen", "coarse_screen", "WGS72", "WGS84"]
+__all__ = ["__version__", "Tle", "Sgp4Constellation", "Constellation", "propagate", "screen", "coarse_screen",
+           "WGS72", "WGS84"]

@@ -32,7 +32,7 @@ EXPORTS = [
     "azh_last_kernel_ms", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
     "azh_screen_target_host", "azh_screen_target_device", "azh_coarse_screen_device", "azh_coarse_screen_host",
     "azh_screen_all_host", "azh_constellation_from_omm_json", "azh_propagate_one_device", "azh_selftest_math",
-    "coords_julian_to_gmst", "coords_eci_to_ecef", "coords_ecef_to_geodetic",
+    "azh_parse_tle_text", "azh_parse_omm_json", "coords_julian_to_gmst", "coords_eci_to_ecef", "coords_ecef_to_geodetic",
 ]
 
 
@@ -107,6 +107,9 @@ def lib():
     L.azh_parse_tle_lines.restype = i32
     L.azh_constellation_from_tle_text.argtypes = [C.c_char_p, sz, i32, i32, C.POINTER(vp)]
     L.azh_constellation_from_tle_text.restype = i32
+    for f in ("azh_parse_tle_text", "azh_parse_omm_json"):
+        getattr(L, f).argtypes = [C.c_char_p, sz, vp, sz, C.POINTER(sz)]
+        getattr(L, f).restype = i32
     L.azh_constellation_from_omm_json.argtypes = [C.c_char_p, sz, i32, i32, C.POINTER(vp)]
     L.azh_constellation_from_omm_json.restype = i32
     L.azh_propagate_one_device.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp]
@@ -395,6 +398,23 @@ def parse_tle_lines(line1, line2):
     rc = lib().azh_parse_tle_lines(line1.encode(), line2.encode(), out.ctypes.data)
     if rc != 0:
         raise ValueError("Failed to parse TLE lines")
+    return out
+
+
+def parse_element_text(text):
+    """(n, 16) array of the numeric fields of every element set in multi-TLE text or OMM JSON (object or
+    array).  Host-side text handling only; raises ValueError on malformed OMM."""
+    b = text.encode() if isinstance(text, str) else bytes(text)
+    fn = lib().azh_parse_omm_json if b.lstrip()[:1] in (b"{", b"[") else lib().azh_parse_tle_text
+    k = C.c_size_t(0)
+    rc = fn(b, len(b), None, 0, C.byref(k))
+    if rc != 0:
+        raise ValueError("malformed element text (code %d)" % rc)
+    out = np.zeros((k.value, 16), dtype=np.float64)
+    if k.value:
+        rc = fn(b, len(b), out.ctypes.data, k.value, C.byref(k))
+        if rc != 0:
+            raise ValueError("malformed element text (code %d)" % rc)
     return out
 
 

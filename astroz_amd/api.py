@@ -165,6 +165,7 @@ class SatrecArray:
             if not isinstance(s, Satrec):
                 raise TypeError("All items must be Satrec objects")
         self._num_sats = len(satrecs)
+        self._device = int(device)
         grav = satrecs[0].whichconst
         self._dev = _native.DeviceConstellation.from_tle_lines(
             [(s._line1, s._line2) for s in satrecs], grav, device)
@@ -217,11 +218,11 @@ class SatrecArray:
 
         times, offsets = self._grid(jd, fr)
         n_times, n_sats = len(times), self._num_sats
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device("cuda", self._device)  # the device the element table lives on
         r_tm = torch.empty((n_times, n_sats, 3), dtype=torch.float64, device=dev)
         v_tm = torch.empty((n_times, n_sats, 3), dtype=torch.float64, device=dev) if velocities else None
         e = torch.empty((n_sats, n_times), dtype=torch.uint8, device=dev)
-        torch.cuda.current_stream().synchronize()  # allocations visible before a foreign stream writes
+        torch.cuda.current_stream(dev).synchronize()  # allocations visible before a foreign stream writes
         self._dev.propagate_device(times, offsets, r_tm.data_ptr(), None if v_tm is None else v_tm.data_ptr(),
                                    layout=_native.TIME_MAJOR, d_err=e.data_ptr(), stream=stream)
         return e, r_tm, v_tm

@@ -640,6 +640,22 @@ int azh_device_count(void)
 
 const char *azh_last_error(void) { return g_last_error.c_str(); }
 
+namespace {
+void record_to_fields(const azh::TleRecord &r, double *o)
+{
+    o[0] = r.satnum; o[1] = r.epoch_year; o[2] = r.epoch_day; o[3] = r.epoch_jd; o[4] = r.ndot; o[5] = r.bstar;
+    o[6] = r.incl_deg; o[7] = r.raan_deg; o[8] = r.ecc; o[9] = r.argp_deg; o[10] = r.ma_deg; o[11] = r.mm_revday;
+    o[12] = r.elnum; o[13] = r.revnum; o[14] = (double)(unsigned char)r.classification; o[15] = 0.0;
+}
+int32_t records_out(const std::vector<azh::TleRecord> &recs, double *out16, size_t max_records, size_t *n_found)
+{
+    if (!n_found || (max_records && !out16)) return AZ_ERR_NULL_POINTER;
+    *n_found = recs.size();
+    for (size_t i = 0; i < recs.size() && i < max_records; ++i) record_to_fields(recs[i], out16 + 16 * i);
+    return AZ_OK;
+}
+} // namespace
+
 int32_t azh_parse_tle_lines(const char *line1, const char *line2, double *o)
 {
     if (!line1 || !line2 || !o) return AZ_ERR_NULL_POINTER;
@@ -647,10 +663,27 @@ int32_t azh_parse_tle_lines(const char *line1, const char *line2, double *o)
     int rc = azh::parse_lines(line1, line2, r);
     if (rc == -1) return AZ_ERR_BAD_TLE_LENGTH;
     if (rc != 0) return AZ_ERR_UNKNOWN;
-    o[0] = r.satnum; o[1] = r.epoch_year; o[2] = r.epoch_day; o[3] = r.epoch_jd; o[4] = r.ndot; o[5] = r.bstar;
-    o[6] = r.incl_deg; o[7] = r.raan_deg; o[8] = r.ecc; o[9] = r.argp_deg; o[10] = r.ma_deg; o[11] = r.mm_revday;
-    o[12] = r.elnum; o[13] = r.revnum; o[14] = (double)(unsigned char)r.classification; o[15] = 0.0;
+    record_to_fields(r, o);
     return AZ_OK;
+}
+
+
+int32_t azh_parse_tle_text(const char *text, size_t len, double *out16, size_t max_records, size_t *n_found)
+{
+    if (!text) return AZ_ERR_NULL_POINTER;
+    std::vector<azh::TleRecord> recs;
+    azh::parse_all(std::string_view(text, len), recs);
+    return records_out(recs, out16, max_records, n_found);
+}
+
+int32_t azh_parse_omm_json(const char *text, size_t len, double *out16, size_t max_records, size_t *n_found)
+{
+    if (!text) return AZ_ERR_NULL_POINTER;
+    std::vector<azh::TleRecord> recs;
+    const int rc = azh::parse_omm_json(std::string_view(text, len), recs);
+    if (rc == -1) return AZ_ERR_BAD_TLE_LENGTH;
+    if (rc != 0) return AZ_ERR_VALUE;
+    return records_out(recs, out16, max_records, n_found);
 }
 
 int32_t azh_constellation_from_tle_text(const char *text, size_t len, int32_t grav, int32_t device,

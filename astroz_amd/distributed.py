@@ -15,7 +15,9 @@ all-gathers over xGMI (``torch.distributed`` backend "nccl" on ROCm).  Two thing
   all-gather of chunk c lands in ``out[c*world*rows : (c+1)*world*rows]`` -- contiguous, already in
   catalog order, no repacking pass.  Because every super-block is spread over all ranks, a catalog
   that is sorted by orbit regime (all deep-space members at the end: 2-3x the cost per propagation)
-  still loads every rank evenly, which plain contiguous ranges do not.
+  still loads the ranks evenly once a super-block is short against that run (1,522 deep-space members at
+  the end of 15,000: 16 chunks give every one of 8 ranks 128-256 of them; plain contiguous ranges put all
+  1,522 on the last rank).
 * **Chunk pipeline** (:class:`ShardedPropagator`).  Chunk c+1 is computed
   (``azh_propagate_device_window``) while chunk c is in flight on the communication stream.
 
@@ -23,7 +25,7 @@ Cost model: the gather moves ``(world-1)/world`` of the 931.6 MB res
 MI355X ingests at most 7 x ~75 GB/s over xGMI, so t_allgather >= 1.6 ms at 8 GPUs (>= 6 ms at 2, one
 link) against 0.26 ms to compute the WHOLE result on one GPU.  Consumers that can work on their own shard
 (conjunction screening, ground tracks) should skip the gather; consumers that need everything everywhere
-are better served by every GPU propagating the full catalog (``replicate=True`` below) -- no bytes move at all.
+are better served by every GPU propagating the full catalog itself -- 0.2 ms, and no bytes move at all.
 """
 import os
 

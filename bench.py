@@ -5,16 +5,18 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over the whole workload: every satellite of the rank's
-catalog propagated to every time, fp64, TEME, positions + velocities, written into a device-resident
-(n_sats, n_times, 3) x 2 output (the shape BASELINE.json's north_star names; `--layout time` selects
-the (n_times, n_sats, 3) layout and with it the lane = satellite kernel).  Inputs (element table, time grid, epoch offsets)
-are resident in HBM before the timed region starts; nothing is copied to the host inside it.
+One "step" = one pass of the hot path over the whole workload: every satellite of the catalog propagated to
+every time, fp64, TEME, positions + velocities, written into device-resident (n_sats, n_times, 3) x 2 outputs
+(the shape BASELINE.json's north_star names; `--layout time` selects the (n_times, n_sats, 3) layout and
+with it the lane = satellite kernel).  Inputs (element table, time grid, epoch offsets) are resident in HBM
+before the timed region starts; nothing is copied to the host inside it.
 
-Multi-GPU: satellites shard embarrassingly; there is no data-path collective.
-Default is weak scaling -- every rank owns a 13,478-satellite catalog (different seeds) -- so
-`value` = N x 13,478 x 1,440 x K / t.  `--scaling strong` splits one 13,478-satellite catalog
-into contiguous ranges instead; `--gather` adds the optional RCCL all-gather of the result blocks.
+N = 1 is BASELINE config 2.  N > 1 is config 4 by default: STRONG scaling of the same 13,478-satellite
+catalog -- block-cyclic satellite shards (astroz_amd.distributed.ShardPlan), every rank propagates its shard and
+RCCL all-gathers re-assemble the full (n_sats, n_times, 3) arrays on every GPU, chunk-pipelined so that chunk
+c+1 is computed while chunk c is in flight; `value` = 13,478 x 1,440 / t_total, and `config` carries t_kernel,
+t_allgather and t_total separately.  `--scaling weak` (every rank its own 13,478-satellite catalog, no gather)
+and `--no-gather` are explicit alternatives and say so in `config.workload`.
 """
 import argparse
 import json
@@ -53,8 +55,11 @@ def parse_args():
                     help="fp32 OUTPUT arrays (BASELINE config 5); the arithmetic stays fp64")
     ap.add_argument("--layout", choices=["time", "sat"], default="sat",
                     help="physical output layout: sat = (n_sats, n_times, 3) [default], time = (n_times, n_sats, 3)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--gather", action="store_true", help="all-gather the result blocks (RCCL)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1: strong = one 13,478-satellite catalog sharded over the ranks (BASELINE config 4, default); "
+                         "weak = every rank its own catalog, no gather")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1, strong: skip the RCCL all-gather of the result")
+    ap.add_argument("--chunks", type=int, default=4, help="N > 1: pipeline depth of the compute / all-gather overlap")
     ap.add_argument("--tile", type=int, default=0, help="time steps per workgroup (0 = auto)")
     ap.add_argument("--stride-align", type=int, default=0,
                     help="time-major only: round the row length (out_stride_sats) up to a multiple of this many "
@@ -117,6 +122,18 @@ def cpu_baseline(pairs, times, offsets, seconds, sat_major):
     }, (n_s, p, v)
 
 
+def csrc_fingerprint():
+    """sha256 (16 hex digits) over the kernel sources: ties a committed PMC measurement to the build it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "astroz_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     a = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -137,70 +154,87 @@ def main():
     if world > 1:
         dist.barrier()         # nobody loads the library before rank 0 has (re)built it
     from astroz_amd import _native, synth
+    from astroz_amd.distributed import ShardPlan, ShardedPropagator
+
+    cuda = torch.device("cuda", local_rank)
+    n_times = a.times
+    times = np.arange(n_times, dtype=np.float64)
+    vel_on = not a.pos_only
+    odt = torch.float32 if a.f32_out else torch.float64
+    sharded = world > 1 and a.scaling == "strong"      # BASELINE config 4
+    gather = sharded and not a.no_gather
+    if sharded and (a.layout != "sat" or a.f32_out):
+        raise SystemExit("bench.py: the sharded (config 4) path is satellite-major fp64; use --scaling weak for other variants")
 
     # ---- workload -------------------------------------------------------------------------
-    if a.scaling == "weak" or world == 1:
+    plan = None
+    if sharded:
+        allp = synth.synth_catalog(n_near=a.sats, n_deep=a.deep, seed=20260926)
+        n_total = len(allp)
+        plan = ShardPlan(n_total, world, a.chunks)
+        pairs = [allp[i] for i in plan.local_rows(rank)]
+    else:
         pairs = synth.synth_catalog(n_near=a.sats, n_deep=a.deep, seed=20260926 + 101 * rank)
         n_total = len(pairs) * world
-    else:
-        allp = synth.synth_catalog(n_near=a.sats, n_deep=a.deep, seed=20260926)
-        per = -(-len(allp) // world)
-        per = -(-per // 64) * 64
-        pairs = allp[rank * per:(rank + 1) * per]
-        n_total = len(allp)
     dev = _native.DeviceConstellation.from_tle_lines(pairs, _native.WGS72, local_rank)
     if a.tile:
         dev.set_time_tile(a.tile, a.tile)
     if a.no_fast_path:
         dev.set_fast_path(False)
-    n_local, n_times = dev.n, a.times
-    times = np.arange(n_times, dtype=np.float64)
+    n_local = dev.n
     offsets = (synth.START_JD - dev.epochs) * 1440.0
-    vel_on = not a.pos_only
     layout = _native.TIME_MAJOR if a.layout == "time" else _native.SAT_MAJOR
     stride = 0
     if layout == _native.TIME_MAJOR and a.stride_align > 0:
         stride = -(-n_local // a.stride_align) * a.stride_align
-    shape = (n_times, stride or n_local, 3) if layout == _native.TIME_MAJOR else (n_local, n_times, 3)
-    cuda = torch.device("cuda", local_rank)
-    odt = torch.float32 if a.f32_out else torch.float64
-    pos = torch.empty(shape, dtype=odt, device=cuda)
-    vel = torch.empty(shape, dtype=odt, device=cuda) if vel_on else None
-    gathered = None
-    if a.gather and world > 1:
-        gathered = [torch.empty((world,) + shape, dtype=odt, device=cuda) for _ in range(2 if vel_on else 1)]
-    # an explicit (non-null) stream: the kernels, the collectives and the timing events all live on it
+    # an explicit (non-null) stream: the kernels and the timing events live on it
     stream = torch.cuda.Stream(device=cuda)
     torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
     assert sptr != 0
-    p_ptr, v_ptr = pos.data_ptr(), (vel.data_ptr() if vel_on else None)
-    torch.cuda.synchronize()
 
-    def step():
-        dev.propagate_device_cached(p_ptr, v_ptr, layout=layout, stride=stride, stream=sptr, f32=a.f32_out)
-        if gathered is not None:
-            dist.all_gather_into_tensor(gathered[0], pos)
-            if vel_on:
-                dist.all_gather_into_tensor(gathered[1], vel)
+    sp = None
+    if sharded:
+        sp = ShardedPropagator(dev, plan, rank, n_times, velocities=vel_on, device=cuda)
+        pos, vel = sp.local[0], (sp.local[1] if vel_on else None)
+        p_ptr, v_ptr = pos.data_ptr(), (vel.data_ptr() if vel_on else None)
+
+        def step(do_gather=gather):
+            sp.step(gather=do_gather)
+
+        def drain():                      # the launch stream waits for the pipeline's streams
+            stream.wait_stream(sp.comm)
+            stream.wait_stream(sp.compute)
+    else:
+        shape = (n_times, stride or n_local, 3) if layout == _native.TIME_MAJOR else (n_local, n_times, 3)
+        pos = torch.empty(shape, dtype=odt, device=cuda)
+        vel = torch.empty(shape, dtype=odt, device=cuda) if vel_on else None
+        p_ptr, v_ptr = pos.data_ptr(), (vel.data_ptr() if vel_on else None)
+
+        def step(do_gather=False):
+            dev.propagate_device_cached(p_ptr, v_ptr, layout=layout, stride=stride, stream=sptr, f32=a.f32_out)
+
+        def drain():
+            pass
+    torch.cuda.synchronize()
 
     # stage inputs (times, offsets) once; this call also runs the kernels (counts as warm-up)
     dev.propagate_device(times, offsets, p_ptr, v_ptr, layout=layout, stride=stride, stream=sptr, f32=a.f32_out)
     torch.cuda.synchronize()
     last_kernel_ms = dev.last_kernel_ms()   # the library's own hipEvent pair around that launch
     dev.set_timing(False)                    # the timed loop below is bracketed by events of its own
-    # Device preconditioning (untimed, reported in the JSON line): measured on MI355X, the shader clock
-    # dips for ~1-30 ms after the onset of a sustained load and then settles (0.33 ms/launch inside the
-    # dip, 0.29 ms from ~30 ms on, independent of how long the run continues).  W warm-up steps of a
-    # 0.3-ms kernel end inside the dip unless W is in the hundreds, so the same step is first run back to
-    # back for a fixed wall time; the W warm-up steps and the K timed steps follow immediately.
+    # Device preconditioning (untimed, reported in the JSON line): measured on MI355X, the clocks move for
+    # tens of milliseconds after the onset of a sustained load and then settle.  W warm-up steps of a
+    # 0.2-ms kernel end inside that transient unless W is in the hundreds, so the same step is first run back
+    # to back for a fixed wall time; the W warm-up steps and the K timed steps follow immediately.
     n_pre = 0
     t_pre = time.perf_counter()
-    if gathered is not None:
-        # the step contains a collective: every rank must run the same number of them
-        for _ in range(int(a.precondition_ms / 5.0)):
+    if sharded:
+        # the step contains collectives: every rank must run the same number of them
+        for _ in range(max(1, int(a.precondition_ms / (5.0 if gather else 0.3)))):
             step()
             n_pre += 1
+        drain()
         torch.cuda.synchronize()
     else:
         while (time.perf_counter() - t_pre) * 1e3 < a.precondition_ms:
@@ -210,6 +244,7 @@ def main():
             n_pre += 20
     for _ in range(a.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -219,8 +254,11 @@ def main():
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
+    if sharded:
+        sp.compute.wait_stream(stream)
     for _ in range(a.steps):
         step()
+    drain()
     ev1.record(stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -233,17 +271,19 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(tt[0]), float(tt[1])
 
-    # config 4 (--gather): the kernel alone, timed the same way, so that t_kernel and t_allgather can be
-    # reported next to t_total
+    # config 4: the kernels alone, timed the same way, so that t_kernel and t_allgather are reported next to
+    # t_total
     kernel_only_ms = None
-    if gathered is not None:
+    if sharded:
         dist.barrier()
         torch.cuda.synchronize()
         k0 = torch.cuda.Event(enable_timing=True)
         k1 = torch.cuda.Event(enable_timing=True)
         k0.record(stream)
+        sp.compute.wait_stream(stream)
         for _ in range(a.steps):
-            dev.propagate_device_cached(p_ptr, v_ptr, layout=layout, stride=stride, stream=sptr, f32=a.f32_out)
+            step(False)
+        drain()
         k1.record(stream)
         torch.cuda.synchronize()
         kt = torch.tensor([k0.elapsed_time(k1) / a.steps], dtype=torch.float64, device=cuda)
@@ -255,51 +295,68 @@ def main():
             dist.destroy_process_group()
         return
 
-    props_per_step = n_total * n_times if (a.scaling == "strong" and world > 1) else n_local * n_times * world
+    props_per_step = n_total * n_times
     value = props_per_step * a.steps / elapsed
     launch_s = (ev_ms / 1e3) / a.steps            # average duration of one launch (HIP events on the launch stream)
     if kernel_only_ms is not None:
-        launch_s = kernel_only_ms / 1e3           # with --gather the step also holds the collective
+        launch_s = kernel_only_ms / 1e3           # sharded: the step also holds the collectives
     local_props = n_local * n_times
-    n_tiles = max(1, -(-n_times // max(a.tile, 1))) if a.tile else None
     bytes_per_launch = local_props * (BYTES_OUT_PV if vel_on else BYTES_OUT_P) * (0.5 if a.f32_out else 1.0) + n_times * 8 + \
         n_local * ELEM_BYTES_PER_SAT  # elements counted once (re-reads across tiles are cache hits)
     gbs = bytes_per_launch / launch_s / 1e9
     tflops = local_props * FLOPS_PER_PROP / launch_s / 1e12
 
-    # HBM traffic per launch from the PMC counters: collected offline with rocprofv3 on this same
-    # command (separate --pmc passes, tools/profile.sh) and committed under profiles/
+    # HBM traffic per launch from the PMC counters: collected offline with rocprofv3 on this same command
+    # (separate --pmc passes, tools/profile.sh) and committed under profiles/ together with a fingerprint of
+    # the kernel sources it was measured on; a stale measurement is not reported
     traffic = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
-        if layout == _native.SAT_MAJOR and vel_on and a.sats == 13478 and n_times == 1440 and not a.deep:
+        if (pm.get("csrc_sha16") == csrc_fingerprint() and world == 1 and layout == _native.SAT_MAJOR and vel_on and
+                a.sats == 13478 and n_times == 1440 and not a.deep and not a.f32_out and not a.no_fast_path):
             traffic = pm["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
 
+    if world == 1:
+        wl = "config 2: %d-sat synthetic active catalog (SGP4 near-earth%s) x %d one-minute steps" % (
+            a.sats, " + %d deep-space SDP4" % a.deep if a.deep else "", n_times)
+        par = "single GPU"
+    elif sharded:
+        wl = "config 4: the %d-sat synthetic catalog%s x %d one-minute steps, block-cyclic satellite shards over %d GPUs%s" % (
+            n_total, " (incl. %d deep-space SDP4)" % a.deep if a.deep else "", n_times, world,
+            ", RCCL all-gather of the full result onto every GPU (%d-chunk compute/gather pipeline)" % plan.n_chunks
+            if gather else ", NO gather (--no-gather: every GPU keeps its shard)")
+        par = "satellite-sharded x%d%s" % (world, " + RCCL all-gather" if gather else ", no data-path collective")
+    else:
+        wl = "WEAK scaling (--scaling weak): %d GPUs x an own %d-sat synthetic catalog x %d one-minute steps, no gather" % (
+            world, a.sats + a.deep, n_times)
+        par = "independent catalogs x%d, no data-path collective" % world
+    wl += ", fp64 arithmetic, %s TEME %s, %s-major device-resident output" % (
+        "fp32-stored" if a.f32_out else "fp64", "pos+vel" if vel_on else "pos only", a.layout)
+    if layout == _native.SAT_MAJOR:
+        kname = ("k_rows_fast<%s> (branch-free uniform-grid step, one wave per satellite row, lane = time) + k_rows redo pass"
+                 if not a.no_fast_path else "k_rows<%s> (one wave per satellite row, lane = time)") % ("pos+vel" if vel_on else "pos")
+    else:
+        kname = "k_propagate<time-major,%s> (lane = satellite)" % ("pos+vel" if vel_on else "pos")
     out = {
         "metric": "propagations/sec, 13,478 sats x 1,440 times, at 1/2/4/8 MI355X",
         "value": value, "unit": "propagations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
-        "scaling": a.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "n/a" if world == 1 else a.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": "config 2: %d-sat synthetic active catalog (SGP4 near-earth%s) x %d one-minute steps, "
-                        "fp64 arithmetic, %s TEME %s, %s-major device-resident output%s" % (
-                            a.sats, " + %d deep-space SDP4" % a.deep if a.deep else "", n_times,
-                            "fp32-stored" if a.f32_out else "fp64", "pos+vel" if vel_on else "pos only", a.layout,
-                            ", per GPU" if (world > 1 and a.scaling == "weak") else ""),
-            "n_sats_per_gpu": n_local, "n_times": n_times, "gather": bool(gathered is not None),
+            "workload": wl, "n_sats_total": n_total, "n_sats_per_gpu": n_local, "n_times": n_times, "gather": bool(gather),
             "precondition_ms": a.precondition_ms, "precondition_steps": n_pre,
-            **({"t_kernel_ms": kernel_only_ms, "t_allgather_ms": elapsed / a.steps * 1e3 - kernel_only_ms,
-                "t_total_ms": elapsed / a.steps * 1e3} if kernel_only_ms is not None else {}),
-            "parallelism": "satellite-sharded x%d, no data-path collective" % world if gathered is None
-                           else "satellite-sharded x%d + RCCL all-gather" % world,
+            **({"t_kernel_ms": kernel_only_ms, "t_allgather_ms": max(elapsed / a.steps * 1e3 - kernel_only_ms, 0.0),
+                "t_total_ms": elapsed / a.steps * 1e3, "rccl_ranks": world, "chunks": plan.n_chunks,
+                "kernel_only_value": props_per_step / (kernel_only_ms / 1e3),
+                "gather_bytes_per_gpu": (plan.padded - plan.local_capacity()) * n_times * 3 * 8 * (2 if vel_on else 1)}
+               if kernel_only_ms is not None else {}),
+            "parallelism": par,
         },
         "roofline": {
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "kernel": ("k_rows<%s> (one wave per satellite row, lane = time)" if layout == _native.SAT_MAJOR else
-                       "k_propagate<time-major,%s> (lane = satellite)") % ("pos+vel" if vel_on else "pos"),
+            "traffic": traffic, "kernel": kname,
             "avg_launch_ms": launch_s * 1e3, "first_launch_ms_hipevent": last_kernel_ms,
             "algorithmic_bytes_per_launch": bytes_per_launch,
         },

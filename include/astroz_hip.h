@@ -102,6 +102,12 @@ typedef struct azh_constellation azh_constellation;
  * [11] mean motion rev/day [12] element set no [13] rev no [14] classification char [15] 0 */
 int32_t azh_parse_tle_lines(const char *line1, const char *line2, double *out16);
 
+/* the same 16 fields for every element set of a text: multi-TLE text (2- or 3-line, Tle.MultiIterator,
+ * src/Tle.zig L103-132) or OMM JSON (object or array, src/Tle.zig L134-238).  Host-side text handling only --
+ * no GPU needed.  *n_found = records in the text; at most max_records are written to out16 (16 doubles each). */
+int32_t azh_parse_tle_text(const char *text, size_t len, double *out16, size_t max_records, size_t *n_found);
+int32_t azh_parse_omm_json(const char *text, size_t len, double *out16, size_t max_records, size_t *n_found);
+
 /* number of visible HIP devices (0 when there is no GPU / no driver) */
 int azh_device_count(void);
 /* last HIP error string of the calling thread's most recent failing call ("" if none) */

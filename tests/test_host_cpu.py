@@ -100,25 +100,38 @@ def test_time_helpers(golden):
     assert jday(2024, 5, 6, 12, 0, 0.0) == (2460436.5, 0.5)
 
 
-def test_text_front_ends(orc):
+def test_text_front_ends(native, golden):
+    """TLE text and OMM JSON front ends (host-side text handling of the library, no GPU): the reference's own
+    parse tests (src/Tle.zig L306-392) as data."""
     import astroz_amd as az
     l1 = "1 25544U 98067A   24127.82853009  .00015698  00000+0  27310-3 0  9995"
     l2 = "2 25544  51.6393 160.4574 0003580 140.6673 205.7250 15.50957674452123"
-    text = "ISS (ZARYA)\n" + l1 + "\n" + l2 + "\nORPHAN\n" + l1 + "\n"
-    assert az._parse_tle_pairs(text) == [(l1, l2)]
-    assert az._load_tle_text(text) == (text, "tle")
-    omm = ('[{"NORAD_CAT_ID": 25544, "OBJECT_ID": "1998-067A", "EPOCH": "2024-05-06T19:53:05.000000",'
-           ' "MEAN_MOTION": 15.50957674, "ECCENTRICITY": 0.000358, "INCLINATION": 51.6393,'
-           ' "RA_OF_ASC_NODE": 160.4574, "ARG_OF_PERICENTER": 140.6673, "MEAN_ANOMALY": 205.725,'
-           ' "BSTAR": 0.0002731, "MEAN_MOTION_DOT": 0.00015698, "MEAN_MOTION_DDOT": 0,'
-           ' "ELEMENT_SET_NO": 999, "REV_AT_EPOCH": 45212, "CLASSIFICATION_TYPE": "U", "EPHEMERIS_TYPE": 0}]')
-    (o1, o2), = az._omm_to_tle_pairs(omm)
-    assert len(o1) == 69 and len(o2) == 69
-    t = orc.parse_lines(o1, o2)
-    assert t.satnum == 25544 and abs(t.bstar - 0.0002731) < 1e-12 and abs(t.ecc - 0.000358) < 1e-12
-    assert abs(t.mm_revday - 15.50957674) < 1e-9 and abs(t.epoch_day - 127.82853009) < 2e-8
+    # 3-line format with names, an orphaned line 1, garbage (Tle.zig L334-356)
+    text = "ISS (ZARYA)\n" + l1 + "\n" + l2 + "\nORPHAN\n" + l1 + "\nSTARLINK-1234\n"
+    f = native.parse_element_text(text)
+    assert f.shape == (1, 16) and f[0, 0] == 25544 and abs(f[0, 5] - 0.27310e-3) < 1e-15
+    assert native.parse_element_text("hello\ngarbage\n").shape == (0, 16)
+    assert az._as_text(text) == text and not az._is_json(text)
+    for case in golden["G8b_omm"]["cases"]:
+        f = native.parse_element_text(case["json"])
+        assert f.shape[0] == len(case["expect"])
+        for row, exp in zip(f, case["expect"]):
+            assert row[0] == exp["satnum"]
+            for key, col in (("inclination", 6), ("eccentricity", 8), ("mean_motion", 11), ("bstar", 5)):
+                if key in exp:
+                    assert abs(row[col] - exp[key]) <= exp.get("tol_" + key, 1e-12), (key, row[col])
+        assert az._is_json(case["json"])
+    # epoch: ISO-8601 -> two-digit year, day of year, Julian date (Tle.zig L198-238)
+    f = native.parse_element_text(golden["G8b_omm"]["cases"][0]["json"])
+    assert f[0, 1] == 26 and abs(f[0, 2] - (105 + (13 + (17 + 52.692576 / 60) / 60) / 24)) < 1e-9
+    assert abs(f[0, 3] - (2461145.5 + (13 + (17 + 52.692576 / 60) / 60) / 24)) < 1e-8
+    for bad in ('{"NORAD_CAT_ID": 1}', "[1, 2]", '{"EPOCH": "2026-04-15"', "[{]"):
+        with pytest.raises(ValueError):
+            native.parse_element_text(bad)
     from datetime import datetime, timezone
-    assert az._start_jd(datetime(2000, 1, 1, 12, tzinfo=timezone.utc)) == 2451545.0
+    assert az._jd_of(datetime(2000, 1, 1, 12, tzinfo=timezone.utc)) == 2451545.0
+    with pytest.raises(ValueError):
+        az._as_text("starlink")        # no CelesTrak group lookups: this package never fetches
 
 
 def test_synthetic_catalog_is_valid(orc):
