@@ -100,7 +100,8 @@ struct azh_constellation {
     unsigned n_sgp4 = 0, n_sdp4 = 0, n_bad = 0;
     // per-call scratch
     DevBuf<double> d_times, d_offsets, d_sin, d_cos, d_seeds;
-    DevBuf<unsigned> d_redo;    // k_rows_fast -> k_rows redo list: [0] count, then (slot, first, end) triples
+    DevBuf<unsigned> d_redo;    // k_rows_fast -> k_rows redo list: [0],[1] item counters (alternating launches), [4..] (slot, first, end) triples
+    unsigned redo_parity = 0;
     DevBuf<double> d_inc;       // uniform grids: per-satellite rotation increments (k_prep_inc), [12][n_pad]
     double uniform_step = 0.0;  // step of the staged grid if it is uniform, else 0
     DevBuf<double> d_tgt, d_part_d2, d_out_d; // fused screen: target track, partial minima, results
@@ -121,6 +122,7 @@ struct azh_constellation {
     int cached_mode = 0;
     hipStream_t s_main = nullptr, s_deep = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    unsigned off_circ = 0; // offset into d_list of the near-earth members in plain catalog order
     bool timed = false;
     bool timing = true; // record the ev_t0/ev_t1 pair around every launch set (azh_set_timing)
     unsigned tile_sgp4 = 0, tile_sdp4 = 0;
@@ -263,6 +265,10 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
         for (size_t s = 0; s < n; ++s)
             if (AZ_FLAG_ERR(c->h_flags[s]) != 0) list.push_back((unsigned)s);
         c->n_bad = (unsigned)list.size() - c->n_sgp4 - c->n_sdp4;
+        // the near-earth members once more in plain catalog order (k_rows_fast: neighbouring rows on one XCD)
+        c->off_circ = (unsigned)list.size();
+        for (size_t s = 0; s < n; ++s)
+            if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && !(c->h_flags[s] & AZ_FLAG_DEEP)) list.push_back((unsigned)s);
         if (c->d_list.ensure(list.size()) != AZ_OK ||
             !hip_ok(hipMemcpy(c->d_list.p, list.data(), sizeof(unsigned) * list.size(), hipMemcpyHostToDevice), "H2D list")) {
             rc = AZ_ERR_HIP;
@@ -367,7 +373,6 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st)
     } else if (a.redo_items != nullptr) {
         // uniform grid: the branch-free kernel first; what it rejects (eccentric members, angles outside their
         // tier: a few per cent of the segments) is listed and handed to the generic kernel
-        (void)hipMemsetAsync(a.redo_count, 0, sizeof(unsigned), st);
         dim3 rgrid(std::min(2048u, grid.x * grid.y), 4);
         if (a.f32) {
             hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
@@ -543,13 +548,28 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         a.tile = auto_tile(c->n_sgp4, n_times, c->tile_sgp4, 8);
         a.tile_forced = c->tile_sgp4;
         if (a.inc != nullptr && use_rows(a, layout, false)) {
-            const unsigned tile = rows_tile(a.n_list, n_times, a.tile_forced);
-            const size_t segs = (n_times + tile - 1) / tile;
-            if (c->d_redo.ensure(4 + 3 * segs * a.n_list) != AZ_OK) return AZ_ERR_HIP;
-            a.redo_count = c->d_redo.p;
-            a.redo_items = c->d_redo.p + 4;
+            // uniform grid, satellite-major rows: every near-earth member -> k_rows_fast (near-circular or
+            // eccentric Kepler form by class); what its validation rejects comes back through the redo list
+            a.list = c->d_list.p + c->off_circ; // catalog order (the first list is ordered for the lane = satellite kernel)
+            a.n_list = c->n_sgp4;
+            if (c->n_sgp4 > 0) {
+                const unsigned tile = rows_tile(a.n_list, n_times, a.tile_forced);
+                const size_t segs = (n_times + tile - 1) / tile;
+                if (!c->d_redo.p) {
+                    if (c->d_redo.ensure(4 + 3 * segs * c->n_sgp4) != AZ_OK) return AZ_ERR_HIP;
+                    HIP_TRY(hipMemsetAsync(c->d_redo.p, 0, 4 * sizeof(unsigned), st)); // the redo kernel re-arms it
+                } else if (c->d_redo.cap < 4 + 3 * segs * c->n_sgp4) {
+                    HIP_TRY(hipStreamSynchronize(st));
+                    if (c->d_redo.ensure(4 + 3 * segs * c->n_sgp4) != AZ_OK) return AZ_ERR_HIP;
+                    HIP_TRY(hipMemsetAsync(c->d_redo.p, 0, 4 * sizeof(unsigned), st));
+                }
+                a.redo_count = c->d_redo.p + c->redo_parity;
+                a.redo_next = c->d_redo.p + (c->redo_parity ^ 1u);
+                a.redo_items = c->d_redo.p + 4;
+                c->redo_parity ^= 1u;
+            }
         }
-        launch_propagate(a, layout, d_vel != nullptr, false, st);
+        if (a.n_list > 0) launch_propagate(a, layout, d_vel != nullptr, false, st);
         HIP_TRY(hipGetLastError());
     }
     if (c->n_bad > 0) {

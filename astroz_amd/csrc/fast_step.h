@@ -6,8 +6,8 @@
 //     between a lane's consecutive steps: (sin,cos) of mdot*dt, argpdot*dt, nodedot*dt are
 //     per-satellite constants (prepared once per grid by k_prep_inc) and every carried pair moves by
 //     one angle addition (4 FMA-class instructions, no polynomial, no vote);
-//   * the orbit is near-circular (el^2 < 1.6e-5) and every small angle sits inside its usual
-//     rotation tier.
+//   * every small angle sits inside its usual rotation tier, and the orbit is either near-circular
+//     (el^2 < 1.6e-5: the two-step Kepler form) or, ECC = true, converges in five Newton trips with fixed tiers.
 // Instead of choosing tiers with wave votes and branches the step runs straight through and RETURNS a
 // per-lane `bad` predicate; the caller votes once per step and, on a violation, hands the remaining
 // grid points to the generic az_sgp4_step loop (results are only stored after the vote, so nothing
@@ -123,8 +123,7 @@ AZ_DEVICE void az_rotate_tiny2(double &s, double &c, double d, const RotK &k)
 }
 
 // (p,q) = (sin d, cos d - 1) for |d| <= 1/16: sin to d^7, cos to d^8 (d^9/9! < 3e-17, d^10/10! < 3e-19).
-// Two instructions more than the 2^-7 tier; used for the along-track drag term, which grows with t^2 and
-// leaves the 2^-7 tier within days for high-drag members.
+// Two instructions more than the 2^-7 tier; used for delomg + delm, which reaches 2^-7 for one member in fifty.
 #define AZ_ROT_16TH 0.0625
 AZ_DEVICE void az_pq_16th(double d, const RotK &k, double &p, double &q)
 {
@@ -133,13 +132,28 @@ AZ_DEVICE void az_pq_16th(double d, const RotK &k, double &p, double &q)
     p = d * fma(d2, fma(d2, fma(d2, -1.0 / 5040.0, k.p120), k.n6), 1.0);
 }
 
+// (p,q) for |d| <= 1/8: sin to d^9, cos to d^10 (the polynomial of az_rotate_med).  The along-track drag term
+// no*templ grows with t^2: 1/8 rad holds 99.4% of a catalog up to six days from epoch.
+AZ_DEVICE void az_pq_med(double d, double &p, double &q)
+{
+    const double d2 = d * d;
+    q = fma(d2, -1.0 / 3628800.0, 1.0 / 40320.0);
+    q = fma(d2, q, -1.0 / 720.0);
+    q = fma(d2, q, 1.0 / 24.0);
+    q = d2 * fma(d2, q, -0.5);
+    p = fma(d2, 1.0 / 362880.0, -1.0 / 5040.0);
+    p = fma(d2, p, 1.0 / 120.0);
+    p = fma(d2, p, -1.0 / 6.0);
+    p = d * fma(d2, p, 1.0);
+}
+
 // validation thresholds of the fast step
 #define AZ_FAST_EL2 1.6e-5
 #define AZ_FAST_TEMP2 6.0e-4
 
 // one near-earth propagation on a uniform grid; returns true when an assumption of the fast path does
 // not hold for this lane (the caller must then discard r/v and use az_sgp4_step)
-template <bool VEL, class K>
+template <bool VEL, bool ECC = false, class K = FastK>
 AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, double t, FastCarry &st, double r[3],
                                   double v[3])
 {
@@ -163,9 +177,9 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, do
     const double th = fma(k.xmcof(), dm * dm * dm, fma(k.omgcof(), t, -k.xd())); // delomg + delm
     const double tempa = fma(-t, fma(t, fma(t, fma(t, k.d4(), k.d3()), k.d2()), k.cc1()), 1.0);
     const double nl = t2 * fma(t, fma(t, fma(t, k.nl5(), k.nl4()), k.nl3()), k.nl2()); // no_unkozai * templ
-    bool bad = !(fabs(th) <= AZ_ROT_SMALL);
+    bool bad = !(fabs(th) <= AZ_ROT_16TH);
     double p, q;
-    az_pq_small(th, rk, p, q);
+    az_pq_16th(th, rk, p, q);
     const double smm = fma(cA, p, fma(sA, q, sA));            // sin(M + th)
     const double sw = fma(-st.cW, p, fma(st.sW, q, st.sW));   // (sin,cos)(W - th)
     const double cw = fma(st.sW, p, fma(st.cW, q, st.cW));
@@ -186,33 +200,72 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, do
     double c = fma(cA, st.cW, -(sA * st.sW));
     {
         const double eps = fma(temp * k.xlcof(), axnl, nl);
-        bad |= !(fabs(eps) <= AZ_ROT_16TH);
-        az_pq_16th(eps, rk, p, q);
+        bad |= !(fabs(eps) <= AZ_ROT_MED);
+        az_pq_med(eps, p, q);
         az_rot_apply2(s, c, p, q);
     }
 
-    // Kepler, near-circular form (see az_kepler_posvel): Newton step from E0 = u, chord step with the
-    // same reciprocal, first-order rotation by the second correction
     const double el2 = fma(axnl, axnl, aynl * aynl);
-    bad |= !(el2 <= AZ_FAST_EL2);
-    const double rden = az_rcp1(fma(-s, aynl, fma(-c, axnl, 1.0)));
-    const double d0 = fma(axnl, s, -(aynl * c)) * rden;
-    az_pq_small(d0, rk, p, q); // |d0| <= el/(1-el) < 2^-7
-    az_rot_apply2(s, c, p, q);
-    const double d1 = fma(axnl, s, fma(-aynl, c, -d0)) * rden;
-    {
-        const double s1 = fma(c, d1, s);
-        c = fma(-s, d1, c);
-        s = s1;
+    double ecose, esine, ome, inv_ome, betal, inv_omel2, inv_1pb;
+    if (!ECC) {
+        // Kepler, near-circular form (see az_kepler_posvel): Newton step from E0 = u, chord step with the
+        // same reciprocal, first-order rotation by the second correction
+        bad |= !(el2 <= AZ_FAST_EL2);
+        const double rden = az_rcp1(fma(-s, aynl, fma(-c, axnl, 1.0)));
+        const double d0 = fma(axnl, s, -(aynl * c)) * rden;
+        az_pq_small(d0, rk, p, q); // |d0| <= el/(1-el) < 2^-7
+        az_rot_apply2(s, c, p, q);
+        const double d1 = fma(axnl, s, fma(-aynl, c, -d0)) * rden;
+        {
+            const double s1 = fma(c, d1, s);
+            c = fma(-s, d1, c);
+            s = s1;
+        }
+        ecose = fma(axnl, c, aynl * s);
+        esine = fma(axnl, s, -(aynl * c));
+        ome = 1.0 - ecose;
+        inv_ome = fma(rden, fma(-ome, rden, 1.0), rden);
+        inv_ome = fma(inv_ome, fma(-ome, inv_ome, 1.0), inv_ome);
+        betal = fma(el2, fma(el2, -0.125, -0.5), 1.0);    // sqrt(1-x)   (- x^3/16)
+        inv_omel2 = fma(el2, el2 + 1.0, 1.0);             // 1/(1-x)     (+ x^3 < 4.1e-15)
+        inv_1pb = fma(el2, fma(el2, 0.0625, 0.125), 0.5); // 1/(1+betal) (+ 5x^3/128)
+    } else {
+        // Kepler, any near-earth eccentricity (el < ~0.33): five Newton trips on E - aynl cosE + axnl sinE = u
+        // carrying eps = E - u and rotating (sinE, cosE) by each correction, with the rotation tier FIXED per
+        // trip (quadratic convergence: |d| <= 1/2, 1/8, 2^-7, 2^-7, 2^-7) and validated instead of voted; the
+        // generic loop's exit criterion el^2 d^4 < 4e-26 must hold for the last correction.
+        double eps = 0.0, rden = 1.0, d = 0.0;
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {
+            rden = az_rcp1(fma(-s, aynl, fma(-c, axnl, 1.0)));
+            d = fma(axnl, s, fma(-aynl, c, -eps)) * rden;
+            eps += d;
+            if (it == 0) {
+                bad |= !(fabs(d) <= 0.5);
+                az_rotate_large(s, c, d);
+            } else if (it == 1) {
+                bad |= !(fabs(d) <= AZ_ROT_MED);
+                az_pq_med(d, p, q);
+                az_rot_apply2(s, c, p, q);
+            } else {
+                bad |= !(fabs(d) <= AZ_ROT_SMALL);
+                az_pq_small(d, rk, p, q);
+                az_rot_apply2(s, c, p, q);
+            }
+        }
+        const double d2 = d * d;
+        bad |= !(el2 * d2 * d2 < 4.0e-26);
+        ecose = fma(axnl, c, aynl * s);
+        esine = fma(axnl, s, -(aynl * c));
+        ome = 1.0 - ecose;
+        // the last trip's reciprocal is 1/(1 - ecose) before the final rotation: off by el*d, one Newton step
+        inv_ome = fma(rden, fma(-ome, rden, 1.0), rden);
+        const double omel2 = 1.0 - el2;
+        const double rb = az_rsqrt(omel2);
+        betal = omel2 * rb;
+        inv_omel2 = rb * rb;
+        inv_1pb = az_rcp(1.0 + betal);
     }
-    const double ecose = fma(axnl, c, aynl * s);
-    const double esine = fma(axnl, s, -(aynl * c));
-    const double ome = 1.0 - ecose;
-    double inv_ome = fma(rden, fma(-ome, rden, 1.0), rden);
-    inv_ome = fma(inv_ome, fma(-ome, inv_ome, 1.0), inv_ome);
-    const double betal = fma(el2, fma(el2, -0.125, -0.5), 1.0);   // sqrt(1-x)   (- x^3/16)
-    const double inv_omel2 = fma(el2, el2 + 1.0, 1.0);            // 1/(1-x)     (+ x^3 < 4.1e-15)
-    const double inv_1pb = fma(el2, fma(el2, 0.0625, 0.125), 0.5); // 1/(1+betal) (+ 5x^3/128)
 
     const double est = esine * inv_1pb;
     const double sinu = inv_ome * (s - fma(axnl, est, aynl));
@@ -232,10 +285,11 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, do
     // J2 short-period corrections as tiny rotations (each bounded by 1.5 temp2 <= 9e-4); the secular
     // xnodcf t^2 part of the node rides on the node correction
     const double a_nd = fma(k.k_node(), t2s, k.xnodcf() * t2);
-    bad |= !(fabs(a_nd) <= AZ_ROT_MILLI);
+    bad |= !(fabs(a_nd) <= AZ_ROT_SMALL);
     double ssu = sinu, csu = cosu, sn = st.sO, cn = st.cO, si = k.sinio(), ci = k.cosio();
     az_rotate_tiny2(ssu, csu, k.k_su() * t2s, rk);
-    az_rotate_tiny2(sn, cn, a_nd, rk);
+    az_pq_small(a_nd, rk, p, q); // the node correction carries the secular xnodcf t^2 term: one tier up
+    az_rot_apply2(sn, cn, p, q);
     az_rotate_tiny2(si, ci, k.k_inc() * temp2 * cos2u, rk);
 
     const double xmx = -sn * ci, xmy = cn * ci;

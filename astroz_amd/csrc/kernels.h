@@ -83,6 +83,7 @@ struct PropArgs {
     // k_rows_fast -> k_rows hand-over: (list slot, first grid point, end) of every segment remainder the fast
     // step rejected
     unsigned *redo_count;
+    unsigned *redo_next; // the other launch parity's counter (zeroed by the redo pass for the launch after this one)
     unsigned *redo_items;
     AzGrav g;
 };
@@ -380,8 +381,12 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
         for (; i < t1; ++i) {
             const double t = time_at(i);
             double r[3], v[3];
-            const bool bad = az_sgp4_fast_step<VEL>(k, p.g, rk, t, fc, r, v);
+#if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
+            r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
+#else
+            const bool bad = az_sgp4_fast_step<VEL, false>(k, p.g, rk, t, fc, r, v);
             if (az_any(bad && in_range)) break;
+#endif
             emit(i, r, v, 0);
         }
     }
@@ -558,7 +563,8 @@ struct ColdBroadcast {
     __device__ __forceinline__ void set(int k, double v) const { p[k] = v; }
 };
 #ifndef AZ_ROWSF_WAVES
-#define AZ_ROWSF_WAVES 6 /* k_rows_fast: 74 VGPRs */
+#define AZ_ROWSF_WAVES 5 /* k_rows_fast: 91 VGPRs with both Kepler forms (78 = 6 waves/SIMD with the near-circular one only: 2% faster on
+                           a near-circular catalog, but eccentric members would then go through the redo pass at 5x the cost) */
 #endif
 #ifndef AZ_ROWS_TLDS
 #define AZ_ROWS_TLDS 1024 /* k_rows: time values staged in LDS per refill (a power of two >= 64) */
@@ -638,10 +644,11 @@ __device__ __forceinline__ void az_rows_store(bool staged, bool full, bool live,
 }
 
 // Near-earth rows on a UNIFORM grid: the branch-free step of fast_step.h, one wave per (satellite row, time
-// segment), lane = time.  74 VGPRs (6 waves/SIMD; the generic k_rows needs 135 = 3): the 18 hot constants sit in
+// segment), lane = time.  91 VGPRs (5 waves/SIMD; the generic k_rows needs 135 = 3): the 18 hot constants sit in
 // SGPRs, the 16 once-per-step ones in LDS (broadcast reads), time is t0 + i*step (no staging, no loads in the
-// loop).  A wave whose validation vote fails -- eccentric orbit, an angle outside its tier -- appends the rest of
-// its segment to the redo list and exits; the generic kernel runs that list afterwards.
+// loop).  The Kepler form follows the member's eccentricity class (wave-uniform).  A wave whose validation vote
+// fails -- an angle outside its tier, a Newton iteration that needs more than five trips -- appends the rest of its
+// segment to the redo list and exits; the generic kernel runs that list afterwards.
 template <bool VEL, bool FRAME, int SINK>
 __global__ void __launch_bounds__(64, AZ_ROWSF_WAVES) k_rows_fast(PropArgs p)
 {
@@ -656,7 +663,8 @@ __global__ void __launch_bounds__(64, AZ_ROWSF_WAVES) k_rows_fast(PropArgs p)
     const unsigned t_lo = blockIdx.y * p.tile;
     const unsigned t_hi = min(t_lo + p.tile, p.n_times);
     unsigned base = t_lo;
-    if (AZ_FLAG_ECLASS(fl) == 0) {
+    {
+        const bool ecc = AZ_FLAG_ECLASS(fl) != 0; // wave-uniform: which Kepler form the step uses
         __shared__ __attribute__((aligned(16))) double cold_lds[FC_NUM];
         __shared__ __attribute__((aligned(16))) out_t rows_stage[AZ_ROWS_LDS_STORE ? 2 * 64 * 3 : 4];
         const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
@@ -696,7 +704,8 @@ __global__ void __launch_bounds__(64, AZ_ROWSF_WAVES) k_rows_fast(PropArgs p)
 #if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
             r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
 #else
-            const bool bad = az_sgp4_fast_step<VEL>(k, p.g, rk, t, fc, r, v);
+            const bool bad = ecc ? az_sgp4_fast_step<VEL, true>(k, p.g, rk, t, fc, r, v)
+                                 : az_sgp4_fast_step<VEL, false>(k, p.g, rk, t, fc, r, v);
             if (az_any(bad && live)) break;
 #endif
             if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
@@ -838,6 +847,10 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
         }
     }
     } // items
+    // two item counters used alternately: this launch consumed redo_count, the NEXT launch's k_rows_fast (ordered
+    // after this kernel on the stream) appends through redo_next, which is re-armed here.  (An arrival counter
+    // with "last one out resets" serialises one atomic per workgroup on a single address: measured 100 us.)
+    if (redo && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) *p.redo_next = 0u;
 }
 
 // Deep-space rows, satellite-major output (and the fused screen): ONE WAVE PER SATELLITE, lane = time,

@@ -59,7 +59,7 @@ void emul_propagate(const double* fields, unsigned flags, const double* grav6, c
 // the branch-free uniform-grid step (fast_step.h) as one lane of the lane = time kernel runs it: seeded one
 // increment before ts0, then n steps of `dt` minutes.  bad_out[i] = the step's validation predicate.
 void emul_propagate_fast(const double* fields, unsigned flags, const double* grav6, double ts0, double dt, int n,
-                         double* out6, int* bad_out)
+                         int ecc, double* out6, int* bad_out)
 {
     AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
     double inc[12];
@@ -72,7 +72,8 @@ void emul_propagate_fast(const double* fields, unsigned flags, const double* gra
     az_seed_fast(fields, 1, 0, ts0 - dt, st);
     for (int i = 0; i < n; ++i) {
         double r[3], v[3];
-        bad_out[i] = az_sgp4_fast_step<true>(k, g, az_rotk(), ts0 + i * dt, st, r, v) ? 1 : 0;
+        bad_out[i] = (ecc ? az_sgp4_fast_step<true, true>(k, g, az_rotk(), ts0 + i * dt, st, r, v)
+                          : az_sgp4_fast_step<true, false>(k, g, az_rotk(), ts0 + i * dt, st, r, v)) ? 1 : 0;
         memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
     }
 }

@@ -168,7 +168,7 @@ def emul():
     E.emul_init.restype = C.c_uint
     E.emul_init.argtypes = [C.c_void_p] * 3
     E.emul_propagate.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    E.emul_propagate_fast.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    E.emul_propagate_fast.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     E.emul_sincos.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
     E.emul_rcp.restype = C.c_double
     E.emul_rcp.argtypes = [C.c_double]
@@ -233,9 +233,9 @@ def test_emulated_kernels_match_oracle(emul, orc, step):
 
 @pytest.mark.parametrize("dt", [64.0, 1.0, 640.0])
 def test_emulated_fast_step_matches_oracle(emul, orc, dt):
-    """fast_step.h (the branch-free uniform-grid step of k_rows / k_propagate), host-compiled: wherever its
-    validation predicate accepts a step the result must match the oracle; the predicate must accept the bulk
-    of a near-circular catalog and reject eccentric members."""
+    """fast_step.h (the branch-free uniform-grid step of k_rows_fast / k_propagate), host-compiled: wherever its
+    validation predicate accepts a step the result must match the oracle; the near-circular form must accept the
+    bulk of a near-circular catalog and reject eccentric members, the eccentric form must accept those."""
     from astroz_amd import synth
     pairs = synth.synth_catalog(300, 0, seed=9)
     tles = [orc.parse_lines(a, b) for a, b in pairs]
@@ -245,26 +245,32 @@ def test_emulated_fast_step_matches_oracle(emul, orc, dt):
     n = 40
     off = (synth.START_JD - cat.epoch_jd) * 1440.0
     worst_r = worst_v = 0.0
-    accepted = total = 0
+    accepted = total = ecc_accepted = ecc_total = 0
     for i, t in enumerate(tles):
         raw = np.array([t.epoch_jd, t.mm_revday, t.ecc, t.incl_deg, t.raan_deg, t.argp_deg, t.ma_deg, t.bstar])
         fields = np.zeros(nf)
         flags = emul.emul_init(raw.ctypes.data, g.ctypes.data, fields.ctypes.data)
-        out = np.zeros((n, 6))
-        bad = np.zeros(n, dtype=np.int32)
         ts0 = off[i] + 3.0
-        emul.emul_propagate_fast(fields.ctypes.data, flags, g.ctypes.data, ts0, dt, n, out.ctypes.data, bad.ctypes.data)
-        total += n
-        if t.ecc > 0.01:
-            assert bad.all(), "eccentric orbit accepted by the fast step"
-        for k in range(n):
-            if bad[k]:
-                continue
-            accepted += 1
-            _, r, v = cat.propagate_one(i, ts0 + k * dt)
-            worst_r = max(worst_r, np.abs(out[k, :3] - r).max())
-            worst_v = max(worst_v, np.abs(out[k, 3:] - v).max())
+        for ecc_form in (0, 1):
+            out = np.zeros((n, 6))
+            bad = np.zeros(n, dtype=np.int32)
+            emul.emul_propagate_fast(fields.ctypes.data, flags, g.ctypes.data, ts0, dt, n, ecc_form, out.ctypes.data, bad.ctypes.data)
+            if ecc_form == 0:
+                total += n
+                accepted += int((bad == 0).sum())
+                if t.ecc > 0.01:
+                    assert bad.all(), "eccentric orbit accepted by the near-circular form"
+            elif t.ecc > 0.01:
+                ecc_total += n
+                ecc_accepted += int((bad == 0).sum())
+            for k in range(n):
+                if bad[k]:
+                    continue
+                _, r, v = cat.propagate_one(i, ts0 + k * dt)
+                worst_r = max(worst_r, np.abs(out[k, :3] - r).max())
+                worst_v = max(worst_v, np.abs(out[k, 3:] - v).max())
     assert accepted > 0.8 * total, (accepted, total)
+    assert ecc_total > 0 and ecc_accepted > 0.7 * ecc_total, (ecc_accepted, ecc_total)
     assert worst_r < 1e-6 and worst_v < 1e-9, (worst_r, worst_v)
 
 
