@@ -120,12 +120,13 @@ struct azh_constellation {
     bool have_offsets = false, have_mask = false;
     unsigned cached_n_times = 0;
     int cached_mode = 0;
-    hipStream_t s_main = nullptr, s_deep = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
-    unsigned off_circ = 0; // offset into d_list of the near-earth members in plain catalog order
+    hipStream_t s_main = nullptr, s_deep = nullptr, s_ecc = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    unsigned off_circ = 0, n_circ = 0; // d_list + off_circ: near-earth members in catalog order, [n_circ of eccentricity class 0 | the rest]
     bool timed = false;
     bool timing = true; // record the ev_t0/ev_t1 pair around every launch set (azh_set_timing)
     unsigned tile_sgp4 = 0, tile_sdp4 = 0;
+    bool f32_arith = true; // fp32 outputs: fp32 arithmetic where fast_step_f32.h applies (azh_set_f32_arithmetic)
     bool fast_path = true; // use the branch-free uniform-grid step where it applies (azh_set_fast_path)
 };
 
@@ -162,6 +163,9 @@ void destroy(azh_constellation *c)
     c->d_host_err.release();
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
+    if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+    if (c->s_ecc) (void)hipStreamDestroy(c->s_ecc);
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     if (c->s_main) (void)hipStreamDestroy(c->s_main);
@@ -194,6 +198,9 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
         if (set_device(c) != AZ_OK) { rc = AZ_ERR_HIP; break; }
         if (!hip_ok(hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking), "hipStreamCreate") ||
             !hip_ok(hipStreamCreateWithFlags(&c->s_deep, hipStreamNonBlocking), "hipStreamCreate") ||
+            !hip_ok(hipStreamCreateWithFlags(&c->s_ecc, hipStreamNonBlocking), "hipStreamCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreate(&c->ev_t0), "hipEventCreate") || !hip_ok(hipEventCreate(&c->ev_t1), "hipEventCreate")) {
@@ -265,10 +272,16 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
         for (size_t s = 0; s < n; ++s)
             if (AZ_FLAG_ERR(c->h_flags[s]) != 0) list.push_back((unsigned)s);
         c->n_bad = (unsigned)list.size() - c->n_sgp4 - c->n_sdp4;
-        // the near-earth members once more in plain catalog order (k_rows_fast: neighbouring rows on one XCD)
+        // the near-earth members once more, in catalog order, by eccentricity class: [class 0 | other classes]
+        // (the two instantiations of k_rows_fast)
         c->off_circ = (unsigned)list.size();
         for (size_t s = 0; s < n; ++s)
-            if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && !(c->h_flags[s] & AZ_FLAG_DEEP)) list.push_back((unsigned)s);
+            if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && !(c->h_flags[s] & AZ_FLAG_DEEP) && AZ_FLAG_ECLASS(c->h_flags[s]) == 0)
+                list.push_back((unsigned)s);
+        c->n_circ = (unsigned)list.size() - c->off_circ;
+        for (size_t s = 0; s < n; ++s)
+            if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && !(c->h_flags[s] & AZ_FLAG_DEEP) && AZ_FLAG_ECLASS(c->h_flags[s]) != 0)
+                list.push_back((unsigned)s);
         if (c->d_list.ensure(list.size()) != AZ_OK ||
             !hip_ok(hipMemcpy(c->d_list.p, list.data(), sizeof(unsigned) * list.size(), hipMemcpyHostToDevice), "H2D list")) {
             rc = AZ_ERR_HIP;
@@ -364,30 +377,63 @@ unsigned screen_parts(const PropArgs &a, bool deep)
     return (a.n_times + a.tile - 1) / a.tile;
 }
 
+// second stream for the eccentric-member launch of the row kernels (runs beside the near-circular bulk)
+struct EccSide {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+
 template <bool VEL, bool FRAME>
-void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st)
+void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const EccSide &side = EccSide())
 {
     if (deep) {
         if (a.f32) hipLaunchKernelGGL((k_rows_deep<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_rows_deep<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
     } else if (a.redo_items != nullptr) {
-        // uniform grid: the branch-free kernel first; what it rejects (eccentric members, angles outside their
-        // tier: a few per cent of the segments) is listed and handed to the generic kernel
-        dim3 rgrid(std::min(2048u, grid.x * grid.y), 4);
-        if (a.f32) {
-            hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
-            hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32, true>), rgrid, dim3(64), 0, st, a);
-        } else {
-            hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
-            hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
+        // uniform grid: the branch-free kernels -- eccentric members first (few rows, finer time segments so that
+        // they still fill the chip), then the near-circular bulk; what their validation rejects (an angle outside
+        // its tier: well under one per cent of the segments) is listed and handed to the generic kernel
+        PropArgs e = a, c = a;
+        e.list = a.list + a.n_circ;
+        e.n_list = a.n_list - a.n_circ;
+        e.tile = rows_tile(std::max(e.n_list, 1u), a.n_times, 256);
+        c.n_list = a.n_circ;
+        dim3 egrid((e.n_list + 7) / 8 * 8, (a.n_times + e.tile - 1) / e.tile);
+        dim3 cgrid((c.n_list + 7) / 8 * 8, grid.y);
+        dim3 rgrid(256, 4);
+        // redo items carry (list slot, first, end): slots of the eccentric launch are offset into the common list
+        e.redo_slot0 = a.n_circ;
+        // the eccentric launch is a single short generation of waves: on the same stream it would cost its whole
+        // latency (30 us); on the side stream it runs underneath the bulk launch
+        const bool beside = side.stream != nullptr && e.n_list && c.n_list;
+        hipStream_t se = beside ? side.stream : st;
+        if (beside) {
+            (void)hipEventRecord(side.fork, st);
+            (void)hipStreamWaitEvent(se, side.fork, 0);
         }
+        if (a.f32) {
+            if (e.n_list) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32, true>), egrid, dim3(64), 0, se, e);
+            if (c.n_list) {
+                if (!FRAME && a.arith32) hipLaunchKernelGGL((k_rows_fast32<VEL>), cgrid, dim3(64), 0, st, c);
+                else hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32, false>), cgrid, dim3(64), 0, st, c);
+            }
+        } else {
+            if (e.n_list) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F64, true>), egrid, dim3(64), 0, se, e);
+            if (c.n_list) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F64, false>), cgrid, dim3(64), 0, st, c);
+        }
+        if (beside) {
+            (void)hipEventRecord(side.join, se);
+            (void)hipStreamWaitEvent(st, side.join, 0);
+        }
+        if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32, true>), rgrid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
     } else {
         if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
     }
 }
 
-void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStream_t st)
+void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStream_t st, const EccSide &side = EccSide())
 {
     const bool frame = a.mode != AZ_OUT_TEME;
     if (use_rows(a, layout, deep)) {
@@ -400,11 +446,11 @@ void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStr
             if (deep) hipLaunchKernelGGL((k_rows_deep<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);
             else hipLaunchKernelGGL((k_rows<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);
         } else if (frame) {
-            if (vel) launch_rows2<true, true>(b, grid, deep, st);
-            else launch_rows2<false, true>(b, grid, deep, st);
+            if (vel) launch_rows2<true, true>(b, grid, deep, st, side);
+            else launch_rows2<false, true>(b, grid, deep, st, side);
         } else {
-            if (vel) launch_rows2<true, false>(b, grid, deep, st);
-            else launch_rows2<false, false>(b, grid, deep, st);
+            if (vel) launch_rows2<true, false>(b, grid, deep, st, side);
+            else launch_rows2<false, false>(b, grid, deep, st, side);
         }
         return;
     }
@@ -523,6 +569,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     a.stride_sats = stride;
     a.mode = c->cached_mode;
     a.f32 = f32;
+    a.arith32 = (f32 && c->f32_arith) ? 1 : 0;
     a.g = c->g;
     a.uniform_step = c->fast_path ? c->uniform_step : 0.0;
     a.inc = (a.uniform_step != 0.0) ? c->d_inc.p : nullptr;
@@ -550,8 +597,9 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         if (a.inc != nullptr && use_rows(a, layout, false)) {
             // uniform grid, satellite-major rows: every near-earth member -> k_rows_fast (near-circular or
             // eccentric Kepler form by class); what its validation rejects comes back through the redo list
-            a.list = c->d_list.p + c->off_circ; // catalog order (the first list is ordered for the lane = satellite kernel)
+            a.list = c->d_list.p + c->off_circ; // [class 0 | other classes], catalog order inside each
             a.n_list = c->n_sgp4;
+            a.n_circ = c->n_circ;
             if (c->n_sgp4 > 0) {
                 const unsigned tile = rows_tile(a.n_list, n_times, a.tile_forced);
                 const size_t segs = (n_times + tile - 1) / tile;
@@ -569,7 +617,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
                 c->redo_parity ^= 1u;
             }
         }
-        if (a.n_list > 0) launch_propagate(a, layout, d_vel != nullptr, false, st);
+        if (a.n_list > 0) launch_propagate(a, layout, d_vel != nullptr, false, st, EccSide{c->s_ecc, c->ev_fork2, c->ev_join2});
         HIP_TRY(hipGetLastError());
     }
     if (c->n_bad > 0) {
@@ -811,6 +859,13 @@ int32_t azh_set_timing(azh_constellation *c, int32_t enabled)
     if (!c) return AZ_ERR_NULL_POINTER;
     c->timing = enabled != 0;
     if (!c->timing) c->timed = false;
+    return AZ_OK;
+}
+
+int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t enabled)
+{
+    if (!c) return AZ_ERR_NULL_POINTER;
+    c->f32_arith = enabled != 0;
     return AZ_OK;
 }
 
@@ -1208,6 +1263,7 @@ int32_t azh_synchronize(azh_constellation *c)
     if (!c) return AZ_ERR_NULL_POINTER;
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(c->s_deep));
+    HIP_TRY(hipStreamSynchronize(c->s_ecc));
     HIP_TRY(hipStreamSynchronize(c->s_main));
     return AZ_OK;
 }

@@ -21,6 +21,7 @@
 #include "init_device.h"
 #include "propagate_device.h"
 #include "fast_step.h"
+#include "fast_step_f32.h"
 
 #ifndef AZ_BLOCK
 // 256 satellites per workgroup = four independent waves (no barriers anywhere).  The host orders
@@ -82,6 +83,9 @@ struct PropArgs {
     unsigned row_lo, row_hi;
     // k_rows_fast -> k_rows hand-over: (list slot, first grid point, end) of every segment remainder the fast
     // step rejected
+    int arith32;         // fp32 outputs: fp32 arithmetic for near-circular TEME rows (k_rows_fast32)
+    unsigned n_circ;     // row kernels on a uniform grid: list = [n_circ members of eccentricity class 0 | the rest]
+    unsigned redo_slot0; // added to a k_rows_fast launch's list slots when it files redo items (sub-list launches)
     unsigned *redo_count;
     unsigned *redo_next; // the other launch parity's counter (zeroed by the redo pass for the launch after this one)
     unsigned *redo_items;
@@ -553,6 +557,14 @@ AZ_DEVICE double az_uniform(double x)
                             __builtin_amdgcn_readfirstlane(__double2loint(x)));
 #endif
 }
+AZ_DEVICE float az_uniform32(float x)
+{
+#ifdef AZ_HOST_EMUL
+    return x;
+#else
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+#endif
+}
 // once-per-step constants of a lane = time kernel: one LDS word per constant, read by all 64 lanes
 // at once (broadcast ds_read_b64: no VALU slot, no SGPRs -- the 33 uniform doubles of a satellite do
 // not fit the SGPR file next to the kernel's pointers, and every SGPR spilled to a VGPR lane costs
@@ -563,8 +575,11 @@ struct ColdBroadcast {
     __device__ __forceinline__ void set(int k, double v) const { p[k] = v; }
 };
 #ifndef AZ_ROWSF_WAVES
-#define AZ_ROWSF_WAVES 5 /* k_rows_fast: 91 VGPRs with both Kepler forms (78 = 6 waves/SIMD with the near-circular one only: 2% faster on
-                           a near-circular catalog, but eccentric members would then go through the redo pass at 5x the cost) */
+#define AZ_ROWSF_WAVES 6 /* k_rows_fast, near-circular Kepler form: 78 VGPRs */
+#endif
+#ifndef AZ_ROWSF_ECC_WAVES
+#define AZ_ROWSF_ECC_WAVES 5 /* k_rows_fast, eccentric form: 91 VGPRs (its own instantiation and launch, so that the
+                                 few eccentric members do not cost every wave a sixth of the occupancy) */
 #endif
 #ifndef AZ_ROWS_TLDS
 #define AZ_ROWS_TLDS 1024 /* k_rows: time values staged in LDS per refill (a power of two >= 64) */
@@ -644,13 +659,14 @@ __device__ __forceinline__ void az_rows_store(bool staged, bool full, bool live,
 }
 
 // Near-earth rows on a UNIFORM grid: the branch-free step of fast_step.h, one wave per (satellite row, time
-// segment), lane = time.  91 VGPRs (5 waves/SIMD; the generic k_rows needs 135 = 3): the 18 hot constants sit in
+// segment), lane = time.  78 VGPRs (6 waves/SIMD; the generic k_rows needs 135 = 3): the 18 hot constants sit in
 // SGPRs, the 16 once-per-step ones in LDS (broadcast reads), time is t0 + i*step (no staging, no loads in the
-// loop).  The Kepler form follows the member's eccentricity class (wave-uniform).  A wave whose validation vote
+// loop).  Two instantiations, launched on the host's two near-earth lists: ECC = false for eccentricity class 0
+// (near-circular Kepler form), ECC = true for the other classes (general form).  A wave whose validation vote
 // fails -- an angle outside its tier, a Newton iteration that needs more than five trips -- appends the rest of its
 // segment to the redo list and exits; the generic kernel runs that list afterwards.
-template <bool VEL, bool FRAME, int SINK>
-__global__ void __launch_bounds__(64, AZ_ROWSF_WAVES) k_rows_fast(PropArgs p)
+template <bool VEL, bool FRAME, int SINK, bool ECC>
+__global__ void __launch_bounds__(64, FRAME ? 3 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ_ROWSF_WAVES)) k_rows_fast(PropArgs p)
 {
     typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
     const unsigned lane = threadIdx.x;
@@ -663,8 +679,7 @@ __global__ void __launch_bounds__(64, AZ_ROWSF_WAVES) k_rows_fast(PropArgs p)
     const unsigned t_lo = blockIdx.y * p.tile;
     const unsigned t_hi = min(t_lo + p.tile, p.n_times);
     unsigned base = t_lo;
-    {
-        const bool ecc = AZ_FLAG_ECLASS(fl) != 0; // wave-uniform: which Kepler form the step uses
+    if (ECC || AZ_FLAG_ECLASS(fl) == 0) { // (the near-circular instantiation hands a stray eccentric member to the redo list)
         __shared__ __attribute__((aligned(16))) double cold_lds[FC_NUM];
         __shared__ __attribute__((aligned(16))) out_t rows_stage[AZ_ROWS_LDS_STORE ? 2 * 64 * 3 : 4];
         const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
@@ -704,8 +719,7 @@ __global__ void __launch_bounds__(64, AZ_ROWSF_WAVES) k_rows_fast(PropArgs p)
 #if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
             r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
 #else
-            const bool bad = ecc ? az_sgp4_fast_step<VEL, true>(k, p.g, rk, t, fc, r, v)
-                                 : az_sgp4_fast_step<VEL, false>(k, p.g, rk, t, fc, r, v);
+            const bool bad = az_sgp4_fast_step<VEL, ECC>(k, p.g, rk, t, fc, r, v);
             if (az_any(bad && live)) break;
 #endif
             if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
@@ -718,7 +732,80 @@ __global__ void __launch_bounds__(64, AZ_ROWSF_WAVES) k_rows_fast(PropArgs p)
     if (base < t_hi && lane == 0) {
         // rest of the segment -> generic kernel (one item: list slot, first grid point, end)
         const unsigned k = atomicAdd(p.redo_count, 1u);
-        p.redo_items[3 * (size_t)k + 0] = row;
+        p.redo_items[3 * (size_t)k + 0] = row + p.redo_slot0;
+        p.redo_items[3 * (size_t)k + 1] = base;
+        p.redo_items[3 * (size_t)k + 2] = t_hi;
+    }
+}
+
+// k_rows_fast in fp32 arithmetic (fast_step_f32.h) for fp32 outputs: near-circular members, TEME, uniform grid.
+// All constants are wave-uniform scalars (34 floats + 11 doubles fit the SGPR file); ~60 VGPRs.
+template <bool VEL>
+__global__ void __launch_bounds__(64, 6) k_rows_fast32(PropArgs p)
+{
+    const unsigned lane = threadIdx.x;
+    const unsigned per_xcd = gridDim.x >> 3; // XCD-aware row assignment, see k_rows
+    const unsigned row = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (row >= p.n_list) return;
+    const unsigned s = p.list[row];
+    const unsigned fl = p.flags[s];
+    if ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi) return;
+    const unsigned t_lo = blockIdx.y * p.tile;
+    const unsigned t_hi = min(t_lo + p.tile, p.n_times);
+    unsigned base = t_lo;
+    if (AZ_FLAG_ECLASS(fl) == 0) {
+        __shared__ __attribute__((aligned(16))) float rows_stage[2 * 64 * 3];
+        const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
+        float *prow = reinterpret_cast<float *>(p.pos) + (size_t)s * p.n_times * 3;
+        float *vrow = VEL ? reinterpret_cast<float *>(p.vel) + (size_t)s * p.n_times * 3 : nullptr;
+        const bool staged = AZ_ROWS_LDS_STORE &&
+                            (((reinterpret_cast<size_t>(prow) | (VEL ? reinterpret_cast<size_t>(vrow) : 0)) & 15u) == 0);
+        FastK32 k;
+        {
+            FastK k0;
+            az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k0);
+            FastK32 k1;
+            az_load_fast32(k0, k1);
+#define X(n) k.n##_ = az_uniform32(k1.n##_);
+            AZ_FASTK_COLD(X) AZ_FASTK_HOT(X)
+#undef X
+            k.sab64 = az_uniform(k1.sab64); k.cc1d = az_uniform(k1.cc1d); k.d2d = az_uniform(k1.d2d);
+            k.d3d = az_uniform(k1.d3d); k.d4d = az_uniform(k1.d4d);
+            k.sdA = az_uniform(k1.sdA); k.cdA = az_uniform(k1.cdA); k.sdW = az_uniform(k1.sdW);
+            k.cdW = az_uniform(k1.cdW); k.sdO = az_uniform(k1.sdO); k.cdO = az_uniform(k1.cdO);
+        }
+        const double step = p.uniform_step;
+        const double t_first = p.times[0] + off;
+        FastCarry fc;
+        az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + lane) - 64.0, step, t_first), fc);
+#pragma unroll 1
+        for (; base < t_hi; base += 64) {
+            const unsigned i = base + lane;
+            const bool live = i < t_hi;
+            const double t = fma((double)i, step, t_first);
+            float r[3], v[3];
+            const bool bad = az_sgp4_fast_step_f32<VEL>(k, p.g, t, fc, r, v);
+            if (az_any(bad && live)) break;
+            if (staged && base + 64 <= t_hi) {
+                rows_stage[lane * 3 + 0] = r[0]; rows_stage[lane * 3 + 1] = r[1]; rows_stage[lane * 3 + 2] = r[2];
+                if (VEL) { rows_stage[192 + lane * 3 + 0] = v[0]; rows_stage[192 + lane * 3 + 1] = v[1]; rows_stage[192 + lane * 3 + 2] = v[2]; }
+                az_wave_lds_fence();
+                az_flush_stage(rows_stage, prow + (size_t)base * 3, lane);
+                if (VEL) az_flush_stage(rows_stage + 192, vrow + (size_t)base * 3, lane);
+                az_wave_lds_fence();
+            } else if (live) {
+                const az_f3s a = {r[0], r[1], r[2]};
+                __builtin_nontemporal_store(a, reinterpret_cast<az_f3s *>(prow + (size_t)i * 3));
+                if (VEL) {
+                    const az_f3s b = {v[0], v[1], v[2]};
+                    __builtin_nontemporal_store(b, reinterpret_cast<az_f3s *>(vrow + (size_t)i * 3));
+                }
+            }
+        }
+    }
+    if (base < t_hi && lane == 0) {
+        const unsigned k = atomicAdd(p.redo_count, 1u);
+        p.redo_items[3 * (size_t)k + 0] = row + p.redo_slot0;
         p.redo_items[3 * (size_t)k + 1] = base;
         p.redo_items[3 * (size_t)k + 2] = t_hi;
     }

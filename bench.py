@@ -64,6 +64,11 @@ def parse_args():
     ap.add_argument("--stride-align", type=int, default=0,
                     help="time-major only: round the row length (out_stride_sats) up to a multiple of this many "
                          "satellites (16 = 128-byte aligned rows)")
+    ap.add_argument("--config5-share", action="store_true",
+                    help="BASELINE config 5, one GPU's share: 125,000 synthetic satellites (seed 20260927) x 10,000 one-minute "
+                         "steps, fp32 pos+vel (30 GB), fp32 arithmetic where it applies; parity on sampled rows")
+    ap.add_argument("--f32-rounded", action="store_true",
+                    help="with fp32 outputs: fp64 arithmetic rounded at the store instead of the fp32-arithmetic kernel")
     ap.add_argument("--no-fast-path", action="store_true",
                     help="disable the branch-free uniform-grid step (A/B against the generic tier-voting loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -136,6 +141,10 @@ def csrc_fingerprint():
 
 def main():
     a = parse_args()
+    if a.config5_share:
+        a.sats, a.times, a.f32_out, a.deep = 125000, 10000, True, 0
+        if a.steps == 200 and a.warmup == 100:
+            a.steps, a.warmup = 20, 5
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -174,13 +183,15 @@ def main():
         plan = ShardPlan(n_total, world, a.chunks)
         pairs = [allp[i] for i in plan.local_rows(rank)]
     else:
-        pairs = synth.synth_catalog(n_near=a.sats, n_deep=a.deep, seed=20260926 + 101 * rank)
+        pairs = synth.synth_catalog(n_near=a.sats, n_deep=a.deep, seed=(20260927 if a.config5_share else 20260926) + 101 * rank)
         n_total = len(pairs) * world
     dev = _native.DeviceConstellation.from_tle_lines(pairs, _native.WGS72, local_rank)
     if a.tile:
         dev.set_time_tile(a.tile, a.tile)
     if a.no_fast_path:
         dev.set_fast_path(False)
+    if a.f32_rounded:
+        dev.set_f32_arithmetic(False)
     n_local = dev.n
     offsets = (synth.START_JD - dev.epochs) * 1440.0
     layout = _native.TIME_MAJOR if a.layout == "time" else _native.SAT_MAJOR
@@ -318,7 +329,10 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
 
-    if world == 1:
+    if world == 1 and a.config5_share:
+        wl = "config 5, ONE GPU's share of 8: %d synthetic satellites (seed 20260927) x %d one-minute steps" % (a.sats, n_times)
+        par = "single GPU (1/8 of the 1M-satellite job; shards are independent, no gather)"
+    elif world == 1:
         wl = "config 2: %d-sat synthetic active catalog (SGP4 near-earth%s) x %d one-minute steps" % (
             a.sats, " + %d deep-space SDP4" % a.deep if a.deep else "", n_times)
         par = "single GPU"
@@ -332,18 +346,24 @@ def main():
         wl = "WEAK scaling (--scaling weak): %d GPUs x an own %d-sat synthetic catalog x %d one-minute steps, no gather" % (
             world, a.sats + a.deep, n_times)
         par = "independent catalogs x%d, no data-path collective" % world
-    wl += ", fp64 arithmetic, %s TEME %s, %s-major device-resident output" % (
-        "fp32-stored" if a.f32_out else "fp64", "pos+vel" if vel_on else "pos only", a.layout)
+    arith = "fp64 arithmetic" if not a.f32_out or a.f32_rounded or a.no_fast_path or layout != _native.SAT_MAJOR else \
+        "fp32 arithmetic with fp64 phase and radius chains (near-circular members; fp64 for the rest)"
+    wl += ", %s, %s TEME %s, %s-major device-resident output" % (
+        arith, "fp32-stored" if a.f32_out else "fp64", "pos+vel" if vel_on else "pos only", a.layout)
     if layout == _native.SAT_MAJOR:
         kname = ("k_rows_fast<%s> (branch-free uniform-grid step, one wave per satellite row, lane = time) + k_rows redo pass"
                  if not a.no_fast_path else "k_rows<%s> (one wave per satellite row, lane = time)") % ("pos+vel" if vel_on else "pos")
+        if a.f32_out and not a.f32_rounded and not a.no_fast_path:
+            kname = kname.replace("k_rows_fast<", "k_rows_fast32<")
     else:
         kname = "k_propagate<time-major,%s> (lane = satellite)" % ("pos+vel" if vel_on else "pos")
     out = {
-        "metric": "propagations/sec, 13,478 sats x 1,440 times, at 1/2/4/8 MI355X",
+        "metric": ("propagations/sec, 13,478 sats x 1,440 times, at 1/2/4/8 MI355X" if not a.config5_share else
+                   "propagations/sec, config 5 (1M sats x 10,000 times, fp32, 8 MI355X): one GPU's 125,000-satellite share"),
         "value": value, "unit": "propagations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
-        "scaling": "n/a" if world == 1 else a.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "n/a" if world == 1 else a.scaling, "vs_baseline": None,
+        "dtype": "f64" if "fp64 arithmetic" == arith else "f32 (+f64 phase/radius chains)", "data": "synthetic",
         "config": {
             "workload": wl, "n_sats_total": n_total, "n_sats_per_gpu": n_local, "n_times": n_times, "gather": bool(gather),
             "precondition_ms": a.precondition_ms, "precondition_steps": n_pre,
@@ -368,7 +388,22 @@ def main():
     }
 
     # ---- parity spot-check + CPU baseline (untimed, rank 0, N=1 only) ------------------------
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and a.config5_share:
+        try:
+            from oracle import oracle
+            rows = np.unique(np.linspace(0, n_local - 1, 24).astype(np.int64))
+            cat = oracle.Catalog.from_pairs([pairs[i] for i in rows], oracle.WGS72)
+            _, p0, v0 = cat.propagate(times, offsets[rows], layout=oracle.SAT_MAJOR, threads=usable_cpus())
+            idx = torch.as_tensor(rows, device=cuda)
+            out["parity"] = {"sample_sats": int(len(rows)), "sample": "24 rows spread over the catalog, all 10,000 times, vs the fp64 oracle",
+                             "max_dr_km": float(np.linalg.norm(pos[idx].cpu().numpy().astype(np.float64) - p0, axis=2).max())}
+            if vel_on:
+                out["parity"]["max_dv_kms"] = float(np.linalg.norm(vel[idx].cpu().numpy().astype(np.float64) - v0, axis=2).max())
+            out["cpu_baseline"] = {"value": None, "unit": "propagations/s", "cores": 0, "kind": "port",
+                                   "sample": "not timed for this flag (see the default run's cpu_baseline)"}
+        except Exception as exc:
+            out["parity"] = {"failed": repr(exc)}
+    elif world == 1 and not a.no_cpu_baseline:
         try:
             cb, (n_s, p0, v0) = cpu_baseline(pairs, times, offsets, a.cpu_seconds, layout == _native.SAT_MAJOR)
             out["cpu_baseline"] = cb

@@ -192,9 +192,13 @@ int32_t azh_propagate_device_cached(azh_constellation *c, double *d_pos, double 
  * all-gather (astroz_amd/distributed.py).  No reference counterpart (single process). */
 int32_t azh_propagate_device_window(azh_constellation *c, size_t row_lo, size_t row_hi, double *d_pos, double *d_vel,
                                     int32_t layout, size_t out_stride_sats, uint8_t *d_err, void *stream);
-/* fp32 OUTPUT variants (BASELINE config 5: 1M satellites x 10,000 steps would be 480 GB in fp64):
- * identical fp64 arithmetic, every component rounded once when it is stored; d_pos/d_vel are
- * float arrays of the same shapes.  No reference counterpart (astroz is fp64 only). */
+/* fp32 OUTPUT variants (BASELINE config 5: 1M satellites x 10,000 steps would be 480 GB in fp64); d_pos/d_vel
+ * are float arrays of the same shapes.  No reference counterpart (astroz is fp64 only).  Arithmetic:
+ *   default                      fp32 arithmetic with fp64 phase and radius chains (astroz_amd/csrc/fast_step_f32.h)
+ *                                for near-circular members on uniform grids, satellite-major TEME: positions within
+ *                                metres and velocities within mm/s of the fp64 result; everything else as below;
+ *   azh_set_f32_arithmetic(c,0)  fp64 arithmetic throughout, every component rounded once when it is stored. */
+int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t enabled);
 int32_t azh_propagate_device_f32(azh_constellation *c, const double *times_min, size_t n_times,
                                  const double *epoch_offsets_min, float *d_pos, float *d_vel, int32_t output_mode,
                                  double reference_jd, const uint8_t *sat_mask, int32_t layout,

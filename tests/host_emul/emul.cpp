@@ -12,6 +12,7 @@
 #include "../../astroz_amd/csrc/init_device.h"
 #include "../../astroz_amd/csrc/propagate_device.h"
 #include "../../astroz_amd/csrc/fast_step.h"
+#include "../../astroz_amd/csrc/fast_step_f32.h"
 
 extern "C" {
 
@@ -75,6 +76,28 @@ void emul_propagate_fast(const double* fields, unsigned flags, const double* gra
         bad_out[i] = (ecc ? az_sgp4_fast_step<true, true>(k, g, az_rotk(), ts0 + i * dt, st, r, v)
                           : az_sgp4_fast_step<true, false>(k, g, az_rotk(), ts0 + i * dt, st, r, v)) ? 1 : 0;
         memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
+    }
+}
+
+// the fp32-arithmetic form (fast_step_f32.h), same driving as emul_propagate_fast; out6 stays double (exact widening)
+void emul_propagate_fast32(const double* fields, unsigned flags, const double* grav6, double ts0, double dt, int n,
+                           double* out6, int* bad_out)
+{
+    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
+    double inc[12];
+    const double rate[3] = {fields[F_mdot], fields[F_argpdot], fields[F_nodedot]};
+    for (int which = 0; which < 2; ++which)
+        for (int a = 0; a < 3; ++a) az_sincos(rate[a] * dt, inc[6 * which + 2 * a], inc[6 * which + 2 * a + 1]);
+    FastK k;
+    az_load_fast(fields, 1, 0, flags, inc, 0, k);
+    FastK32 k32;
+    az_load_fast32(k, k32);
+    FastCarry st;
+    az_seed_fast(fields, 1, 0, ts0 - dt, st);
+    for (int i = 0; i < n; ++i) {
+        float r[3], v[3];
+        bad_out[i] = az_sgp4_fast_step_f32<true>(k32, g, ts0 + i * dt, st, r, v) ? 1 : 0;
+        for (int j = 0; j < 3; ++j) { out6[6*i + j] = r[j]; out6[6*i + 3 + j] = v[j]; }
     }
 }
 

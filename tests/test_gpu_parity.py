@@ -190,7 +190,9 @@ def test_output_modes_mask_and_stride(native, orc, synth, layout):
         dev.propagate_host(times, off, pos=pos, vel=vel, mode=mode, reference_jd=ref, layout=lay)
         _, p0, v0 = cat.propagate(times, off, mode=omode, reference_jd=ref, layout=olay)
         if mode == native.OUT_GEODETIC:
-            assert np.abs(pos[..., :2] - p0[..., :2]).max() < 1e-10  # rad
+            assert np.abs(pos[..., 0] - p0[..., 0]).max() < 1e-10     # latitude, rad
+            dlon = pos[..., 1] - p0[..., 1]                           # longitude = atan2(y, x): +pi and -pi are one meridian
+            assert np.abs((dlon + np.pi) % (2.0 * np.pi) - np.pi).max() < 1e-10
             assert np.abs(pos[..., 2] - p0[..., 2]).max() < tol      # km
         else:
             assert np.abs(pos - p0).max() < tol
@@ -293,6 +295,7 @@ def test_fp32_outputs(native, orc, synth, layout):
     torch = _torch_dev()
     pairs = synth.synth_catalog(n_near=700, n_deep=60, seed=31)
     dev, cat = _dev_and_oracle(native, orc, pairs)
+    dev.set_f32_arithmetic(False)   # this test pins the "fp64 arithmetic, rounded once at the store" mode
     times = np.arange(0.0, 500.0, 1.0)
     off = (synth.START_JD - dev.epochs) * 1440.0
     lay = native.TIME_MAJOR if layout == "time_major" else native.SAT_MAJOR
@@ -333,6 +336,7 @@ def test_fp32_config5_shape_properties(native, orc, synth):
     n = 4096
     pairs = synth.synth_catalog(n_near=n, n_deep=0, seed=20260927)
     dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    dev.set_f32_arithmetic(False)   # rounded-fp64 mode (the fp32-arithmetic mode has its own test in test_gpu_round2.py)
     times = np.arange(10000, dtype=np.float64)
     off = (synth.START_JD - dev.epochs) * 1440.0
     p32 = torch.empty((n, len(times), 3), dtype=torch.float32, device="cuda")

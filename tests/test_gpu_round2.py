@@ -83,10 +83,79 @@ def test_fast_path_pos_only_ecef_and_f32(native, orc, synth):
     _, q0, w0 = cat.propagate(times, off, layout=orc.SAT_MAJOR)
     p32 = torch.empty((dev.n, len(times), 3), dtype=torch.float32, device="cuda")
     v32 = torch.empty_like(p32)
+    dev.set_f32_arithmetic(False)   # fast fp64 step + rounded stores
     dev.propagate_device(times, off, p32.data_ptr(), v32.data_ptr(), layout=native.SAT_MAJOR, f32=True)
     dev.synchronize()
     assert np.abs(p32.cpu().numpy() - q0.astype(np.float32)).max() <= 2 * np.spacing(np.float32(8000.0))
     assert np.abs(v32.cpu().numpy() - w0.astype(np.float32)).max() <= 2 * np.spacing(np.float32(8.0))
+
+
+# fp32-ARITHMETIC mode of the fp32 outputs (astroz_amd/csrc/fast_step_f32.h; BASELINE config 5).  The reference is
+# fp64 only and states no fp32 tolerance; the gate here is its own fp64 gate scaled to what fp32 storage can hold:
+# fp32 half-ulp at LEO radius is 0.25 m per component -- positions within 4 m, velocities within 6 mm/s of the oracle
+# (measured: median 0.5 m / 0.8 mm/s, maximum 2.7 m / 3.8 mm/s over 10,000-minute spans).
+F32_TOL_R = 4e-3   # km
+F32_TOL_V = 6e-6   # km/s
+
+
+def test_fp32_arithmetic_vs_oracle(native, orc, synth):
+    import torch
+    pairs = _mixed_class_pairs(synth, 900, seed=61) + synth.synth_catalog(n_near=0, n_deep=20, seed=62)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    times = np.arange(0.0, 1000.0, 1.0)
+    off = (synth.START_JD - dev.epochs) * 1440.0
+    _, p0, v0 = cat.propagate(times, off, layout=orc.SAT_MAJOR, threads=8)
+    p32 = torch.full((dev.n, len(times), 3), float("nan"), dtype=torch.float32, device="cuda")
+    v32 = torch.full_like(p32, float("nan"))
+    torch.cuda.synchronize()
+    dev.propagate_device(times, off, p32.data_ptr(), v32.data_ptr(), layout=native.SAT_MAJOR, f32=True)
+    dev.synchronize()
+    p, v = p32.cpu().numpy().astype(np.float64), v32.cpu().numpy().astype(np.float64)
+    assert np.isfinite(p).all() and np.isfinite(v).all()
+    dr = np.linalg.norm(p - p0, axis=2)
+    dv = np.linalg.norm(v - v0, axis=2)
+    deep = cat.is_deep
+    assert dr[~deep].max() < F32_TOL_R and dv[~deep].max() < F32_TOL_V, (dr[~deep].max(), dv[~deep].max())
+    # deep-space rows (fp64 arithmetic, rounded stores): storage precision at GEO radius
+    assert dr[deep].max() < 2 * np.spacing(np.float32(45000.0))
+    # the two modes agree to the same tolerance; the fp32-arithmetic one is NOT bit-identical to rounded fp64
+    dev.set_f32_arithmetic(False)
+    q32 = torch.empty_like(p32)
+    dev.propagate_device(times, off, q32.data_ptr(), None, layout=native.SAT_MAJOR, f32=True)
+    dev.synchronize()
+    q = q32.cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(q - p, axis=2).max() < F32_TOL_R
+    assert np.abs(q - p0).max() <= 0.5 * np.spacing(np.float32(np.abs(p0).max())) + 1e-6
+
+
+def test_fp32_arithmetic_config5_geometry(native, orc, synth):
+    """Config 5 geometry (10,000 one-minute steps, fp32 pos+vel, satellite-major) in the fp32-arithmetic mode:
+    sampled rows against the oracle over the whole week, range properties and a bit-identical repeat."""
+    import torch
+    n = 4096
+    pairs = synth.synth_catalog(n_near=n, n_deep=0, seed=20260927)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    times = np.arange(10000, dtype=np.float64)
+    off = (synth.START_JD - dev.epochs) * 1440.0
+    p32 = torch.empty((n, len(times), 3), dtype=torch.float32, device="cuda")
+    v32 = torch.empty_like(p32)
+    torch.cuda.synchronize()
+    dev.propagate_device(times, off, p32.data_ptr(), v32.data_ptr(), layout=native.SAT_MAJOR, f32=True)
+    dev.synchronize()
+    chk1 = (p32.double().sum().item(), v32.double().sum().item())
+    rr = torch.linalg.norm(p32.double(), dim=2)
+    assert torch.isfinite(rr).all() and rr.min().item() > 6200.0 and rr.max().item() < 6378.135 * 4.0
+    rows = np.array([0, 1, 63, 64, 777, 1500, 2048, 3333, n - 1])
+    cat = orc.Catalog.from_pairs([pairs[i] for i in rows], 1)
+    _, p0, v0 = cat.propagate(times, off[rows], layout=orc.SAT_MAJOR, threads=4)
+    ps = p32[torch.as_tensor(rows, device="cuda")].cpu().numpy().astype(np.float64)
+    vs = v32[torch.as_tensor(rows, device="cuda")].cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(ps - p0, axis=2).max() < F32_TOL_R
+    assert np.linalg.norm(vs - v0, axis=2).max() < F32_TOL_V
+    dev.propagate_device_cached(p32.data_ptr(), v32.data_ptr(), layout=native.SAT_MAJOR, f32=True)
+    dev.synchronize()
+    assert (p32.double().sum().item(), v32.double().sum().item()) == chk1
 
 
 def test_row_window_launches_tile_the_full_launch(native, synth):
