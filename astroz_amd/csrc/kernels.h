@@ -784,8 +784,15 @@ __global__ void __launch_bounds__(64, 6) k_rows_fast32(PropArgs p)
             const bool live = i < t_hi;
             const double t = fma((double)i, step, t_first);
             float r[3], v[3];
+#if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
+            r[0] = (float)t; r[1] = r[0] + 1.0f; r[2] = r[0] + 2.0f; v[0] = r[0] + 3.0f; v[1] = r[0] + 4.0f; v[2] = r[0] + 5.0f;
+#else
             const bool bad = az_sgp4_fast_step_f32<VEL>(k, p.g, t, fc, r, v);
             if (az_any(bad && live)) break;
+#endif
+#if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only (every component stays live) */
+            if (!(live && (r[0] + r[1] + r[2] + (VEL ? v[0] + v[1] + v[2] : 0.0f)) == 1.2345e30f)) continue;
+#endif
             if (staged && base + 64 <= t_hi) {
                 rows_stage[lane * 3 + 0] = r[0]; rows_stage[lane * 3 + 1] = r[1]; rows_stage[lane * 3 + 2] = r[2];
                 if (VEL) { rows_stage[192 + lane * 3 + 0] = v[0]; rows_stage[192 + lane * 3 + 1] = v[1]; rows_stage[192 + lane * 3 + 2] = v[2]; }
