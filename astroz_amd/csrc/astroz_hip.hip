@@ -102,7 +102,7 @@ struct azh_constellation {
     DevBuf<double> d_times, d_offsets, d_sin, d_cos, d_seeds;
     DevBuf<unsigned> d_redo;    // k_rows_fast -> k_rows redo list: [0],[1] item counters (alternating launches), [4..] (slot, first, end) triples
     unsigned redo_parity = 0;
-    DevBuf<double> d_inc;       // uniform grids: per-satellite rotation increments (k_prep_inc), [12][n_pad]
+    DevBuf<double> d_inc;       // uniform grids: per-satellite rotation increments (k_prep_inc), [2 * AZ_INC_NUM][n_pad]
     double uniform_step = 0.0;  // step of the staged grid if it is uniform, else 0
     DevBuf<double> d_tgt, d_part_d2, d_out_d; // fused screen: target track, partial minima, results
     DevBuf<unsigned> d_part_t, d_out_t;
@@ -396,10 +396,15 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const
         PropArgs e = a, c = a;
         e.list = a.list + a.n_circ;
         e.n_list = a.n_list - a.n_circ;
-        e.tile = rows_tile(std::max(e.n_list, 1u), a.n_times, 256);
         c.n_list = a.n_circ;
+        // a wave's time window must stay short enough for the window-centred constants of the fast step (the node
+        // moves ~6e-5 rad/min: +-1,500 minutes keep it inside the 1/8-rad rotation tier)
+        const double span = 3000.0 / std::max(std::fabs(a.uniform_step), 1e-9);
+        const unsigned cap = span >= 4.0e9 ? 0xffffffc0u : std::max(64u, (unsigned)span / 64u * 64u);
+        e.tile = std::min(rows_tile(std::max(e.n_list, 1u), a.n_times, 256), cap);
+        c.tile = std::min(a.tile, cap);
         dim3 egrid((e.n_list + 7) / 8 * 8, (a.n_times + e.tile - 1) / e.tile);
-        dim3 cgrid((c.n_list + 7) / 8 * 8, grid.y);
+        dim3 cgrid((c.n_list + 7) / 8 * 8, (a.n_times + c.tile - 1) / c.tile);
         dim3 rgrid(256, 4);
         // redo items carry (list slot, first, end): slots of the eccentric launch are offset into the common list
         e.redo_slot0 = a.n_circ;
@@ -506,7 +511,7 @@ int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, 
         bool uni = std::isfinite(step) && step != 0.0;
         for (size_t i = 1; uni && i < n_times; ++i) uni = std::fabs(times[i] - (t0 + (double)i * step)) <= tol;
         if (uni) {
-            if (c->d_inc.ensure((size_t)12 * c->n_pad) != AZ_OK) return AZ_ERR_HIP;
+            if (c->d_inc.ensure((size_t)2 * AZ_INC_NUM * c->n_pad) != AZ_OK) return AZ_ERR_HIP;
             hipLaunchKernelGGL(k_prep_inc, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, st, c->d_el, c->n, c->n_pad,
                                step, c->d_inc.p);
             HIP_TRY(hipGetLastError());
@@ -601,8 +606,8 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
             a.n_list = c->n_sgp4;
             a.n_circ = c->n_circ;
             if (c->n_sgp4 > 0) {
-                const unsigned tile = rows_tile(a.n_list, n_times, a.tile_forced);
-                const size_t segs = (n_times + tile - 1) / tile;
+                // every wave of the fast launches may file one item; their segments are never shorter than 64 points
+                const size_t segs = ((size_t)n_times + 63) / 64;
                 if (!c->d_redo.p) {
                     if (c->d_redo.ensure(4 + 3 * segs * c->n_sgp4) != AZ_OK) return AZ_ERR_HIP;
                     HIP_TRY(hipMemsetAsync(c->d_redo.p, 0, 4 * sizeof(unsigned), st)); // the redo kernel re-arms it

@@ -24,7 +24,7 @@
     X(cc1) X(d2) X(d3) X(d4) X(nl2) X(nl3) X(nl4) X(nl5) X(eta) X(omgcof) X(xmcof) X(xd) X(bc4) X(bc5) X(ecb) X(sab)
 #define AZ_FASTK_HOT(X)                                                                                      \
     X(aycof) X(xlcof) X(xnodcf) X(sinio) X(cosio) X(k_mrt) X(k_c2u) X(k_su) X(k_node) X(k_inc) X(x1mth2) X(k_rv) \
-    X(sdA) X(cdA) X(sdW) X(cdW) X(sdO) X(cdO)
+    X(sdA) X(cdA) X(sdW) X(cdW) X(tc) X(sdU) X(cdU) X(tmid) X(nodedot) X(sOc) X(cOc)
 enum FastCold {
 #define X(n) FC_##n,
     AZ_FASTK_COLD(X)
@@ -56,15 +56,22 @@ struct FastKBcast {
 #undef X
 };
 
-// carried (sin,cos) pairs: M = mo + mdot t, W = argpo + argpdot t, O = nodeo + nodedot t (the
-// xnodcf t^2 part of the node is folded into the J2 node correction, a tiny rotation anyway)
+// carried (sin,cos) pairs: M = mo + mdot t, W = argpo + argpdot t, and
+// U = M + W + the part of the along-track drag phase kappa t^2 (kappa = no_unkozai t2cof) that is LINEAR about
+// the centre tc of the wave's time window:  kappa t^2 = kappa tc^2 + 2 kappa tc (t - tc) + kappa (t - tc)^2.
+// The first two terms ride on U (a linear phase: constant increment), only kappa (t - tc)^2 stays in the small
+// rotation of the step -- so a high-drag member a week from epoch (kappa t^2 of a radian) is as cheap and as
+// valid as a fresh one.  tc = 0 (the plain form U = M + W) whenever kappa t^2 is small over the whole window.
+// The node needs no carried pair at all: it moves by a few hundredths of a radian across a window, so (sin,cos) of the node at
+// the window centre tmid are per-window constants and nodedot (t - tmid), like the secular xnodcf t^2, rides on
+// the J2 short-period rotation of the node (one FMA).
 struct FastCarry {
-    double sA, cA, sW, cW, sO, cO;
+    double sA, cA, sW, cW, sU, cU;
 };
 
-// row offsets of the increment table written by k_prep_inc: inc[(AZ_INC_* + 6*which) * n_pad + sat],
+// row offsets of the increment table written by k_prep_inc: inc[(AZ_INC_* + AZ_INC_NUM*which) * n_pad + sat],
 // which = 0: dt = 64 grid steps (lane = time kernels), 1: dt = one grid step (lane = satellite kernels)
-enum { AZ_INC_sdA, AZ_INC_cdA, AZ_INC_sdW, AZ_INC_cdW, AZ_INC_sdO, AZ_INC_cdO, AZ_INC_NUM };
+enum { AZ_INC_sdA, AZ_INC_cdA, AZ_INC_sdW, AZ_INC_cdW, AZ_INC_NUM };
 
 AZ_DEVICE void az_load_fast(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags,
                             const double *__restrict__ inc, int which, FastK &k)
@@ -87,21 +94,50 @@ AZ_DEVICE void az_load_fast(const double *__restrict__ el, size_t n_pad, size_t 
     az_j2_factors(L(con41), L(x1mth2), L(x7thm1), k.sinio_, k.cosio_, k.k_mrt_, k.k_c2u_, k.k_su_, k.k_node_,
                   k.k_inc_, k.k_rv_);
     k.x1mth2_ = L(x1mth2);
-    const double *q = inc + (size_t)(6 * which) * n_pad + i;
+    const double *q = inc + (size_t)(AZ_INC_NUM * which) * n_pad + i;
     k.sdA_ = q[(size_t)AZ_INC_sdA * n_pad]; k.cdA_ = q[(size_t)AZ_INC_cdA * n_pad];
     k.sdW_ = q[(size_t)AZ_INC_sdW * n_pad]; k.cdW_ = q[(size_t)AZ_INC_cdW * n_pad];
-    k.sdO_ = q[(size_t)AZ_INC_sdO * n_pad]; k.cdO_ = q[(size_t)AZ_INC_cdO * n_pad];
+    k.nodedot_ = L(nodedot);
+#undef L
+}
+
+// Window set-up: the centre tc about which the drag phase is expanded and the increment (sin,cos) of U for
+// steps of dt.  [t_a, t_b]: the tsince range of the window (any order).  Wave-uniform in the lane = time kernels.
+template <class K>
+AZ_DEVICE void az_fast_window(const double *__restrict__ el, size_t n_pad, size_t i, double t_a, double t_b, double dt, K &k)
+{
+#define L(f) el[(size_t)F_##f * n_pad + i]
+    const double kappa = L(no_unkozai) * L(t2cof);
+    const double tmax = fmax(fabs(t_a), fabs(t_b));
+    k.tmid_ = 0.5 * (t_a + t_b);
+    az_sincos(fma(k.nodedot_, k.tmid_, L(nodeo)), k.sOc_, k.cOc_);
+    if (!az_any(fabs(kappa) * tmax * tmax > 0.05)) {
+        // U = M + W: its increment is the sum of the two increments
+        k.tc_ = 0.0;
+        k.sdU_ = fma(k.sdA_, k.cdW_, k.cdA_ * k.sdW_);
+        k.cdU_ = fma(k.cdA_, k.cdW_, -(k.sdA_ * k.sdW_));
+    } else {
+        k.tc_ = 0.5 * (t_a + t_b);
+        az_sincos((L(mdot) + L(argpdot) + 2.0 * kappa * k.tc_) * dt, k.sdU_, k.cdU_);
+    }
 #undef L
 }
 
 // seed the carried pairs with full sincos at time t (the step BEFORE the first one to be produced: every
-// az_sgp4_fast_step call first advances the pairs by one increment)
-AZ_DEVICE void az_seed_fast(const double *__restrict__ el, size_t n_pad, size_t i, double t, FastCarry &st)
+// az_sgp4_fast_step call first advances the pairs by one increment); tc from az_fast_window
+AZ_DEVICE void az_seed_fast(const double *__restrict__ el, size_t n_pad, size_t i, double t, double tc, FastCarry &st)
 {
 #define L(f) el[(size_t)F_##f * n_pad + i]
     az_sincos(fma(L(mdot), t, L(mo)), st.sA, st.cA);
     az_sincos(fma(L(argpdot), t, L(argpo)), st.sW, st.cW);
-    az_sincos(fma(L(nodedot), t, L(nodeo)), st.sO, st.cO);
+    if (!az_any(tc != 0.0)) {
+        st.sU = fma(st.sA, st.cW, st.cA * st.sW);
+        st.cU = fma(st.cA, st.cW, -(st.sA * st.sW));
+    } else {
+        const double kappa = L(no_unkozai) * L(t2cof);
+        // (mo + argpo - kappa tc^2) + (mdot + argpdot + 2 kappa tc) t
+        az_sincos(fma(L(mdot) + L(argpdot) + 2.0 * kappa * tc, t, L(mo) + L(argpo) - kappa * tc * tc), st.sU, st.cU);
+    }
 #undef L
 }
 
@@ -113,37 +149,73 @@ AZ_DEVICE void az_rot_apply2(double &s, double &c, double p, double q)
     c = fma(-s, p, fma(c, q, c));
     s = ns;
 }
+// Taylor coefficients of the rotation polynomials, read through an accessor: literals (the compiler keeps them
+// where it likes: lane = satellite kernels, host emulation) or LDS words read by all lanes at once.  v_fma_f64
+// takes no 64-bit literal and one scalar operand, so a Horner chain's constants otherwise end up parked in VGPRs
+// for the whole loop -- 8 coefficients = 16 VGPRs, a sixth wave per SIMD in k_rows_fast.
+enum RotCoef { RC_n6, RC_p24, RC_p120, RC_n720, RC_n5040, RC_p40320, RC_p362880, RC_n3628800, RC_NUM };
+struct RotCoefLit {
+    AZ_MEMBER double operator()(int k) const
+    {
+        return k == RC_n6 ? -1.0 / 6.0 : k == RC_p24 ? 1.0 / 24.0 : k == RC_p120 ? 1.0 / 120.0 : k == RC_n720 ? -1.0 / 720.0
+             : k == RC_n5040 ? -1.0 / 5040.0 : k == RC_p40320 ? 1.0 / 40320.0 : k == RC_p362880 ? 1.0 / 362880.0
+             : -1.0 / 3628800.0;
+    }
+};
+struct RotCoefLds {
+    const double *p;
+    AZ_MEMBER double operator()(int k) const { return p[k]; }
+};
+template <class W>
+AZ_DEVICE void az_rotcoef_store(W write)
+{
+    const RotCoefLit lit;
+#pragma unroll
+    for (int k = 0; k < RC_NUM; ++k) write(k, lit(k));
+}
+
 // |d| <= 2^-10: sin to d^3, cos to d^2 (dropped d^4/24 < 3.8e-14, d^5/120 < 8e-18)
-AZ_DEVICE void az_rotate_tiny2(double &s, double &c, double d, const RotK &k)
+template <class RC>
+AZ_DEVICE void az_rotate_tiny2(double &s, double &c, double d, const RC &k)
 {
     const double d2 = d * d;
     const double q = -0.5 * d2;
-    const double p = fma(d2 * k.n6, d, d);
+    const double p = fma(d2 * k(RC_n6), d, d);
     az_rot_apply2(s, c, p, q);
 }
-
-// (p,q) = (sin d, cos d - 1) for |d| <= 1/16: sin to d^7, cos to d^8 (d^9/9! < 3e-17, d^10/10! < 3e-19).
-// Two instructions more than the 2^-7 tier; used for delomg + delm, which reaches 2^-7 for one member in fifty.
-#define AZ_ROT_16TH 0.0625
-AZ_DEVICE void az_pq_16th(double d, const RotK &k, double &p, double &q)
+// (p,q) = (sin d, cos d - 1) of the 2^-7 tier (the polynomial of devmath.h's az_pq_small)
+template <class RC>
+AZ_DEVICE void az_fpq_small(double d, const RC &k, double &p, double &q)
 {
     const double d2 = d * d;
-    q = d2 * fma(d2, fma(d2, fma(d2, 1.0 / 40320.0, k.n720), k.p24), -0.5);
-    p = d * fma(d2, fma(d2, fma(d2, -1.0 / 5040.0, k.p120), k.n6), 1.0);
+    q = d2 * fma(d2, fma(d2, k(RC_n720), k(RC_p24)), -0.5);
+    p = d * fma(d2, fma(d2, k(RC_p120), k(RC_n6)), 1.0);
 }
 
-// (p,q) for |d| <= 1/8: sin to d^9, cos to d^10 (the polynomial of az_rotate_med).  The along-track drag term
-// no*templ grows with t^2: 1/8 rad holds 99.4% of a catalog up to six days from epoch.
-AZ_DEVICE void az_pq_med(double d, double &p, double &q)
+// (p,q) for |d| <= 1/16: sin to d^7, cos to d^8 (d^9/9! < 3e-17, d^10/10! < 3e-19).
+// Two instructions more than the 2^-7 tier; used for delomg + delm, which reaches 2^-7 for one member in fifty.
+#define AZ_ROT_16TH 0.0625
+template <class RC>
+AZ_DEVICE void az_pq_16th(double d, const RC &k, double &p, double &q)
 {
     const double d2 = d * d;
-    q = fma(d2, -1.0 / 3628800.0, 1.0 / 40320.0);
-    q = fma(d2, q, -1.0 / 720.0);
-    q = fma(d2, q, 1.0 / 24.0);
+    q = d2 * fma(d2, fma(d2, fma(d2, k(RC_p40320), k(RC_n720)), k(RC_p24)), -0.5);
+    p = d * fma(d2, fma(d2, fma(d2, k(RC_n5040), k(RC_p120)), k(RC_n6)), 1.0);
+}
+
+// (p,q) for |d| <= 1/8: sin to d^9, cos to d^10 (the polynomial of az_rotate_med).  Used for the rest of the
+// along-track drag term and for the node's motion across a time window.
+template <class RC>
+AZ_DEVICE void az_pq_med(double d, const RC &k, double &p, double &q)
+{
+    const double d2 = d * d;
+    q = fma(d2, k(RC_n3628800), k(RC_p40320));
+    q = fma(d2, q, k(RC_n720));
+    q = fma(d2, q, k(RC_p24));
     q = d2 * fma(d2, q, -0.5);
-    p = fma(d2, 1.0 / 362880.0, -1.0 / 5040.0);
-    p = fma(d2, p, 1.0 / 120.0);
-    p = fma(d2, p, -1.0 / 6.0);
+    p = fma(d2, k(RC_p362880), k(RC_n5040));
+    p = fma(d2, p, k(RC_p120));
+    p = fma(d2, p, k(RC_n6));
     p = d * fma(d2, p, 1.0);
 }
 
@@ -153,8 +225,8 @@ AZ_DEVICE void az_pq_med(double d, double &p, double &q)
 
 // one near-earth propagation on a uniform grid; returns true when an assumption of the fast path does
 // not hold for this lane (the caller must then discard r/v and use az_sgp4_step)
-template <bool VEL, bool ECC = false, class K = FastK>
-AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, double t, FastCarry &st, double r[3],
+template <bool VEL, bool ECC = false, class K = FastK, class RC = RotCoefLit>
+AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, double t, FastCarry &st, double r[3],
                                   double v[3])
 {
     // advance the carried pairs by their constant increments
@@ -165,9 +237,9 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, do
         const double nsW = fma(st.sW, k.cdW(), st.cW * k.sdW());
         st.cW = fma(st.cW, k.cdW(), -(st.sW * k.sdW()));
         st.sW = nsW;
-        const double nsO = fma(st.sO, k.cdO(), st.cO * k.sdO());
-        st.cO = fma(st.cO, k.cdO(), -(st.sO * k.sdO()));
-        st.sO = nsO;
+        const double nsU = fma(st.sU, k.cdU(), st.cU * k.sdU());
+        st.cU = fma(st.cU, k.cdU(), -(st.sU * k.sdU()));
+        st.sU = nsU;
     }
     const double sA = st.sA, cA = st.cA;
     const double t2 = t * t;
@@ -176,7 +248,9 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, do
     const double dm = fma(k.eta(), cA, 1.0);
     const double th = fma(k.xmcof(), dm * dm * dm, fma(k.omgcof(), t, -k.xd())); // delomg + delm
     const double tempa = fma(-t, fma(t, fma(t, fma(t, k.d4(), k.d3()), k.d2()), k.cc1()), 1.0);
-    const double nl = t2 * fma(t, fma(t, fma(t, k.nl5(), k.nl4()), k.nl3()), k.nl2()); // no_unkozai * templ
+    // no_unkozai * templ without the part carried by U: kappa (t - tc)^2 + t^3 (nl3 + t (nl4 + t nl5))
+    const double dtc = t - k.tc();
+    const double nl = fma(k.nl2() * dtc, dtc, t2 * (t * fma(t, fma(t, k.nl5(), k.nl4()), k.nl3())));
     bool bad = !(fabs(th) <= AZ_ROT_16TH);
     double p, q;
     az_pq_16th(th, rk, p, q);
@@ -195,13 +269,12 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, do
 
     const double axnl = em * cw;
     const double aynl = fma(em, sw, temp * k.aycof());
-    // u0 = M + W + no*templ + temp*xlcof*axnl
-    double s = fma(sA, st.cW, cA * st.sW);
-    double c = fma(cA, st.cW, -(sA * st.sW));
+    // u0 = U + (rest of no*templ) + temp*xlcof*axnl
+    double s = st.sU, c = st.cU;
     {
         const double eps = fma(temp * k.xlcof(), axnl, nl);
         bad |= !(fabs(eps) <= AZ_ROT_MED);
-        az_pq_med(eps, p, q);
+        az_pq_med(eps, rk, p, q);
         az_rot_apply2(s, c, p, q);
     }
 
@@ -213,7 +286,7 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, do
         bad |= !(el2 <= AZ_FAST_EL2);
         const double rden = az_rcp1(fma(-s, aynl, fma(-c, axnl, 1.0)));
         const double d0 = fma(axnl, s, -(aynl * c)) * rden;
-        az_pq_small(d0, rk, p, q); // |d0| <= el/(1-el) < 2^-7
+        az_fpq_small(d0, rk, p, q); // |d0| <= el/(1-el) < 2^-7
         az_rot_apply2(s, c, p, q);
         const double d1 = fma(axnl, s, fma(-aynl, c, -d0)) * rden;
         {
@@ -245,11 +318,11 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, do
                 az_rotate_large(s, c, d);
             } else if (it == 1) {
                 bad |= !(fabs(d) <= AZ_ROT_MED);
-                az_pq_med(d, p, q);
+                az_pq_med(d, rk, p, q);
                 az_rot_apply2(s, c, p, q);
             } else {
                 bad |= !(fabs(d) <= AZ_ROT_SMALL);
-                az_pq_small(d, rk, p, q);
+                az_fpq_small(d, rk, p, q);
                 az_rot_apply2(s, c, p, q);
             }
         }
@@ -282,13 +355,13 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RotK &rk, do
 
     const double mrt = fma(rl, fma(k.k_mrt() * temp2, betal, 1.0), k.k_c2u() * temp1 * cos2u);
     const double t2s = temp2 * sin2u;
-    // J2 short-period corrections as tiny rotations (each bounded by 1.5 temp2 <= 9e-4); the secular
-    // xnodcf t^2 part of the node rides on the node correction
-    const double a_nd = fma(k.k_node(), t2s, k.xnodcf() * t2);
-    bad |= !(fabs(a_nd) <= AZ_ROT_SMALL);
-    double ssu = sinu, csu = cosu, sn = st.sO, cn = st.cO, si = k.sinio(), ci = k.cosio();
+    // J2 short-period corrections as tiny rotations (each bounded by 1.5 temp2 <= 9e-4); the node's own motion
+    // about the window centre, nodedot (t - tmid) + xnodcf t^2, rides on the node correction
+    const double a_nd = fma(k.k_node(), t2s, fma(k.nodedot(), t - k.tmid(), k.xnodcf() * t2));
+    bad |= !(fabs(a_nd) <= AZ_ROT_MED);
+    double ssu = sinu, csu = cosu, sn = k.sOc(), cn = k.cOc(), si = k.sinio(), ci = k.cosio();
     az_rotate_tiny2(ssu, csu, k.k_su() * t2s, rk);
-    az_pq_small(a_nd, rk, p, q); // the node correction carries the secular xnodcf t^2 term: one tier up
+    az_pq_med(a_nd, rk, p, q); // J2 correction + the node's motion across the window (up to ~0.03 rad over +-400 min)
     az_rot_apply2(sn, cn, p, q);
     az_rotate_tiny2(si, ci, k.k_inc() * temp2 * cos2u, rk);
 

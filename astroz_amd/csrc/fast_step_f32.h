@@ -1,8 +1,8 @@
 // fast_step_f32.h -- the branch-free uniform-grid step (fast_step.h) in fp32 arithmetic, for fp32 OUTPUTS
 // (BASELINE config 5: 1M satellites x 10,000 steps, an HBM-bound stress case; the reference itself is fp64 only).
 //
-// What stays fp64: the three carried angle pairs (their phase runs to hundreds of radians over 10,000 minutes:
-// 12 fp64 instructions per step), the angle addition that forms the Newton start u0 = M + W (4), and the
+// What stays fp64: the three carried angle pairs M, W, U (their phase runs to hundreds of radians over 10,000
+// minutes: 12 fp64 instructions per step) and the
 // along-radius chain a -> r (the semi-major axis, 1 - e cos E and the J2 radius factor: ~12) -- together ~30 fp64
 // instructions.  Everything else -- drag polynomials, Kepler step, short-period terms, orientation, velocity --
 // is fp32 (v_fma_f32 issues at twice the fp64 rate on gfx950; v_rcp_f32 needs no refinement at this precision):
@@ -17,7 +17,7 @@ struct FastK32 {
     AZ_FASTK_COLD(X) AZ_FASTK_HOT(X)
 #undef X
     double sab64, cc1d, d2d, d3d, d4d;  // fp64: the along-radius chain (sqrt(a_base), drag polynomial of the semi-major axis)
-    double sdA, cdA, sdW, cdW, sdO, cdO; // fp64: the carried-angle increments
+    double sdA, cdA, sdW, cdW, sdU, cdU, tc, tmid; // fp64: the carried-angle increments, window centres
 };
 
 AZ_DEVICE void az_load_fast32(const FastK &k, FastK32 &f)
@@ -26,7 +26,8 @@ AZ_DEVICE void az_load_fast32(const FastK &k, FastK32 &f)
     AZ_FASTK_COLD(X) AZ_FASTK_HOT(X)
 #undef X
     f.sab64 = k.sab_; f.cc1d = k.cc1_; f.d2d = k.d2_; f.d3d = k.d3_; f.d4d = k.d4_;
-    f.sdA = k.sdA_; f.cdA = k.cdA_; f.sdW = k.sdW_; f.cdW = k.cdW_; f.sdO = k.sdO_; f.cdO = k.cdO_;
+    f.sdA = k.sdA_; f.cdA = k.cdA_; f.sdW = k.sdW_; f.cdW = k.cdW_;
+    f.sdU = k.sdU_; f.cdU = k.cdU_; f.tc = k.tc_; f.tmid = k.tmid_;
 }
 
 #ifdef AZ_HOST_EMUL
@@ -75,9 +76,9 @@ AZ_DEVICE bool az_sgp4_fast_step_f32(const FastK32 &k, const AzGrav &g, double t
         const double nsW = fma(st.sW, k.cdW, st.cW * k.sdW);
         st.cW = fma(st.cW, k.cdW, -(st.sW * k.sdW));
         st.sW = nsW;
-        const double nsO = fma(st.sO, k.cdO, st.cO * k.sdO);
-        st.cO = fma(st.cO, k.cdO, -(st.sO * k.sdO));
-        st.sO = nsO;
+        const double nsU = fma(st.sU, k.cdU, st.cU * k.sdU);
+        st.cU = fma(st.cU, k.cdU, -(st.sU * k.sdU));
+        st.sU = nsU;
     }
     const float t = (float)t64;
     const float sA = (float)st.sA, cA = (float)st.cA, sW = (float)st.sW, cW = (float)st.cW;
@@ -86,7 +87,8 @@ AZ_DEVICE bool az_sgp4_fast_step_f32(const FastK32 &k, const AzGrav &g, double t
     const float dm = fmaf(k.eta_, cA, 1.0f);
     const float th = fmaf(k.xmcof_, dm * dm * dm, fmaf(k.omgcof_, t, -k.xd_));
     const double tempa64 = fma(-t64, fma(t64, fma(t64, fma(t64, k.d4d, k.d3d), k.d2d), k.cc1d), 1.0);
-    const float nl = t2 * fmaf(t, fmaf(t, fmaf(t, k.nl5_, k.nl4_), k.nl3_), k.nl2_);
+    const float dtc = (float)(t64 - k.tc);
+    const float nl = fmaf(k.nl2_ * dtc, dtc, t2 * (t * fmaf(t, fmaf(t, k.nl5_, k.nl4_), k.nl3_)));
     bool bad = !(fabsf(th) <= (float)AZ_ROT_16TH);
     float smm = sA, cmm = cA, sw = sW, cw = cW;
     az_rot32_med(smm, cmm, th);
@@ -104,9 +106,8 @@ AZ_DEVICE bool az_sgp4_fast_step_f32(const FastK32 &k, const AzGrav &g, double t
 
     const float axnl = em * cw;
     const float aynl = fmaf(em, sw, temp * k.aycof_);
-    // u0 = M + W (+ drag/long-period term): the angle addition in fp64, then fp32
-    float s = (float)fma(st.sA, st.cW, st.cA * st.sW);
-    float c = (float)fma(st.cA, st.cW, -(st.sA * st.sW));
+    // u0 = U (carried in fp64) + the rest of the drag term + the long-period term
+    float s = (float)st.sU, c = (float)st.cU;
     {
         const float eps = fmaf(temp * k.xlcof_, axnl, nl);
         bad |= !(fabsf(eps) <= (float)AZ_ROT_MED);
@@ -145,11 +146,11 @@ AZ_DEVICE bool az_sgp4_fast_step_f32(const FastK32 &k, const AzGrav &g, double t
     const double rl64 = am64 * (1.0 - (double)ecose);
     const double mrt64 = fma(rl64, (double)fmaf(k.k_mrt_ * temp2, betal, 1.0f), (double)(k.k_c2u_ * temp1 * cos2u));
     const float t2s = temp2 * sin2u;
-    const float a_nd = fmaf(k.k_node_, t2s, k.xnodcf_ * t2);
-    bad |= !(fabsf(a_nd) <= (float)AZ_ROT_SMALL);
-    float ssu = sinu, csu = cosu, sn = (float)st.sO, cn = (float)st.cO, si = k.sinio_, ci = k.cosio_;
+    const float a_nd = fmaf(k.k_node_, t2s, fmaf(k.nodedot_, (float)(t64 - k.tmid), k.xnodcf_ * t2));
+    bad |= !(fabsf(a_nd) <= (float)AZ_ROT_MED);
+    float ssu = sinu, csu = cosu, sn = k.sOc_, cn = k.cOc_, si = k.sinio_, ci = k.cosio_;
     az_rot32_tiny(ssu, csu, k.k_su_ * t2s);
-    az_rot32_small(sn, cn, a_nd);
+    az_rot32_med(sn, cn, a_nd);
     az_rot32_tiny(si, ci, k.k_inc_ * temp2 * cos2u);
 
     const float xmx = -sn * ci, xmy = cn * ci;

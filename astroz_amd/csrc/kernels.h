@@ -379,8 +379,9 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
     if (!DEEP && p.inc != nullptr && p.uniform_step != 0.0 && !az_any(AZ_FLAG_ECLASS(fl) != 0)) {
         FastK k;
         az_load_fast(p.el, p.n_pad, s, fl, p.inc, 1, k);
+        az_fast_window(p.el, p.n_pad, s, p.times[t0] + off, p.times[t1 - 1] + off, p.uniform_step, k);
         FastCarry fc;
-        az_seed_fast(p.el, p.n_pad, s, p.times[t0] + off - p.uniform_step, fc);
+        az_seed_fast(p.el, p.n_pad, s, p.times[t0] + off - p.uniform_step, k.tc_, fc);
 #pragma unroll 1
         for (; i < t1; ++i) {
             const double t = time_at(i);
@@ -388,7 +389,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
 #if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
             r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
 #else
-            const bool bad = az_sgp4_fast_step<VEL, false>(k, p.g, rk, t, fc, r, v);
+            const bool bad = az_sgp4_fast_step<VEL, false>(k, p.g, RotCoefLit(), t, fc, r, v);
             if (az_any(bad && in_range)) break;
 #endif
             emit(i, r, v, 0);
@@ -575,11 +576,11 @@ struct ColdBroadcast {
     __device__ __forceinline__ void set(int k, double v) const { p[k] = v; }
 };
 #ifndef AZ_ROWSF_WAVES
-#define AZ_ROWSF_WAVES 6 /* k_rows_fast, near-circular Kepler form: 78 VGPRs */
+#define AZ_ROWSF_WAVES 6 /* k_rows_fast, near-circular Kepler form: 68 VGPRs (7 waves/SIMD fit) */
 #endif
 #ifndef AZ_ROWSF_ECC_WAVES
-#define AZ_ROWSF_ECC_WAVES 5 /* k_rows_fast, eccentric form: 91 VGPRs (its own instantiation and launch, so that the
-                                 few eccentric members do not cost every wave a sixth of the occupancy) */
+#define AZ_ROWSF_ECC_WAVES 4 /* k_rows_fast, eccentric form: ~100 VGPRs (its own instantiation and launch, so that the
+                                 few eccentric members do not cost every wave of the bulk its occupancy) */
 #endif
 #ifndef AZ_ROWS_TLDS
 #define AZ_ROWS_TLDS 1024 /* k_rows: time values staged in LDS per refill (a power of two >= 64) */
@@ -666,7 +667,7 @@ __device__ __forceinline__ void az_rows_store(bool staged, bool full, bool live,
 // fails -- an angle outside its tier, a Newton iteration that needs more than five trips -- appends the rest of its
 // segment to the redo list and exits; the generic kernel runs that list afterwards.
 template <bool VEL, bool FRAME, int SINK, bool ECC>
-__global__ void __launch_bounds__(64, FRAME ? 3 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ_ROWSF_WAVES)) k_rows_fast(PropArgs p)
+__global__ void __launch_bounds__(64, FRAME ? 2 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ_ROWSF_WAVES)) k_rows_fast(PropArgs p)
 {
     typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
     const unsigned lane = threadIdx.x;
@@ -680,10 +681,10 @@ __global__ void __launch_bounds__(64, FRAME ? 3 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
     const unsigned t_hi = min(t_lo + p.tile, p.n_times);
     unsigned base = t_lo;
     if (ECC || AZ_FLAG_ECLASS(fl) == 0) { // (the near-circular instantiation hands a stray eccentric member to the redo list)
-        __shared__ __attribute__((aligned(16))) double cold_lds[FC_NUM];
+        __shared__ __attribute__((aligned(16))) double cold_lds[FC_NUM + RC_NUM];
         __shared__ __attribute__((aligned(16))) out_t rows_stage[AZ_ROWS_LDS_STORE ? 2 * 64 * 3 : 4];
         const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
-        const RotK rk = az_rotk();
+        if (lane == 0) az_rotcoef_store([&](int k, double v) { cold_lds[FC_NUM + k] = v; });
         out_t *prow = reinterpret_cast<out_t *>(p.pos) + (size_t)s * p.n_times * 3;
         out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + (size_t)s * p.n_times * 3 : nullptr;
         const bool staged = AZ_ROWS_LDS_STORE &&
@@ -692,6 +693,8 @@ __global__ void __launch_bounds__(64, FRAME ? 3 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
         {
             FastK k0;
             az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k0);
+            az_fast_window(p.el, p.n_pad, s, fma((double)t_lo, p.uniform_step, p.times[0] + off),
+                           fma((double)(t_hi - 1), p.uniform_step, p.times[0] + off), 64.0 * p.uniform_step, k0);
 #define X(n) if (lane == 0) cold_lds[FC_##n] = k0.n##_;
             AZ_FASTK_COLD(X)
 #undef X
@@ -704,7 +707,7 @@ __global__ void __launch_bounds__(64, FRAME ? 3 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
         const double t_first = p.times[0] + off; // tsince of grid point 0; grid point i is t_first + i*step
         FastCarry fc;
         // seed one increment (64 grid steps) BEFORE this lane's first grid point
-        az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + lane) - 64.0, step, t_first), fc);
+        az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, fc);
 #pragma unroll 1
         for (; base < t_hi; base += 64) {
             const unsigned i = base + lane;
@@ -715,6 +718,7 @@ __global__ void __launch_bounds__(64, FRAME ? 3 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
             unsigned zero = 0;
             asm volatile("" : "+s"(zero));
             k.cold = cold_lds + zero;
+            const RotCoefLds rk{cold_lds + FC_NUM + zero};
             double r[3], v[3];
 #if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
             r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
@@ -741,7 +745,7 @@ __global__ void __launch_bounds__(64, FRAME ? 3 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
 // k_rows_fast in fp32 arithmetic (fast_step_f32.h) for fp32 outputs: near-circular members, TEME, uniform grid.
 // All constants are wave-uniform scalars (34 floats + 11 doubles fit the SGPR file); ~60 VGPRs.
 template <bool VEL>
-__global__ void __launch_bounds__(64, 6) k_rows_fast32(PropArgs p)
+__global__ void __launch_bounds__(64, 5) k_rows_fast32(PropArgs p)
 {
     const unsigned lane = threadIdx.x;
     const unsigned per_xcd = gridDim.x >> 3; // XCD-aware row assignment, see k_rows
@@ -764,6 +768,8 @@ __global__ void __launch_bounds__(64, 6) k_rows_fast32(PropArgs p)
         {
             FastK k0;
             az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k0);
+            az_fast_window(p.el, p.n_pad, s, fma((double)t_lo, p.uniform_step, p.times[0] + off),
+                           fma((double)(t_hi - 1), p.uniform_step, p.times[0] + off), 64.0 * p.uniform_step, k0);
             FastK32 k1;
             az_load_fast32(k0, k1);
 #define X(n) k.n##_ = az_uniform32(k1.n##_);
@@ -772,12 +778,13 @@ __global__ void __launch_bounds__(64, 6) k_rows_fast32(PropArgs p)
             k.sab64 = az_uniform(k1.sab64); k.cc1d = az_uniform(k1.cc1d); k.d2d = az_uniform(k1.d2d);
             k.d3d = az_uniform(k1.d3d); k.d4d = az_uniform(k1.d4d);
             k.sdA = az_uniform(k1.sdA); k.cdA = az_uniform(k1.cdA); k.sdW = az_uniform(k1.sdW);
-            k.cdW = az_uniform(k1.cdW); k.sdO = az_uniform(k1.sdO); k.cdO = az_uniform(k1.cdO);
+            k.cdW = az_uniform(k1.cdW); k.tmid = az_uniform(k1.tmid);
+            k.sdU = az_uniform(k1.sdU); k.cdU = az_uniform(k1.cdU); k.tc = az_uniform(k1.tc);
         }
         const double step = p.uniform_step;
         const double t_first = p.times[0] + off;
         FastCarry fc;
-        az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + lane) - 64.0, step, t_first), fc);
+        az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc, fc);
 #pragma unroll 1
         for (; base < t_hi; base += 64) {
             const unsigned i = base + lane;
@@ -1233,23 +1240,22 @@ __global__ void k_gmst(const double *times, unsigned n, double reference_jd, dou
     cos_g[i] = cos(gm);
 }
 
-// uniform time grid: (sin,cos) of the per-step increments of the three secular angles, per satellite,
+// uniform time grid: (sin,cos) of the per-step increments of the mean anomaly and the argument of perigee, per satellite,
 // for the two lane mappings (fast_step.h).  One lane per satellite, once per staged grid.
 __global__ void __launch_bounds__(256) k_prep_inc(const double *el, size_t n, size_t n_pad, double step, double *inc)
 {
     const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
-    const double rate[3] = {el[(size_t)F_mdot * n_pad + s], el[(size_t)F_argpdot * n_pad + s],
-                            el[(size_t)F_nodedot * n_pad + s]};
+    const double rate[2] = {el[(size_t)F_mdot * n_pad + s], el[(size_t)F_argpdot * n_pad + s]};
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
         const double dt = which == 0 ? 64.0 * step : step;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < 2; ++a) {
             double sn, cs;
             az_sincos(rate[a] * dt, sn, cs);
-            inc[(size_t)(6 * which + 2 * a) * n_pad + s] = sn;
-            inc[(size_t)(6 * which + 2 * a + 1) * n_pad + s] = cs;
+            inc[(size_t)(AZ_INC_NUM * which + 2 * a) * n_pad + s] = sn;
+            inc[(size_t)(AZ_INC_NUM * which + 2 * a + 1) * n_pad + s] = cs;
         }
     }
 }

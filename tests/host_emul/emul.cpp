@@ -57,48 +57,52 @@ void emul_propagate(const double* fields, unsigned flags, const double* grav6, c
     }
 }
 
-// the branch-free uniform-grid step (fast_step.h) as one lane of the lane = time kernel runs it: seeded one
-// increment before ts0, then n steps of `dt` minutes.  bad_out[i] = the step's validation predicate.
+// the branch-free uniform-grid step (fast_step.h) as one lane of the lane = time kernel runs it: windows of 12
+// steps of `dt` minutes (a 768-point segment of k_rows_fast), each seeded one increment before its first step.
+// bad_out[i] = the step's validation predicate.  f32 = 1: the fp32-arithmetic form (fast_step_f32.h).
+static void emul_fast_run(const double* fields, unsigned flags, const double* grav6, double ts0, double dt, int n, int ecc,
+                          int f32, double* out6, int* bad_out)
+{
+    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
+    double inc[2 * AZ_INC_NUM];
+    const double rate[2] = {fields[F_mdot], fields[F_argpdot]};
+    for (int which = 0; which < 2; ++which)
+        for (int a = 0; a < 2; ++a) az_sincos(rate[a] * dt, inc[AZ_INC_NUM * which + 2 * a], inc[AZ_INC_NUM * which + 2 * a + 1]);
+    // window length as the host picks it: at most 12 steps (768 grid points) and at most ~3,000 minutes
+    int wlen = (int)(3000.0 / (dt < 0 ? -dt : dt));
+    wlen = wlen < 1 ? 1 : (wlen > 12 ? 12 : wlen);
+    for (int w0 = 0; w0 < n; w0 += wlen) {
+        const int w1 = (w0 + wlen < n) ? w0 + wlen : n;
+        FastK k;
+        az_load_fast(fields, 1, 0, flags, inc, 0, k);
+        az_fast_window(fields, 1, 0, ts0 + w0 * dt, ts0 + (w1 - 1) * dt, dt, k);
+        FastK32 k32;
+        az_load_fast32(k, k32);
+        FastCarry st;
+        az_seed_fast(fields, 1, 0, ts0 + (w0 - 1) * dt, k.tc_, st);
+        for (int i = w0; i < w1; ++i) {
+            if (f32) {
+                float r[3], v[3];
+                bad_out[i] = az_sgp4_fast_step_f32<true>(k32, g, ts0 + i * dt, st, r, v) ? 1 : 0;
+                for (int j = 0; j < 3; ++j) { out6[6*i + j] = r[j]; out6[6*i + 3 + j] = v[j]; }
+            } else {
+                double r[3], v[3];
+                bad_out[i] = (ecc ? az_sgp4_fast_step<true, true>(k, g, RotCoefLit(), ts0 + i * dt, st, r, v)
+                                  : az_sgp4_fast_step<true, false>(k, g, RotCoefLit(), ts0 + i * dt, st, r, v)) ? 1 : 0;
+                memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
+            }
+        }
+    }
+}
 void emul_propagate_fast(const double* fields, unsigned flags, const double* grav6, double ts0, double dt, int n,
                          int ecc, double* out6, int* bad_out)
 {
-    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
-    double inc[12];
-    const double rate[3] = {fields[F_mdot], fields[F_argpdot], fields[F_nodedot]};
-    for (int which = 0; which < 2; ++which)
-        for (int a = 0; a < 3; ++a) az_sincos(rate[a] * dt, inc[6 * which + 2 * a], inc[6 * which + 2 * a + 1]);
-    FastK k;
-    az_load_fast(fields, 1, 0, flags, inc, 0, k);
-    FastCarry st;
-    az_seed_fast(fields, 1, 0, ts0 - dt, st);
-    for (int i = 0; i < n; ++i) {
-        double r[3], v[3];
-        bad_out[i] = (ecc ? az_sgp4_fast_step<true, true>(k, g, az_rotk(), ts0 + i * dt, st, r, v)
-                          : az_sgp4_fast_step<true, false>(k, g, az_rotk(), ts0 + i * dt, st, r, v)) ? 1 : 0;
-        memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
-    }
+    emul_fast_run(fields, flags, grav6, ts0, dt, n, ecc, 0, out6, bad_out);
 }
-
-// the fp32-arithmetic form (fast_step_f32.h), same driving as emul_propagate_fast; out6 stays double (exact widening)
 void emul_propagate_fast32(const double* fields, unsigned flags, const double* grav6, double ts0, double dt, int n,
                            double* out6, int* bad_out)
 {
-    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
-    double inc[12];
-    const double rate[3] = {fields[F_mdot], fields[F_argpdot], fields[F_nodedot]};
-    for (int which = 0; which < 2; ++which)
-        for (int a = 0; a < 3; ++a) az_sincos(rate[a] * dt, inc[6 * which + 2 * a], inc[6 * which + 2 * a + 1]);
-    FastK k;
-    az_load_fast(fields, 1, 0, flags, inc, 0, k);
-    FastK32 k32;
-    az_load_fast32(k, k32);
-    FastCarry st;
-    az_seed_fast(fields, 1, 0, ts0 - dt, st);
-    for (int i = 0; i < n; ++i) {
-        float r[3], v[3];
-        bad_out[i] = az_sgp4_fast_step_f32<true>(k32, g, ts0 + i * dt, st, r, v) ? 1 : 0;
-        for (int j = 0; j < 3; ++j) { out6[6*i + j] = r[j]; out6[6*i + 3 + j] = v[j]; }
-    }
+    emul_fast_run(fields, flags, grav6, ts0, dt, n, 0, 1, out6, bad_out);
 }
 
 void emul_sincos(double x, double* s, double* c) { az_sincos(x, *s, *c); }
