@@ -32,7 +32,10 @@ EXPORTS = [
     "azh_last_kernel_ms", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
     "azh_screen_target_host", "azh_screen_target_device", "azh_coarse_screen_device", "azh_coarse_screen_host",
     "azh_screen_all_host", "azh_constellation_from_omm_json", "azh_propagate_one_device", "azh_selftest_math",
-    "azh_parse_tle_text", "azh_parse_omm_json", "coords_julian_to_gmst", "coords_eci_to_ecef", "coords_ecef_to_geodetic",
+    "azh_parse_tle_text", "azh_parse_omm_json", "coords_julian_to_gmst",
+    "azh_group_create_from_tle_text", "azh_group_create_from_omm_json", "azh_group_free", "azh_group_num_satellites",
+    "azh_group_num_devices", "azh_group_padded_rows", "azh_group_get_epochs", "azh_group_propagate_host",
+    "azh_group_propagate_allgather", "coords_eci_to_ecef", "coords_ecef_to_geodetic",
 ]
 
 
@@ -110,6 +113,22 @@ def lib():
     for f in ("azh_parse_tle_text", "azh_parse_omm_json"):
         getattr(L, f).argtypes = [C.c_char_p, sz, vp, sz, C.POINTER(sz)]
         getattr(L, f).restype = i32
+    for f in ("azh_group_create_from_tle_text", "azh_group_create_from_omm_json"):
+        getattr(L, f).argtypes = [C.c_char_p, sz, i32, vp, i32, i32, C.POINTER(vp)]
+        getattr(L, f).restype = i32
+    L.azh_group_free.argtypes = [vp]
+    L.azh_group_num_satellites.argtypes = [vp]
+    L.azh_group_num_satellites.restype = sz
+    L.azh_group_num_devices.argtypes = [vp]
+    L.azh_group_num_devices.restype = i32
+    L.azh_group_padded_rows.argtypes = [vp]
+    L.azh_group_padded_rows.restype = sz
+    L.azh_group_get_epochs.argtypes = [vp, vp]
+    L.azh_group_get_epochs.restype = i32
+    L.azh_group_propagate_host.argtypes = [vp, vp, sz, vp, vp, vp, i32, dbl, vp]
+    L.azh_group_propagate_host.restype = i32
+    L.azh_group_propagate_allgather.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.azh_group_propagate_allgather.restype = i32
     L.azh_constellation_from_omm_json.argtypes = [C.c_char_p, sz, i32, i32, C.POINTER(vp)]
     L.azh_constellation_from_omm_json.restype = i32
     L.azh_propagate_one_device.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp]
@@ -396,6 +415,56 @@ class DeviceConstellation:
 
     def last_kernel_ms(self):
         return lib().azh_last_kernel_ms(self._h)
+
+
+class DeviceGroup:
+    """azh_group: one catalog over several GPUs of this process (the C-host route to N devices; Python hosts with
+    one process per GPU use astroz_amd.distributed instead)."""
+
+    def __init__(self, text, devices, grav=WGS72, n_chunks=4):
+        b = text.encode() if isinstance(text, str) else bytes(text)
+        dv = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        fn = lib().azh_group_create_from_omm_json if b.lstrip()[:1] in (b"{", b"[") else lib().azh_group_create_from_tle_text
+        check(fn(b, len(b), grav, dv, len(devices), n_chunks, C.byref(h)), "azh_group_create")
+        self._h = h
+        self.n = lib().azh_group_num_satellites(h)
+        self.n_devices = lib().azh_group_num_devices(h)
+        self.padded_rows = lib().azh_group_padded_rows(h)
+        self.epochs = np.empty(self.n)
+        check(lib().azh_group_get_epochs(h, self.epochs.ctypes.data), "azh_group_get_epochs")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().azh_group_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def propagate_host(self, times_min, offsets_min=None, *, velocities=True, mode=OUT_TEME, reference_jd=0.0, errors=False):
+        """-> pos (n, n_times, 3)[, vel][, err (n, n_times) u8], catalog order, host arrays."""
+        t = _f64(times_min)
+        off = None if offsets_min is None else _f64(offsets_min)
+        pos = np.empty((self.n, len(t), 3))
+        vel = np.empty_like(pos) if velocities else None
+        err = np.zeros((self.n, len(t)), dtype=np.uint8) if errors else None
+        check(lib().azh_group_propagate_host(self._h, t.ctypes.data, len(t), _ptr(off), pos.ctypes.data, _ptr(vel), mode,
+                                             float(reference_jd), _ptr(err)), "azh_group_propagate_host")
+        return pos, vel, err
+
+    def propagate_allgather(self, times_min, offsets_min, d_pos_ptrs, d_vel_ptrs=None):
+        """Full TEME arrays on every device: d_pos_ptrs[i] = raw device pointer on devices[i] to
+        padded_rows x n_times x 3 doubles."""
+        t = _f64(times_min)
+        off = None if offsets_min is None else _f64(offsets_min)
+        pp = (C.c_void_p * self.n_devices)(*d_pos_ptrs)
+        vv = (C.c_void_p * self.n_devices)(*d_vel_ptrs) if d_vel_ptrs is not None else None
+        check(lib().azh_group_propagate_allgather(self._h, t.ctypes.data, len(t), _ptr(off), pp, vv),
+              "azh_group_propagate_allgather")
 
 
 def parse_tle_lines(line1, line2):

@@ -3,6 +3,8 @@
 #include "../../include/astroz_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and prototypes only: librccl is loaded on first use (azh_group_propagate_allgather)
 
 #include <algorithm>
 #include <cmath>
@@ -1330,6 +1332,269 @@ int32_t azh_selftest_math(const double *x, size_t n, double *out6n, int32_t devi
             rc = AZ_ERR_HIP;
     }
     (void)hipFree(d);
+    return rc;
+}
+
+// ======================================================================================= multi-GPU group
+// One process, N devices (a Zig / C host has no torch.distributed): block-cyclic satellite shards -- the same plan
+// as astroz_amd/distributed.py's ShardPlan -- one azh_constellation per device.  A host-memory result needs no
+// collective at all (every device copies its blocks straight into the caller's catalog-ordered array over its own
+// PCIe link); a result that must be resident on EVERY device is re-assembled by RCCL all-gathers over xGMI,
+// chunk-pipelined against the propagation of the next chunk.  The reference has no counterpart
+// (single process, std.Thread: src/Constellation.zig L327-385).
+struct azh_group {
+    int n_dev = 0;
+    size_t n = 0, rows = 0, n_chunks = 1;
+    std::vector<int> devices;
+    std::vector<azh_constellation *> shard;
+    std::vector<std::vector<uint32_t>> members; // catalog rows of every shard, ascending (== local order)
+    std::vector<std::vector<double>> off_stage; // per-shard epoch offsets of the call in flight (source of an async H2D)
+    std::vector<ncclComm_t> comms;              // created on the first all-gather
+    std::vector<hipStream_t> s_comm;
+    std::vector<hipEvent_t> ev;
+    size_t cell_lo(size_t chunk, int d) const { return std::min((chunk * n_dev + d) * rows, n); }
+    size_t cell_hi(size_t chunk, int d) const { return std::min((chunk * n_dev + d) * rows + rows, n); }
+    size_t padded() const { return n_chunks * n_dev * rows; }
+};
+
+namespace {
+
+struct Rccl {
+    void *h = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy already mapped into the process (PyTorch ships its own) is picked up by SONAME
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.h) break;
+        }
+        if (!r.h) return;
+#define AZ_SYM(f) r.f = reinterpret_cast<decltype(r.f)>(dlsym(r.h, "nccl" #f))
+        AZ_SYM(CommInitAll); AZ_SYM(CommDestroy); AZ_SYM(AllGather); AZ_SYM(GroupStart); AZ_SYM(GroupEnd); AZ_SYM(GetErrorString);
+#undef AZ_SYM
+        r.ok = r.CommInitAll && r.CommDestroy && r.AllGather && r.GroupStart && r.GroupEnd;
+    });
+    return r;
+}
+
+bool nccl_ok(ncclResult_t e, const char *what)
+{
+    if (e == ncclSuccess) return true;
+    g_last_error = std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(e) : "RCCL error");
+    return false;
+}
+
+void group_destroy(azh_group *g)
+{
+    if (!g) return;
+    for (size_t d = 0; d < g->comms.size(); ++d)
+        if (g->comms[d]) (void)rccl().CommDestroy(g->comms[d]);
+    for (int d = 0; d < (int)g->s_comm.size(); ++d) {
+        (void)hipSetDevice(g->devices[d]);
+        if (g->s_comm[d]) (void)hipStreamDestroy(g->s_comm[d]);
+        if (d < (int)g->ev.size() && g->ev[d]) (void)hipEventDestroy(g->ev[d]);
+    }
+    for (azh_constellation *c : g->shard) destroy(c);
+    delete g;
+}
+
+int32_t group_build(const std::vector<azh::TleRecord> &recs, int grav, const int32_t *devices, int32_t n_devices,
+                    int32_t n_chunks, azh_group **out)
+{
+    if (!devices || !out) return AZ_ERR_NULL_POINTER;
+    *out = nullptr;
+    if (n_devices < 1 || n_chunks < 1 || recs.empty()) return AZ_ERR_VALUE;
+    azh_group *g = new (std::nothrow) azh_group();
+    if (!g) return AZ_ERR_ALLOC_FAILED;
+    g->n_dev = n_devices;
+    g->n = recs.size();
+    g->devices.assign(devices, devices + n_devices);
+    // ShardPlan: rows per (chunk, device) cell, a multiple of 64; chunks that would be pure padding are dropped
+    const size_t cells = (size_t)n_devices * (size_t)n_chunks;
+    g->rows = ((g->n + cells - 1) / cells + 63) / 64 * 64;
+    g->n_chunks = std::max<size_t>(1, std::min<size_t>((size_t)n_chunks, (g->n + n_devices * g->rows - 1) / (n_devices * g->rows)));
+    g->shard.assign(n_devices, nullptr);
+    g->members.resize(n_devices);
+    g->off_stage.resize(n_devices);
+    int32_t rc = AZ_OK;
+    for (int d = 0; d < n_devices && rc == AZ_OK; ++d) {
+        std::vector<azh::TleRecord> mine;
+        for (size_t c = 0; c < g->n_chunks; ++c)
+            for (size_t r = g->cell_lo(c, d); r < g->cell_hi(c, d); ++r) {
+                mine.push_back(recs[r]);
+                g->members[d].push_back((uint32_t)r);
+            }
+        if (mine.empty()) continue; // more devices than 64-satellite cells
+        rc = build_from_records(mine, grav, devices[d], &g->shard[d]);
+    }
+    if (rc != AZ_OK) {
+        group_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return AZ_OK;
+}
+
+// stage one shard's inputs and (optionally) launch all of it into its grow-only local blocks
+int32_t group_stage(azh_group *g, int d, const double *times, size_t n_times, const double *offsets, int32_t mode,
+                    double reference_jd, bool want_vel, bool want_err)
+{
+    azh_constellation *c = g->shard[d];
+    if (!c) return AZ_OK;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    std::vector<double> &off = g->off_stage[d]; // outlives the asynchronous upload (the callers synchronise before returning)
+    if (offsets) {
+        off.resize(c->n);
+        for (size_t i = 0; i < c->n; ++i) off[i] = offsets[g->members[d][i]];
+    }
+    const size_t cap = g->n_chunks * g->rows * n_times * 3; // cells padded to `rows`: the all-gather needs equal blocks
+    if (c->d_host_pos.ensure(cap) != AZ_OK || (want_vel && c->d_host_vel.ensure(cap) != AZ_OK) ||
+        (want_err && c->d_host_err.ensure(c->n * n_times) != AZ_OK))
+        return AZ_ERR_HIP;
+    return stage_inputs(c, times, n_times, offsets ? off.data() : nullptr, nullptr, mode, reference_jd, c->s_main);
+}
+
+} // namespace
+
+int32_t azh_group_create_from_tle_text(const char *text, size_t len, int32_t grav, const int32_t *devices,
+                                       int32_t n_devices, int32_t n_chunks, azh_group **out)
+{
+    if (!text) return AZ_ERR_NULL_POINTER;
+    std::vector<azh::TleRecord> recs;
+    azh::parse_all(std::string_view(text, len), recs);
+    if (recs.empty()) return AZ_ERR_BAD_TLE_LENGTH;
+    return group_build(recs, grav, devices, n_devices, n_chunks, out);
+}
+
+int32_t azh_group_create_from_omm_json(const char *text, size_t len, int32_t grav, const int32_t *devices,
+                                       int32_t n_devices, int32_t n_chunks, azh_group **out)
+{
+    if (!text) return AZ_ERR_NULL_POINTER;
+    std::vector<azh::TleRecord> recs;
+    const int rc = azh::parse_omm_json(std::string_view(text, len), recs);
+    if (rc == -1 || (rc == 0 && recs.empty())) return AZ_ERR_BAD_TLE_LENGTH;
+    if (rc != 0) return AZ_ERR_VALUE;
+    return group_build(recs, grav, devices, n_devices, n_chunks, out);
+}
+
+void azh_group_free(azh_group *g) { group_destroy(g); }
+size_t azh_group_num_satellites(const azh_group *g) { return g ? g->n : 0; }
+int32_t azh_group_num_devices(const azh_group *g) { return g ? g->n_dev : 0; }
+size_t azh_group_padded_rows(const azh_group *g) { return g ? g->padded() : 0; }
+
+int32_t azh_group_get_epochs(const azh_group *g, double *out)
+{
+    if (!g || !out) return AZ_ERR_NULL_POINTER;
+    for (int d = 0; d < g->n_dev; ++d)
+        if (g->shard[d])
+            for (size_t i = 0; i < g->shard[d]->n; ++i) out[g->members[d][i]] = g->shard[d]->h_epoch[i];
+    return AZ_OK;
+}
+
+int32_t azh_group_propagate_host(azh_group *g, const double *times, size_t n_times, const double *offsets, double *pos,
+                                 double *vel, int32_t mode, double reference_jd, uint8_t *err)
+{
+    if (!g || !pos || (n_times && !times)) return AZ_ERR_NULL_POINTER;
+    if (mode < 0 || mode > 2) return AZ_ERR_VALUE;
+    if (n_times == 0) return AZ_OK;
+    const size_t row = n_times * 3;
+    int32_t rc = AZ_OK;
+    // enqueue everything on every device first (asynchronous), then wait: the devices run side by side
+    for (int d = 0; d < g->n_dev && rc == AZ_OK; ++d) {
+        azh_constellation *c = g->shard[d];
+        if (!c) continue;
+        if ((rc = group_stage(g, d, times, n_times, offsets, mode, reference_jd, vel != nullptr, err != nullptr)) != AZ_OK) break;
+        rc = launch_all(c, c->d_host_pos.p, vel ? c->d_host_vel.p : nullptr, AZ_LAYOUT_SAT_MAJOR, 0,
+                        err ? c->d_host_err.p : nullptr, c->s_main);
+        if (rc != AZ_OK) break;
+        // a cell = consecutive catalog rows = consecutive local rows: one copy per cell and array
+        size_t local = 0;
+        for (size_t k = 0; k < g->n_chunks && rc == AZ_OK; ++k) {
+            const size_t lo = g->cell_lo(k, d), cnt = g->cell_hi(k, d) - lo;
+            if (!cnt) continue;
+            if (!hip_ok(hipMemcpyAsync(pos + lo * row, c->d_host_pos.p + local * row, cnt * row * sizeof(double), hipMemcpyDeviceToHost, c->s_main), "D2H pos") ||
+                (vel && !hip_ok(hipMemcpyAsync(vel + lo * row, c->d_host_vel.p + local * row, cnt * row * sizeof(double), hipMemcpyDeviceToHost, c->s_main), "D2H vel")) ||
+                (err && !hip_ok(hipMemcpyAsync(err + lo * n_times, c->d_host_err.p + local * n_times, cnt * n_times, hipMemcpyDeviceToHost, c->s_main), "D2H err")))
+                rc = AZ_ERR_HIP;
+            local += cnt;
+        }
+    }
+    for (int d = 0; d < g->n_dev; ++d) {
+        azh_constellation *c = g->shard[d];
+        if (!c) continue;
+        if (set_device(c) != AZ_OK || !hip_ok(hipStreamSynchronize(c->s_main), "sync") || !hip_ok(hipStreamSynchronize(c->s_deep), "sync"))
+            rc = rc == AZ_OK ? AZ_ERR_HIP : rc;
+    }
+    return rc;
+}
+
+int32_t azh_group_propagate_allgather(azh_group *g, const double *times, size_t n_times, const double *offsets,
+                                      double *const *d_pos, double *const *d_vel)
+{
+    if (!g || !d_pos || (n_times && !times)) return AZ_ERR_NULL_POINTER;
+    if (n_times == 0) return AZ_OK;
+    for (int d = 0; d < g->n_dev; ++d)
+        if (!g->shard[d]) { g_last_error = "more devices than 64-satellite cells"; return AZ_ERR_VALUE; }
+    Rccl &R = rccl();
+    if (!R.ok) { g_last_error = "librccl.so could not be loaded"; return AZ_ERR_HIP; }
+    if (g->comms.empty()) {
+        g->comms.assign(g->n_dev, nullptr);
+        if (!nccl_ok(R.CommInitAll(g->comms.data(), g->n_dev, g->devices.data()), "ncclCommInitAll")) { g->comms.clear(); return AZ_ERR_HIP; }
+        g->s_comm.assign(g->n_dev, nullptr);
+        g->ev.assign(g->n_dev, nullptr);
+        for (int d = 0; d < g->n_dev; ++d) {
+            HIP_TRY(hipSetDevice(g->devices[d]));
+            HIP_TRY(hipStreamCreateWithFlags(&g->s_comm[d], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&g->ev[d], hipEventDisableTiming));
+        }
+    }
+    const size_t row = n_times * 3, cell = g->rows * row;
+    int32_t rc = AZ_OK;
+    for (int d = 0; d < g->n_dev && rc == AZ_OK; ++d)
+        rc = group_stage(g, d, times, n_times, offsets, AZ_OUT_TEME, 0.0, d_vel != nullptr, false);
+    // chunk pipeline: chunk k is propagated on every device's own stream; its all-gather runs on the communication
+    // streams while chunk k+1 is being propagated
+    for (size_t k = 0; k < g->n_chunks && rc == AZ_OK; ++k) {
+        for (int d = 0; d < g->n_dev && rc == AZ_OK; ++d) {
+            azh_constellation *c = g->shard[d];
+            if (set_device(c) != AZ_OK) { rc = AZ_ERR_HIP; break; }
+            const size_t cnt = g->cell_hi(k, d) - g->cell_lo(k, d);
+            if (cnt) rc = launch_all(c, c->d_host_pos.p, d_vel ? c->d_host_vel.p : nullptr, AZ_LAYOUT_SAT_MAJOR, 0, nullptr,
+                                     c->s_main, 0, k * g->rows, k * g->rows + cnt);
+            if (rc != AZ_OK) break;
+            if (!hip_ok(hipEventRecord(g->ev[d], c->s_main), "record") || !hip_ok(hipStreamWaitEvent(g->s_comm[d], g->ev[d], 0), "wait"))
+                rc = AZ_ERR_HIP;
+        }
+        if (rc != AZ_OK) break;
+        for (int arr = 0; arr < (d_vel ? 2 : 1) && rc == AZ_OK; ++arr) {
+            if (!nccl_ok(R.GroupStart(), "ncclGroupStart")) { rc = AZ_ERR_HIP; break; }
+            for (int d = 0; d < g->n_dev; ++d) {
+                azh_constellation *c = g->shard[d];
+                const double *src = (arr ? c->d_host_vel.p : c->d_host_pos.p) + k * cell;
+                double *dst = (arr ? d_vel[d] : d_pos[d]) + k * g->n_dev * cell;
+                if (!nccl_ok(R.AllGather(src, dst, cell, ncclDouble, g->comms[d], g->s_comm[d]), "ncclAllGather")) rc = AZ_ERR_HIP;
+            }
+            if (!nccl_ok(R.GroupEnd(), "ncclGroupEnd")) rc = AZ_ERR_HIP;
+        }
+    }
+    for (int d = 0; d < g->n_dev; ++d) {
+        azh_constellation *c = g->shard[d];
+        if (set_device(c) != AZ_OK || !hip_ok(hipStreamSynchronize(c->s_main), "sync") || !hip_ok(hipStreamSynchronize(c->s_deep), "sync") ||
+            !hip_ok(hipStreamSynchronize(g->s_comm[d]), "sync"))
+            rc = rc == AZ_OK ? AZ_ERR_HIP : rc;
+    }
     return rc;
 }
 

@@ -242,6 +242,32 @@ int32_t azh_screen_all_host(azh_constellation *c, const double *times_min, size_
                             const double *epoch_offsets_min, double threshold_km, uint32_t *out_pairs,
                             uint32_t *out_t_index, size_t max_results, size_t *n_found);
 
+/* ---- several GPUs behind one handle (one process; a Zig / C host has no torch.distributed) -----------------
+ * Block-cyclic satellite shards over `devices`: the catalog is cut into n_chunks super-blocks of
+ * n_devices * rows consecutive satellites (rows a multiple of 64), device d owns rows [d*rows, (d+1)*rows) of each
+ * (the plan of astroz_amd/distributed.py).  No reference counterpart (src/Constellation.zig L327-385 is
+ * one process on one host).  Satellite-major outputs in CATALOG order:
+ *   azh_group_propagate_host       every device propagates its shard and copies its blocks straight into the caller's
+ *                                  (n_sats, n_times, 3) host arrays over its own PCIe link: no collective;
+ *   azh_group_propagate_allgather  the full TEME arrays resident on EVERY device: d_pos[i] / d_vel[i] are device
+ *                                  buffers on devices[i] of azh_group_padded_rows() x n_times x 3 doubles (rows beyond
+ *                                  n_sats are padding); RCCL all-gathers over xGMI (librccl is loaded on first use),
+ *                                  chunk k in flight while chunk k+1 is propagated.  Synchronous. */
+typedef struct azh_group azh_group;
+int32_t azh_group_create_from_tle_text(const char *text, size_t len, int32_t grav, const int32_t *devices,
+                                       int32_t n_devices, int32_t n_chunks, azh_group **out);
+int32_t azh_group_create_from_omm_json(const char *text, size_t len, int32_t grav, const int32_t *devices,
+                                       int32_t n_devices, int32_t n_chunks, azh_group **out);
+void azh_group_free(azh_group *g);
+size_t azh_group_num_satellites(const azh_group *g);
+int32_t azh_group_num_devices(const azh_group *g);
+size_t azh_group_padded_rows(const azh_group *g);
+int32_t azh_group_get_epochs(const azh_group *g, double *out_n);
+int32_t azh_group_propagate_host(azh_group *g, const double *times_min, size_t n_times, const double *epoch_offsets_min,
+                                 double *pos, double *vel, int32_t output_mode, double reference_jd, uint8_t *err);
+int32_t azh_group_propagate_allgather(azh_group *g, const double *times_min, size_t n_times,
+                                      const double *epoch_offsets_min, double *const *d_pos, double *const *d_vel);
+
 /* Constellation.propagate (src/Constellation.zig L245-308): absolute times jd[t]+fr[t]; the
  * reference epoch is the first satellite's epoch (L139-140). Host pointers. */
 int32_t azh_propagate_jd_host(azh_constellation *c, const double *jd, const double *fr, size_t n_times,

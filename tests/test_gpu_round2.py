@@ -473,3 +473,31 @@ def test_full_size_all_rows_vs_oracle(native, orc, synth, n_deep):
     dr = float(np.abs(ptm.cpu().numpy().transpose(1, 0, 2) - p0).max())
     dv = float(np.abs(vtm.cpu().numpy().transpose(1, 0, 2) - v0).max())
     assert dr < TOL_R and dv < TOL_V, (dr, dv)
+
+
+def test_device_group_single_device(native, orc, synth):
+    """azh_group (the C-host route to several GPUs) with one device: block-cyclic plan, chunk windows, direct
+    D2H assembly in catalog order, and the in-library RCCL all-gather (one rank: the collective is a copy, but
+    librccl is loaded, a communicator is created and every chunk goes through ncclAllGather)."""
+    import torch
+    pairs = synth.synth_catalog(n_near=700, n_deep=45, seed=71)
+    text = synth.pairs_to_text(pairs)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    grp = native.DeviceGroup(text, [0], native.WGS72, n_chunks=3)
+    assert grp.n == len(pairs) and grp.n_devices == 1 and grp.padded_rows >= grp.n and grp.padded_rows % 64 == 0
+    assert np.array_equal(grp.epochs, cat.epoch_jd)
+    times = np.arange(0.0, 150.0, 1.0)
+    off = (synth.START_JD - cat.epoch_jd) * 1440.0
+    e0, p0, v0 = cat.propagate(times, off, layout=orc.SAT_MAJOR, threads=8)
+    pos, vel, err = grp.propagate_host(times, off, errors=True)
+    assert np.array_equal(err, e0)
+    assert np.abs(pos - p0).max() < TOL_R and np.abs(vel - v0).max() < TOL_V
+    ecef, _, _ = grp.propagate_host(times, off, velocities=False, mode=native.OUT_ECEF, reference_jd=synth.START_JD)
+    _, q0, _ = cat.propagate(times, off, layout=orc.SAT_MAJOR, velocities=False, mode=orc.ECEF, reference_jd=synth.START_JD)
+    assert np.abs(ecef - q0).max() < TOL_R
+    dp = torch.full((grp.padded_rows, len(times), 3), float("nan"), dtype=torch.float64, device="cuda")
+    dv = torch.full_like(dp, float("nan"))
+    torch.cuda.synchronize()
+    grp.propagate_allgather(times, off, [dp.data_ptr()], [dv.data_ptr()])
+    assert np.abs(dp[:grp.n].cpu().numpy() - p0).max() < TOL_R and np.abs(dv[:grp.n].cpu().numpy() - v0).max() < TOL_V
+    grp.close()
