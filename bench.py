@@ -59,6 +59,9 @@ def parse_args():
                     help="N > 1: strong = one 13,478-satellite catalog sharded over the ranks (BASELINE config 4, default); "
                          "weak = every rank its own catalog, no gather")
     ap.add_argument("--no-gather", action="store_true", help="N > 1, strong: skip the RCCL all-gather of the result")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the N > 1 code path (shard plan, chunk pipeline, RCCL all-gather) with whatever world size there "
+                         "is, including 1: a smoke test of the config-4 path on a single-GPU box")
     ap.add_argument("--chunks", type=int, default=4, help="N > 1: pipeline depth of the compute / all-gather overlap")
     ap.add_argument("--tile", type=int, default=0, help="time steps per workgroup (0 = auto)")
     ap.add_argument("--stride-align", type=int, default=0,
@@ -156,8 +159,10 @@ def main():
 
     import __graft_entry__ as entry
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world > 1 or a.force_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if rank == 0:
         entry.build()          # no-op when the in-tree .so files are current
     if world > 1:
@@ -170,7 +175,7 @@ def main():
     times = np.arange(n_times, dtype=np.float64)
     vel_on = not a.pos_only
     odt = torch.float32 if a.f32_out else torch.float64
-    sharded = world > 1 and a.scaling == "strong"      # BASELINE config 4
+    sharded = (world > 1 or a.force_sharded) and a.scaling == "strong"      # BASELINE config 4
     gather = sharded and not a.no_gather
     if sharded and (a.layout != "sat" or a.f32_out):
         raise SystemExit("bench.py: the sharded (config 4) path is satellite-major fp64; use --scaling weak for other variants")
@@ -277,7 +282,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
+    if world > 1 or a.force_sharded:
         tt = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=cuda)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(tt[0]), float(tt[1])
@@ -302,8 +307,7 @@ def main():
         kernel_only_ms = float(kt[0])
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     props_per_step = n_total * n_times
@@ -415,7 +419,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "propagations/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (exc,)}
     print(json.dumps(out))
-    if world > 1:
+    if world > 1 or a.force_sharded:
         dist.destroy_process_group()
 
 

@@ -501,3 +501,22 @@ def test_device_group_single_device(native, orc, synth):
     grp.propagate_allgather(times, off, [dp.data_ptr()], [dv.data_ptr()])
     assert np.abs(dp[:grp.n].cpu().numpy() - p0).max() < TOL_R and np.abs(dv[:grp.n].cpu().numpy() - v0).max() < TOL_V
     grp.close()
+
+
+def test_bench_config4_code_path_smoke(native):
+    """bench.py's N > 1 path (block-cyclic shards, chunk pipeline, RCCL all-gather, t_kernel / t_allgather split)
+    forced onto the single GPU of this box: the JSON line must come out and carry the config-4 fields."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-sharded", "--steps", "3", "--warmup", "1",
+                        "--precondition-ms", "0", "--no-cpu-baseline", "--sats", "3000", "--times", "300"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    j = json.loads(line)
+    cfg = j["config"]
+    assert cfg["gather"] is True and cfg["rccl_ranks"] == 1 and cfg["chunks"] >= 1
+    assert cfg["t_total_ms"] > 0 and cfg["t_kernel_ms"] > 0 and j["value"] > 0 and j["n_gpus"] == 1
