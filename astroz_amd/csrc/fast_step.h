@@ -56,6 +56,22 @@ struct FastKBcast {
 #undef X
 };
 
+// lane = satellite kernels: hot constants in registers, the once-per-step ones in a per-lane LDS column
+// (cold[k * AZ_COLD_STRIDE], conflict-free ds_read_b64) -- 32 VGPRs less, which is what keeps k_propagate's fast
+// loop free of scratch spills (a spilled register's reload waits on vmcnt, i.e. on the output stores in flight)
+struct FastKCol {
+    const double *cold;
+#define X(n) double n##_;
+    AZ_FASTK_HOT(X)
+#undef X
+#define X(n) AZ_MEMBER double n() const { return n##_; }
+    AZ_FASTK_HOT(X)
+#undef X
+#define X(n) AZ_MEMBER double n() const { return cold[FC_##n * AZ_COLD_STRIDE]; }
+    AZ_FASTK_COLD(X)
+#undef X
+};
+
 // carried (sin,cos) pairs: M = mo + mdot t, W = argpo + argpdot t, and
 // U = M + W + the part of the along-track drag phase kappa t^2 (kappa = no_unkozai t2cof) that is LINEAR about
 // the centre tc of the wave's time window:  kappa t^2 = kappa tc^2 + 2 kappa tc (t - tc) + kappa (t - tc)^2.

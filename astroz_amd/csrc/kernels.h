@@ -377,9 +377,21 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
     // Optimistic straight-line loop (fast_step.h): uniform grid, all 64 orbits near-circular, every small
     // angle inside its usual tier; one vote per step, the generic loop takes over on a violation.
     if (!DEEP && p.inc != nullptr && p.uniform_step != 0.0 && !az_any(AZ_FLAG_ECLASS(fl) != 0)) {
-        FastK k;
-        az_load_fast(p.el, p.n_pad, s, fl, p.inc, 1, k);
-        az_fast_window(p.el, p.n_pad, s, p.times[t0] + off, p.times[t1 - 1] + off, p.uniform_step, k);
+        FastKCol k;
+        {
+            FastK k0;
+            az_load_fast(p.el, p.n_pad, s, fl, p.inc, 1, k0);
+            az_fast_window(p.el, p.n_pad, s, p.times[t0] + off, p.times[t1 - 1] + off, p.uniform_step, k0);
+            static_assert((int)FC_NUM <= (int)C_NUM, "the fast step's cold constants share the generic step's LDS columns");
+#define X(n) cold[FC_##n * AZ_COLD_STRIDE] = k0.n##_;
+            AZ_FASTK_COLD(X)
+#undef X
+#define X(n) k.n##_ = k0.n##_;
+            AZ_FASTK_HOT(X)
+#undef X
+            k.cold = cold;
+            az_wave_lds_fence();
+        }
         FastCarry fc;
         az_seed_fast(p.el, p.n_pad, s, p.times[t0] + off - p.uniform_step, k.tc_, fc);
 #pragma unroll 1
