@@ -269,7 +269,8 @@ int32_t azh_group_propagate_allgather(azh_group *g, const double *times_min, siz
                                       const double *epoch_offsets_min, double *const *d_pos, double *const *d_vel);
 
 /* Constellation.propagate (src/Constellation.zig L245-308): absolute times jd[t]+fr[t]; the
- * reference epoch is the first satellite's epoch (L139-140). Host pointers. */
+ * reference epoch is that of the first near-earth member (the first entry of the reference's SGP4 batch list,
+ * L139-140; the first member's if there is none). Host pointers. */
 int32_t azh_propagate_jd_host(azh_constellation *c, const double *jd, const double *fr, size_t n_times,
                               double *pos, double *vel, int32_t output_mode, int32_t layout, uint8_t *err);
 int32_t azh_synchronize(azh_constellation *c);

@@ -520,3 +520,35 @@ def test_bench_config4_code_path_smoke(native):
     cfg = j["config"]
     assert cfg["gather"] is True and cfg["rccl_ranks"] == 1 and cfg["chunks"] >= 1
     assert cfg["t_total_ms"] > 0 and cfg["t_kernel_ms"] > 0 and j["value"] > 0 and j["n_gpus"] == 1
+
+
+def test_c_host_end_to_end(c_client, orc, golden, synth, tmp_path):
+    """The C host of tests/c_client through the reference's c_api call sequence (src/c_api/root.zig L13-81) and through
+    the batch boundary, no Python between the program and the library; outputs against the oracle."""
+    import subprocess
+    l1, l2 = golden["G9_structural"]["tles"][2]
+    r = subprocess.run([c_client, "c_api", l1, l2, "-30", "7.5", "50"], capture_output=True, text=True, check=True)
+    rows = r.stdout.strip().split("\n")
+    cat = orc.Catalog.from_pairs([(l1, l2)])
+    times = -30 + 7.5 * np.arange(50)
+    re_, rp, rv = cat.propagate(times)
+    got = np.array([[float(x) for x in line.split()] for line in rows[6:]])
+    assert got.shape == (50, 6)
+    assert np.abs(got[:, :3] - rp[0]).max() < 1e-6 and np.abs(got[:, 3:] - rv[0]).max() < 1e-9
+    one = np.array([float(x) for x in rows[5].split()])
+    assert np.abs(one[:3] - rp[0, 0]).max() < 1e-6
+    assert int(rows[0]) == 55909
+
+    pairs = _mixed_class_pairs(synth, 70, 5) + [tuple(p) for p in golden["G9_structural"]["tles"]]
+    path = tmp_path / "cat.tle"
+    path.write_text("".join(a + "\n" + b + "\n" for a, b in pairs))
+    r = subprocess.run([c_client, "batch", str(path), "10", "3", "33"], capture_output=True, text=True, check=True)
+    lines = r.stdout.strip().split("\n")
+    n = len(pairs)
+    cat = orc.Catalog.from_pairs(pairs)
+    assert [int(x) for x in lines[0].split()] == [n, n - int(cat.is_deep.sum()), int(cat.is_deep.sum())]
+    got = np.array([[float(x) for x in line.split()] for line in lines[1:]]).reshape(n, 33, 7)
+    re_, rp, rv = cat.propagate(10 + 3.0 * np.arange(33))
+    assert np.array_equal(got[..., 0].astype(np.uint8), re_)
+    ok = re_ == 0
+    assert np.abs(got[..., 1:4] - rp)[ok].max() < 1e-6 and np.abs(got[..., 4:7] - rv)[ok].max() < 1e-9

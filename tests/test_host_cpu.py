@@ -66,6 +66,20 @@ def test_tle_ingest_matches_oracle(native, orc, golden):
     assert int(a5[0]) == 111234
 
 
+def test_c_host_compiles_and_parses(c_client, orc, golden):
+    """A strict-C99 host compiled against include/astroz_hip.h and linked to libastroz_hip.so (tests/c_client): the
+    header is valid C, the library links without Python, the text entry points work, compute fails loudly here."""
+    l1, l2 = golden["G9_structural"]["tles"][2]
+    r = subprocess.run([c_client, "parse", l1, l2], capture_output=True, text=True, check=True)
+    f = [float(x) for x in r.stdout.split()]
+    t = orc.parse_lines(l1, l2)
+    assert len(f) == 16 and int(f[0]) == t.satnum and f[3] == t.epoch_jd and f[8] == t.ecc and f[11] == t.mm_revday
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([c_client, "c_api", l1, l2, "0", "1", "4"], capture_output=True, text=True)
+        assert r.returncode == 3 and "sgp4_init failed" in r.stderr   # no device: an error, never a host computation
+
+
 def test_no_cpu_fallback(native):
     """Without a GPU every compute entry point must fail loudly, never compute on the host."""
     if native.device_count() > 0:
