@@ -61,3 +61,41 @@ pub extern "c" fn azh_coarse_screen_host(pos: [*]const f64, n_sats: usize, n_tim
     device: i32) i32;
 pub extern "c" fn azh_screen_all_host(h: ?*Handle, times_min: [*]const f64, n_times: usize, epoch_offsets_min: ?[*]const f64,
     threshold_km: f64, out_pairs: [*]u32, out_t_index: [*]u32, max_results: usize, n_found: *usize) i32;
+
+// ---- round 2 ----
+// text front ends (Tle.MultiIterator / parseOmm / parseOmmArray, src/Tle.zig L103-238)
+pub extern "c" fn azh_parse_tle_text(text: [*]const u8, len: usize, out16: [*]f64, max_records: usize, n_found: *usize) i32;
+pub extern "c" fn azh_parse_omm_json(text: [*]const u8, len: usize, out16: [*]f64, max_records: usize, n_found: *usize) i32;
+pub extern "c" fn azh_constellation_from_omm_json(text: [*]const u8, len: usize, grav: i32, device: i32, out: *?*Handle) i32;
+pub extern "c" fn azh_constellation_subset(h: ?*const Handle, indices: [*]const u32, n: usize, device: i32, out: *?*Handle) i32;
+
+// row windows (chunked multi-GPU pipelines), arithmetic / path switches, device-pointer one-satellite call
+pub extern "c" fn azh_propagate_device_window(h: ?*Handle, row_lo: usize, row_hi: usize, d_pos: [*]f64, d_vel: ?[*]f64, layout: i32,
+    out_stride_sats: usize, d_err: ?[*]u8, stream: ?*anyopaque) i32;
+pub extern "c" fn azh_set_f32_arithmetic(h: ?*Handle, enabled: i32) i32;
+pub extern "c" fn azh_set_fast_path(h: ?*Handle, enabled: i32) i32;
+pub extern "c" fn azh_propagate_one_device(h: ?*Handle, sat_index: usize, d_tsince_min: [*]const f64, n: usize, d_pos: [*]f64,
+    d_vel: ?[*]f64, d_err: ?[*]u8, stream: ?*anyopaque) i32;
+pub extern "c" fn azh_selftest_math(x: [*]const f64, n: usize, out6n: [*]f64, device: i32) i32;
+
+// src/c_api/coords.zig
+pub extern "c" fn coords_julian_to_gmst(jd: f64) f64;
+pub extern "c" fn coords_eci_to_ecef(eci: *const [3]f64, gmst: f64, ecef: *[3]f64) void;
+pub extern "c" fn coords_ecef_to_geodetic(ecef: *const [3]f64, lla: *[3]f64) void;
+
+// one process, several devices: replaces the std.Thread fan-out of Constellation.propagateConstellation
+// (src/Constellation.zig L557-603)
+pub const Group = opaque {};
+pub extern "c" fn azh_group_create_from_tle_text(text: [*]const u8, len: usize, grav: i32, devices: [*]const i32, n_devices: i32,
+    n_chunks: i32, out: *?*Group) i32;
+pub extern "c" fn azh_group_create_from_omm_json(text: [*]const u8, len: usize, grav: i32, devices: [*]const i32, n_devices: i32,
+    n_chunks: i32, out: *?*Group) i32;
+pub extern "c" fn azh_group_free(g: ?*Group) void;
+pub extern "c" fn azh_group_num_satellites(g: ?*const Group) usize;
+pub extern "c" fn azh_group_num_devices(g: ?*const Group) i32;
+pub extern "c" fn azh_group_padded_rows(g: ?*const Group) usize;
+pub extern "c" fn azh_group_get_epochs(g: ?*const Group, out: [*]f64) i32;
+pub extern "c" fn azh_group_propagate_host(g: ?*Group, times_min: [*]const f64, n_times: usize, epoch_offsets_min: ?[*]const f64,
+    pos: [*]f64, vel: ?[*]f64, output_mode: i32, reference_jd: f64, err: ?[*]u8) i32;
+pub extern "c" fn azh_group_propagate_allgather(g: ?*Group, times_min: [*]const f64, n_times: usize,
+    epoch_offsets_min: ?[*]const f64, d_pos: [*]const [*]f64, d_vel: ?[*]const [*]f64) i32;
