@@ -405,6 +405,10 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const
         const unsigned cap = span >= 4.0e9 ? 0xffffffc0u : std::max(64u, (unsigned)span / 64u * 64u);
         e.tile = std::min(rows_tile(std::max(e.n_list, 1u), a.n_times, 256), cap);
         c.tile = std::min(a.tile, cap);
+        // packed fp32 kernel: a lane carries two grid points, a wave iteration 128 (windows shorter than that -- grid
+        // steps beyond ~23 minutes -- keep the fp64 kernel with rounded stores)
+        const bool packed32 = a.f32 && !FRAME && a.arith32 && cap >= 128u;
+        if (packed32) c.tile = std::max(128u, c.tile / 128u * 128u);
         dim3 egrid((e.n_list + 7) / 8 * 8, (a.n_times + e.tile - 1) / e.tile);
         dim3 cgrid((c.n_list + 7) / 8 * 8, (a.n_times + c.tile - 1) / c.tile);
         dim3 rgrid(256, 4);
@@ -421,7 +425,7 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const
         if (a.f32) {
             if (e.n_list) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32, true>), egrid, dim3(64), 0, se, e);
             if (c.n_list) {
-                if (!FRAME && a.arith32) hipLaunchKernelGGL((k_rows_fast32<VEL>), cgrid, dim3(64), 0, st, c);
+                if (packed32) hipLaunchKernelGGL((k_rows_fast32<VEL>), cgrid, dim3(64), 0, st, c);
                 else hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32, false>), cgrid, dim3(64), 0, st, c);
             }
         } else {

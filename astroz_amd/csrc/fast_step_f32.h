@@ -1,178 +1,284 @@
 // fast_step_f32.h -- the branch-free uniform-grid step (fast_step.h) in fp32 arithmetic, for fp32 OUTPUTS
 // (BASELINE config 5: 1M satellites x 10,000 steps, an HBM-bound stress case; the reference itself is fp64 only).
 //
-// What stays fp64: the three carried angle pairs M, W, U (their phase runs to hundreds of radians over 10,000
-// minutes: 12 fp64 instructions per step) and the
-// along-radius chain a -> r (the semi-major axis, 1 - e cos E and the J2 radius factor: ~12) -- together ~30 fp64
-// instructions.  Everything else -- drag polynomials, Kepler step, short-period terms, orientation, velocity --
-// is fp32 (v_fma_f32 issues at twice the fp64 rate on gfx950; v_rcp_f32 needs no refinement at this precision):
-// ~170 instructions.  Near-circular members only; eccentric members and validation failures take the fp64 kernels
-// with rounded stores.  Result accuracy is that of fp32 storage plus ~1e-7 relative from the fp32 chain: metres,
-// mm/s (tests/test_gpu_round2.py::test_fp32_arithmetic_*).
+// TWO grid points per lane.  On gfx950 a plain v_fma_f32 issues at the same rate as v_fma_f64 (one wave instruction
+// per four cycles); the fp32 vector peak (157 TFLOP/s, twice the fp64 one) belongs to the PACKED forms v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32, which work on a register pair.  A lane therefore carries two adjacent grid points
+// (2i, 2i+1) as the two halves of az_f2 values and the whole fp32 part of the step is written on az_f2: one
+// instruction, two propagations.
+//
+// What stays fp64, per grid point: the carried pair of U = M + W (the along-track phase: hundreds of radians over
+// 10,000 minutes, and a metre is 1.4e-7 rad; the even point's pair is carried, the odd point's is the even one
+// rotated by the one-grid-step increment) and the along-radius chain a -> r (1 - e cos E and the J2 radius factor
+// applied to the semi-major axis).  Everything else -- the pairs of M and W (they only enter through terms scaled by
+// the eccentricity, < 0.004 here, and a wave re-seeds them from a full fp64 sincos at the start of its segment, at
+// most 12 steps back), drag polynomials, Kepler step, short-period terms, orientation, velocity -- is packed fp32
+// (v_rcp_f32 needs no refinement at this precision).  Near-circular members
+// only; eccentric members and validation failures take the fp64 kernels with rounded stores.  Result accuracy is
+// that of fp32 storage plus ~1e-7 relative from the fp32 chain: metres, mm/s
+// (tests/test_gpu_round2.py::test_fp32_arithmetic_*).
 #pragma once
 #include "fast_step.h"
 
-struct FastK32 {
-#define X(n) float n##_;
-    AZ_FASTK_COLD(X) AZ_FASTK_HOT(X)
-#undef X
-    double sab64, cc1d, d2d, d3d, d4d;  // fp64: the along-radius chain (sqrt(a_base), drag polynomial of the semi-major axis)
-    double sdA, cdA, sdW, cdW, sdU, cdU, tc, tmid; // fp64: the carried-angle increments, window centres
-};
-
-AZ_DEVICE void az_load_fast32(const FastK &k, FastK32 &f)
-{
-#define X(n) f.n##_ = (float)k.n##_;
-    AZ_FASTK_COLD(X) AZ_FASTK_HOT(X)
-#undef X
-    f.sab64 = k.sab_; f.cc1d = k.cc1_; f.d2d = k.d2_; f.d3d = k.d3_; f.d4d = k.d4_;
-    f.sdA = k.sdA_; f.cdA = k.cdA_; f.sdW = k.sdW_; f.cdW = k.cdW_;
-    f.sdU = k.sdU_; f.cdU = k.cdU_; f.tc = k.tc_; f.tmid = k.tmid_;
-}
-
 #ifdef AZ_HOST_EMUL
+struct az_f2 { float x, y; };
+static inline az_f2 operator+(az_f2 a, az_f2 b) { return {a.x + b.x, a.y + b.y}; }
+static inline az_f2 operator-(az_f2 a, az_f2 b) { return {a.x - b.x, a.y - b.y}; }
+static inline az_f2 operator*(az_f2 a, az_f2 b) { return {a.x * b.x, a.y * b.y}; }
+static inline az_f2 operator*(float a, az_f2 b) { return {a * b.x, a * b.y}; }
+static inline az_f2 operator*(az_f2 a, float b) { return {a.x * b, a.y * b}; }
+static inline az_f2 operator-(az_f2 a) { return {-a.x, -a.y}; }
+static inline az_f2 az_fma2(az_f2 a, az_f2 b, az_f2 c) { return {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
 static inline float az_rcp32(float x) { return 1.0f / x; }
 #else
+typedef float az_f2 __attribute__((ext_vector_type(2)));
+AZ_DEVICE az_f2 az_fma2(az_f2 a, az_f2 b, az_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 AZ_DEVICE float az_rcp32(float x) { return __builtin_amdgcn_rcpf(x); }
 #endif
+AZ_DEVICE az_f2 az_splat2(float a) { az_f2 r; r.x = a; r.y = a; return r; }
+AZ_DEVICE az_f2 az_fma2(float a, az_f2 b, az_f2 c) { return az_fma2(az_splat2(a), b, c); }
+AZ_DEVICE az_f2 az_fma2(az_f2 a, az_f2 b, float c) { return az_fma2(a, b, az_splat2(c)); }
+AZ_DEVICE az_f2 az_fma2(float a, az_f2 b, float c) { return az_fma2(az_splat2(a), b, az_splat2(c)); }
+AZ_DEVICE az_f2 az_rcp2(az_f2 a) { az_f2 r; r.x = az_rcp32(a.x); r.y = az_rcp32(a.y); return r; }
+AZ_DEVICE az_f2 az_cvt2(double a, double b) { az_f2 r; r.x = (float)a; r.y = (float)b; return r; }
+// !(|a| <= lim) in either half (NaN counts as out of range)
+AZ_DEVICE bool az_out2(az_f2 a, float lim) { return !(fabsf(a.x) <= lim) | !(fabsf(a.y) <= lim); }
+
+// per-satellite constants of the packed step.  Used once per step (LDS candidates) / several times (registers):
+#define AZ_F32_ONCE(X) \
+    X(cc1) X(d2) X(d3) X(d4) X(nl2) X(nl3) X(nl4) X(nl5) X(eta) X(omgcof) X(xmcof) X(xd) X(bc4) X(bc5) X(ecb) X(aycof) \
+    X(xlcof) X(xnodcf) X(k_mrt) X(k_c2u) X(k_su) X(k_node) X(k_inc) X(k_rv) X(nodedot) X(sinio) X(cosio) X(sOc) X(cOc)
+#define AZ_F32_MANY(X) X(x1mth2) X(sdA32) X(cdA32) X(sdW32) X(cdW32) X(step1)
+enum Fast32Once {
+#define X(n) F32_##n,
+    AZ_F32_ONCE(X)
+#undef X
+    F32_NUM
+};
+struct FastK32Doubles {
+    double sab64;                       // sqrt(a_base), head of the along-radius chain
+    double sdU, cdU, tc, tmid;          // the increment of U over one lane step, window centres
+    double s1U, c1U;                    // the increment of U over ONE grid step (even -> odd point)
+};
+// everything in registers (host emulation, set-up)
+struct FastK32 : FastK32Doubles {
+#define X(n) float n##_;
+    AZ_F32_ONCE(X) AZ_F32_MANY(X)
+#undef X
+#define X(n) AZ_MEMBER float n() const { return n##_; }
+    AZ_F32_ONCE(X) AZ_F32_MANY(X)
+#undef X
+};
+// k_rows_fast32 (one satellite per wave): the once-per-step constants are LDS words read by all lanes at once (a
+// packed instruction takes ONE scalar operand; every further constant would have to live in a VGPR for the whole
+// loop -- 29 of them are the difference between 4 and 5 waves per SIMD)
+struct FastK32Bcast : FastK32Doubles {
+    const float *once;
+#define X(n) float n##_;
+    AZ_F32_MANY(X)
+#undef X
+#define X(n) AZ_MEMBER float n() const { return n##_; }
+    AZ_F32_MANY(X)
+#undef X
+#define X(n) AZ_MEMBER float n() const { return once[F32_##n]; }
+    AZ_F32_ONCE(X)
+#undef X
+};
+
+// carried state of one lane: M and W pairs of both grid points in fp32, the even point's U pair in fp64
+struct FastCarry32 {
+    az_f2 sA, cA, sW, cW;
+    double sU, cU;
+};
+
+// k: constants with the increments of one LANE step (two grid points x 64 lanes = 128 grid steps);
+// k1: the same satellite's constants with the increments of ONE grid step; step1: the grid step in minutes
+AZ_DEVICE void az_load_fast32(const FastK &k, const FastK &k1, double step1, FastK32 &f)
+{
+#define X(n) f.n##_ = (float)k.n##_;
+    AZ_F32_ONCE(X)
+#undef X
+    f.x1mth2_ = (float)k.x1mth2_;
+    f.sab64 = k.sab_;
+    f.sdU = k.sdU_; f.cdU = k.cdU_; f.tc = k.tc_; f.tmid = k.tmid_;
+    f.s1U = k1.sdU_; f.c1U = k1.cdU_;
+    f.sdA32_ = (float)k.sdA_; f.cdA32_ = (float)k.cdA_; f.sdW32_ = (float)k.sdW_; f.cdW32_ = (float)k.cdW_;
+    f.step1_ = (float)step1;
+}
+
+// st: az_seed_fast's pairs for the even point (one lane step before its first grid point); k1: the one-grid-step
+// increments.  The odd point's M and W pairs are the even ones rotated by one grid step, in fp64, once.
+AZ_DEVICE void az_seed_fast32(const FastCarry &st, const FastK &k1, FastCarry32 &f)
+{
+    f.sA = az_cvt2(st.sA, fma(st.sA, k1.cdA_, st.cA * k1.sdA_));
+    f.cA = az_cvt2(st.cA, fma(st.cA, k1.cdA_, -(st.sA * k1.sdA_)));
+    f.sW = az_cvt2(st.sW, fma(st.sW, k1.cdW_, st.cW * k1.sdW_));
+    f.cW = az_cvt2(st.cW, fma(st.cW, k1.cdW_, -(st.sW * k1.sdW_)));
+    f.sU = st.sU;
+    f.cU = st.cU;
+}
+
+// the increments of twice the angle (k_prep_inc holds 64 grid steps; a lane of the packed kernel advances by 128)
+AZ_DEVICE void az_double_increments(FastK &k)
+{
+    const double sA = 2.0 * k.sdA_ * k.cdA_, cA = fma(-2.0 * k.sdA_, k.sdA_, 1.0);
+    const double sW = 2.0 * k.sdW_ * k.cdW_, cW = fma(-2.0 * k.sdW_, k.sdW_, 1.0);
+    k.sdA_ = sA; k.cdA_ = cA; k.sdW_ = sW; k.cdW_ = cW;
+}
 
 // (s,c) <- rotated by d, |d| <= 2^-10: sin d = d, cos d - 1 = -d^2/2 to fp32 precision (d^3/6 < 1.6e-10)
-AZ_DEVICE void az_rot32_tiny(float &s, float &c, float d)
+AZ_DEVICE void az_rot32_tiny(az_f2 &s, az_f2 &c, az_f2 d)
 {
-    const float q = -0.5f * d * d;
-    const float ns = fmaf(c, d, fmaf(s, q, s));
-    c = fmaf(-s, d, fmaf(c, q, c));
+    const az_f2 q = (-0.5f * d) * d;
+    const az_f2 ns = az_fma2(c, d, az_fma2(s, q, s));
+    c = az_fma2(-s, d, az_fma2(c, q, c));
     s = ns;
 }
 // |d| <= 1/8: sin to d^5, cos to d^6 (next terms 4.5e-11, 1.5e-12)
-AZ_DEVICE void az_rot32_med(float &s, float &c, float d)
+AZ_DEVICE void az_rot32_med(az_f2 &s, az_f2 &c, az_f2 d)
 {
-    const float d2 = d * d;
-    const float p = d * fmaf(d2, fmaf(d2, 1.0f / 120.0f, -1.0f / 6.0f), 1.0f);
-    const float q = d2 * fmaf(d2, fmaf(d2, -1.0f / 720.0f, 1.0f / 24.0f), -0.5f);
-    const float ns = fmaf(c, p, fmaf(s, q, s));
-    c = fmaf(-s, p, fmaf(c, q, c));
+    const az_f2 d2 = d * d;
+    const az_f2 p = d * az_fma2(d2, az_fma2(1.0f / 120.0f, d2, -1.0f / 6.0f), 1.0f);
+    const az_f2 q = d2 * az_fma2(d2, az_fma2(-1.0f / 720.0f, d2, 1.0f / 24.0f), -0.5f);
+    const az_f2 ns = az_fma2(c, p, az_fma2(s, q, s));
+    c = az_fma2(-s, p, az_fma2(c, q, c));
     s = ns;
 }
 // |d| <= 2^-7: sin to d^3, cos to d^4 (next terms 2.4e-13, 3e-16)
-AZ_DEVICE void az_rot32_small(float &s, float &c, float d)
+AZ_DEVICE void az_rot32_small(az_f2 &s, az_f2 &c, az_f2 d)
 {
-    const float d2 = d * d;
-    const float p = fmaf(d2 * (-1.0f / 6.0f), d, d);
-    const float q = d2 * fmaf(d2, 1.0f / 24.0f, -0.5f);
-    const float ns = fmaf(c, p, fmaf(s, q, s));
-    c = fmaf(-s, p, fmaf(c, q, c));
+    const az_f2 d2 = d * d;
+    const az_f2 p = az_fma2((-1.0f / 6.0f) * d2, d, d);
+    const az_f2 q = d2 * az_fma2(1.0f / 24.0f, d2, -0.5f);
+    const az_f2 ns = az_fma2(c, p, az_fma2(s, q, s));
+    c = az_fma2(-s, p, az_fma2(c, q, c));
     s = ns;
 }
 
-template <bool VEL>
-AZ_DEVICE bool az_sgp4_fast_step_f32(const FastK32 &k, const AzGrav &g, double t64, FastCarry &st, float r[3], float v[3])
+// One lane step = the two grid points ta and ta + step1.  st: the carried pairs (advanced here by one lane step
+// first, as in az_sgp4_fast_step).  r, v: component j of the even / odd point in r[j].x / r[j].y.
+template <bool VEL, class K>
+AZ_DEVICE bool az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, FastCarry32 &st, az_f2 r[3], az_f2 v[3])
 {
-    // carried pairs: fp64 (the phase is hundreds of radians; a per-step fp32 rounding would walk away)
     {
-        const double nsA = fma(st.sA, k.cdA, st.cA * k.sdA);
-        st.cA = fma(st.cA, k.cdA, -(st.sA * k.sdA));
+        const az_f2 nsA = az_fma2(k.cdA32(), st.sA, k.sdA32() * st.cA);
+        st.cA = az_fma2(k.cdA32(), st.cA, -(k.sdA32() * st.sA));
         st.sA = nsA;
-        const double nsW = fma(st.sW, k.cdW, st.cW * k.sdW);
-        st.cW = fma(st.cW, k.cdW, -(st.sW * k.sdW));
+        const az_f2 nsW = az_fma2(k.cdW32(), st.sW, k.sdW32() * st.cW);
+        st.cW = az_fma2(k.cdW32(), st.cW, -(k.sdW32() * st.sW));
         st.sW = nsW;
+        // U: fp64 (the phase is hundreds of radians; a per-step fp32 rounding would walk away)
         const double nsU = fma(st.sU, k.cdU, st.cU * k.sdU);
         st.cU = fma(st.cU, k.cdU, -(st.sU * k.sdU));
         st.sU = nsU;
     }
-    const float t = (float)t64;
-    const float sA = (float)st.sA, cA = (float)st.cA, sW = (float)st.sW, cW = (float)st.cW;
-    const float t2 = t * t;
+    az_f2 lane01;
+    lane01.x = 0.0f;
+    lane01.y = k.step1();
+    const az_f2 t = az_splat2((float)ta) + lane01;
+    const az_f2 dtc = az_splat2((float)(ta - k.tc)) + lane01;
+    const az_f2 t2 = t * t;
 
-    const float dm = fmaf(k.eta_, cA, 1.0f);
-    const float th = fmaf(k.xmcof_, dm * dm * dm, fmaf(k.omgcof_, t, -k.xd_));
-    const double tempa64 = fma(-t64, fma(t64, fma(t64, fma(t64, k.d4d, k.d3d), k.d2d), k.cc1d), 1.0);
-    const float dtc = (float)(t64 - k.tc);
-    const float nl = fmaf(k.nl2_ * dtc, dtc, t2 * (t * fmaf(t, fmaf(t, k.nl5_, k.nl4_), k.nl3_)));
-    bool bad = !(fabsf(th) <= (float)AZ_ROT_16TH);
-    float smm = sA, cmm = cA, sw = sW, cw = cW;
-    az_rot32_med(smm, cmm, th);
-    az_rot32_med(sw, cw, -th);
-    const float em = fmaxf(fmaf(-k.bc5_, smm, fmaf(-k.bc4_, t, k.ecb_)), 1.0e-6f);
+    const az_f2 dm = az_fma2(k.eta(), st.cA, 1.0f);
+    const az_f2 th = az_fma2(k.xmcof(), dm * dm * dm, az_fma2(k.omgcof(), t, -k.xd()));
+    // 1 - tempa = t (cc1 + t (d2 + t (d3 + t d4))) is small (1e-3 after a week): fp32 is plenty for it
+    const az_f2 dev = t * az_fma2(t, az_fma2(t, az_fma2(k.d4(), t, k.d3()), k.d2()), k.cc1());
+    const az_f2 nl = az_fma2(k.nl2() * dtc, dtc, t2 * (t * az_fma2(t, az_fma2(k.nl5(), t, k.nl4()), k.nl3())));
+    bool bad = az_out2(th, (float)AZ_ROT_16TH);
+    // M + th and W - th: both pairs only enter through eccentricity-scaled terms (x 0.004), |th| <= 1/16:
+    // sin th = th - th^3/6 (error 8e-9), cos th = 1 - th^2/2 (error 6e-7 x 0.004), one polynomial for both
+    const az_f2 th2 = th * th;
+    const az_f2 pth = az_fma2((-1.0f / 6.0f) * th2, th, th);
+    const az_f2 qth = -0.5f * th2;
+    const az_f2 smm = az_fma2(st.cA, pth, az_fma2(st.sA, qth, st.sA));
+    const az_f2 sw = az_fma2(-st.cW, pth, az_fma2(st.sW, qth, st.sW));
+    const az_f2 cw = az_fma2(st.sW, pth, az_fma2(st.cW, qth, st.cW));
+    az_f2 em = az_fma2(-k.bc5(), smm, az_fma2(-k.bc4(), t, k.ecb()));
+    em.x = fmaxf(em.x, 1.0e-6f);
+    em.y = fmaxf(em.y, 1.0e-6f);
 
     // along-radius chain in fp64: sqrt(am) = sqrt(a_base) |tempa|
-    const double sqrt_am64 = k.sab64 * fabs(tempa64);
-    const double am64 = sqrt_am64 * sqrt_am64;
-    const float sqrt_am = (float)sqrt_am64;
-    const float omem2 = fmaf(-em, em, 1.0f);
-    const float R = az_rcp32(sqrt_am * omem2);
-    const float ra = R * omem2;
-    const float temp = ra * R;
+    const double sqrt_am_a = fabs(fma(-k.sab64, (double)dev.x, k.sab64)), sqrt_am_b = fabs(fma(-k.sab64, (double)dev.y, k.sab64));
+    const az_f2 sqrt_am = az_cvt2(sqrt_am_a, sqrt_am_b);
+    const az_f2 omem2 = az_fma2(-em, em, 1.0f);
+    const az_f2 R = az_rcp2(sqrt_am * omem2);
+    const az_f2 ra = R * omem2;
+    const az_f2 temp = ra * R;
 
-    const float axnl = em * cw;
-    const float aynl = fmaf(em, sw, temp * k.aycof_);
+    const az_f2 axnl = em * cw;
+    const az_f2 aynl = az_fma2(em, sw, k.aycof() * temp);
     // u0 = U (carried in fp64) + the rest of the drag term + the long-period term
-    float s = (float)st.sU, c = (float)st.cU;
+    az_f2 s = az_cvt2(st.sU, fma(st.sU, k.c1U, st.cU * k.s1U));
+    az_f2 c = az_cvt2(st.cU, fma(st.cU, k.c1U, -(st.sU * k.s1U)));
     {
-        const float eps = fmaf(temp * k.xlcof_, axnl, nl);
-        bad |= !(fabsf(eps) <= (float)AZ_ROT_MED);
+        const az_f2 eps = az_fma2(k.xlcof() * temp, axnl, nl);
+        bad |= az_out2(eps, (float)AZ_ROT_MED);
         az_rot32_med(s, c, eps);
     }
 
     // Kepler, near-circular: one Newton step from E0 = u (the next correction, (el/2) d0^2 <= 3.2e-8, is below
     // fp32 resolution)
-    const float el2 = fmaf(axnl, axnl, aynl * aynl);
-    bad |= !(el2 <= (float)AZ_FAST_EL2);
-    const float rden = az_rcp32(fmaf(-s, aynl, fmaf(-c, axnl, 1.0f)));
-    const float d0 = fmaf(axnl, s, -(aynl * c)) * rden;
+    const az_f2 el2 = az_fma2(axnl, axnl, aynl * aynl);
+    bad |= !(el2.x <= (float)AZ_FAST_EL2) | !(el2.y <= (float)AZ_FAST_EL2);
+    const az_f2 rden = az_rcp2(az_fma2(-s, aynl, az_fma2(-c, axnl, 1.0f)));
+    const az_f2 d0 = az_fma2(axnl, s, -(aynl * c)) * rden;
     az_rot32_small(s, c, d0);
-    const float ecose = fmaf(axnl, c, aynl * s);
-    const float esine = fmaf(axnl, s, -(aynl * c));
-    const float ome = 1.0f - ecose;
-    const float inv_ome = az_rcp32(ome);
-    const float betal = fmaf(el2, -0.5f, 1.0f);
-    const float inv_omel2 = 1.0f + el2;
-    const float inv_1pb = fmaf(el2, 0.125f, 0.5f);
+    const az_f2 ecose = az_fma2(axnl, c, aynl * s);
+    const az_f2 esine = az_fma2(axnl, s, -(aynl * c));
+    const az_f2 inv_ome = az_rcp2(az_splat2(1.0f) - ecose);
+    const az_f2 betal = az_fma2(-0.5f, el2, 1.0f);
+    const az_f2 inv_omel2 = az_splat2(1.0f) + el2;
+    const az_f2 inv_1pb = az_fma2(0.125f, el2, 0.5f);
 
-    const float est = esine * inv_1pb;
-    const float sinu = inv_ome * (s - fmaf(axnl, est, aynl));
-    const float cosu = inv_ome * (c + fmaf(aynl, est, -axnl));
-    const float sin2u = (sinu + sinu) * cosu;
-    const float cos2u = fmaf(-2.0f * sinu, sinu, 1.0f);
+    const az_f2 est = esine * inv_1pb;
+    const az_f2 sinu = inv_ome * (s - az_fma2(axnl, est, aynl));
+    const az_f2 cosu = inv_ome * (c + az_fma2(aynl, est, -axnl));
+    const az_f2 sin2u = (sinu + sinu) * cosu;
+    const az_f2 cos2u = az_fma2(-2.0f * sinu, sinu, 1.0f);
 
-    const float inv_am = ra * ra;
-    const float inv_pl = inv_am * inv_omel2;
-    const float temp1 = (float)g.half_j2 * inv_pl;
-    const float temp2 = temp1 * inv_pl;
-    bad |= !(temp2 <= (float)AZ_FAST_TEMP2);
+    const az_f2 inv_am = ra * ra;
+    const az_f2 inv_pl = inv_am * inv_omel2;
+    const az_f2 temp1 = (float)g.half_j2 * inv_pl;
+    const az_f2 temp2 = temp1 * inv_pl;
+    bad |= !(temp2.x <= (float)AZ_FAST_TEMP2) | !(temp2.y <= (float)AZ_FAST_TEMP2);
 
     // mrt = rl (1 + k_mrt temp2 betal) + k_c2u temp1 cos2u, rl = am (1 - ecose): fp64 (cancellation-free, but the
-    // result is the radius itself: an fp32 chain here costs a metre)
-    const double rl64 = am64 * (1.0 - (double)ecose);
-    const double mrt64 = fma(rl64, (double)fmaf(k.k_mrt_ * temp2, betal, 1.0f), (double)(k.k_c2u_ * temp1 * cos2u));
-    const float t2s = temp2 * sin2u;
-    const float a_nd = fmaf(k.k_node_, t2s, fmaf(k.nodedot_, (float)(t64 - k.tmid), k.xnodcf_ * t2));
-    bad |= !(fabsf(a_nd) <= (float)AZ_ROT_MED);
-    float ssu = sinu, csu = cosu, sn = k.sOc_, cn = k.cOc_, si = k.sinio_, ci = k.cosio_;
-    az_rot32_tiny(ssu, csu, k.k_su_ * t2s);
+    // result is the radius itself: an fp32 chain here costs a metre); the two corrections are small and enter as fp32
+    const az_f2 fm1 = k.k_mrt() * temp2 * betal;
+    const az_f2 add = k.k_c2u() * temp1 * cos2u;
+    const double rl_a = sqrt_am_a * sqrt_am_a * (1.0 - (double)ecose.x);
+    const double rl_b = sqrt_am_b * sqrt_am_b * (1.0 - (double)ecose.y);
+    const double mrt_a = fma(rl_a, (double)fm1.x, rl_a + (double)add.x);
+    const double mrt_b = fma(rl_b, (double)fm1.y, rl_b + (double)add.y);
+    const az_f2 rs = az_cvt2(mrt_a * g.radius_km, mrt_b * g.radius_km);
+    const az_f2 t2s = temp2 * sin2u;
+    const az_f2 a_nd = az_fma2(k.k_node(), t2s, az_fma2(k.nodedot(), az_splat2((float)(ta - k.tmid)) + lane01, k.xnodcf() * t2));
+    bad |= az_out2(a_nd, (float)AZ_ROT_MED);
+    az_f2 ssu = sinu, csu = cosu, sn = az_splat2(k.sOc()), cn = az_splat2(k.cOc()), si = az_splat2(k.sinio()),
+          ci = az_splat2(k.cosio());
+    az_rot32_tiny(ssu, csu, k.k_su() * t2s);
     az_rot32_med(sn, cn, a_nd);
-    az_rot32_tiny(si, ci, k.k_inc_ * temp2 * cos2u);
+    az_rot32_tiny(si, ci, k.k_inc() * temp2 * cos2u);
 
-    const float xmx = -sn * ci, xmy = cn * ci;
-    const float ux = fmaf(xmx, ssu, cn * csu);
-    const float uy = fmaf(xmy, ssu, sn * csu);
-    const float uz = si * ssu;
-    const float rs = (float)(mrt64 * g.radius_km);
+    const az_f2 xmx = -sn * ci, xmy = cn * ci;
+    const az_f2 ux = az_fma2(xmx, ssu, cn * csu);
+    const az_f2 uy = az_fma2(xmy, ssu, sn * csu);
+    const az_f2 uz = si * ssu;
     r[0] = rs * ux;
     r[1] = rs * uy;
     r[2] = rs * uz;
     if (VEL) {
-        const float rv = ra * (float)g.vkmpersec;
-        const float vk = rv * inv_ome;
-        const float nxt = rv * inv_am * temp1;
-        const float mvt = fmaf(-nxt * k.x1mth2_, sin2u, vk * esine);
-        const float rvdot = fmaf(nxt, fmaf(k.x1mth2_, cos2u, k.k_rv_), vk * betal);
-        const float vx = fmaf(xmx, csu, -(cn * ssu));
-        const float vy = fmaf(xmy, csu, -(sn * ssu));
-        const float vz = si * csu;
-        v[0] = fmaf(mvt, ux, rvdot * vx);
-        v[1] = fmaf(mvt, uy, rvdot * vy);
-        v[2] = fmaf(mvt, uz, rvdot * vz);
+        const az_f2 rv = (float)g.vkmpersec * ra;
+        const az_f2 vk = rv * inv_ome;
+        const az_f2 nxt = rv * inv_am * temp1;
+        const az_f2 mvt = az_fma2(-k.x1mth2() * nxt, sin2u, vk * esine);
+        const az_f2 rvdot = az_fma2(nxt, az_fma2(k.x1mth2(), cos2u, k.k_rv()), vk * betal);
+        const az_f2 vx = az_fma2(xmx, csu, -(cn * ssu));
+        const az_f2 vy = az_fma2(xmy, csu, -(sn * ssu));
+        const az_f2 vz = si * csu;
+        v[0] = az_fma2(mvt, ux, rvdot * vx);
+        v[1] = az_fma2(mvt, uy, rvdot * vy);
+        v[2] = az_fma2(mvt, uz, rvdot * vz);
     }
     return bad;
 }

@@ -590,6 +590,9 @@ struct ColdBroadcast {
 #ifndef AZ_ROWSF_WAVES
 #define AZ_ROWSF_WAVES 6 /* k_rows_fast, near-circular Kepler form: 68 VGPRs (7 waves/SIMD fit) */
 #endif
+#ifndef AZ_ROWSF32_WAVES
+#define AZ_ROWSF32_WAVES 4 /* k_rows_fast32: two grid points per lane */
+#endif
 #ifndef AZ_ROWSF_ECC_WAVES
 #define AZ_ROWSF_ECC_WAVES 4 /* k_rows_fast, eccentric form: ~100 VGPRs (its own instantiation and launch, so that the
                                  few eccentric members do not cost every wave of the bulk its occupancy) */
@@ -754,10 +757,42 @@ __global__ void __launch_bounds__(64, FRAME ? 2 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
     }
 }
 
-// k_rows_fast in fp32 arithmetic (fast_step_f32.h) for fp32 outputs: near-circular members, TEME, uniform grid.
-// All constants are wave-uniform scalars (34 floats + 11 doubles fit the SGPR file); ~60 VGPRs.
+// Staging of the packed kernel, DS instructions written by hand.  Component j of a lane's two grid points sits in
+// one register pair while the row wants (x y z)(x y z): ds_write2_b32 puts the two halves three floats apart without
+// a register move (the compiler pairs NEIGHBOURING floats into 64-bit writes instead: twelve v_mov per iteration).
+// Writes and reads are both volatile asm, so they keep their program order; the hardware executes one wave's DS
+// instructions in order.
+__device__ __forceinline__ unsigned az_lds_address(const void *p)
+{
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+__device__ __forceinline__ void az_stage_pair3(unsigned a, const az_f2 q[3])
+{
+    asm volatile("ds_write2_b32 %0, %1, %2 offset1:3\n\t"
+                 "ds_write2_b32 %0, %3, %4 offset0:1 offset1:4\n\t"
+                 "ds_write2_b32 %0, %5, %6 offset0:2 offset1:5"
+                 :
+                 : "v"(a), "v"(q[0].x), "v"(q[0].y), "v"(q[1].x), "v"(q[1].y), "v"(q[2].x), "v"(q[2].y));
+}
+// 1,536 staged bytes at LDS address `a` (this lane's piece: a + 16 lane) -> 96 aligned 16-byte pieces at out
+__device__ __forceinline__ void az_flush_pair3(unsigned a, float *out, unsigned lane)
+{
+    az_f4 lo, hi;
+    asm volatile("ds_read_b128 %0, %2\n\t"
+                 "ds_read_b128 %1, %2 offset:1024\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(a));
+    az_f4 *dst = reinterpret_cast<az_f4 *>(out);
+    __builtin_nontemporal_store(lo, dst + lane);
+    if (lane < 32) __builtin_nontemporal_store(hi, dst + lane + 64);
+}
+
+// k_rows_fast in PACKED fp32 arithmetic (fast_step_f32.h) for fp32 outputs: near-circular members, TEME, uniform
+// grid.  A lane carries two adjacent grid points (2i, 2i+1), a wave 128 per iteration: 1,536 contiguous bytes per
+// array, staged through LDS like the fp64 rows.  All constants are wave-uniform scalars (SGPRs).
 template <bool VEL>
-__global__ void __launch_bounds__(64, 5) k_rows_fast32(PropArgs p)
+__global__ void __launch_bounds__(64, AZ_ROWSF32_WAVES) k_rows_fast32(PropArgs p)
 {
     const unsigned lane = threadIdx.x;
     const unsigned per_xcd = gridDim.x >> 3; // XCD-aware row assignment, see k_rows
@@ -766,65 +801,91 @@ __global__ void __launch_bounds__(64, 5) k_rows_fast32(PropArgs p)
     const unsigned s = p.list[row];
     const unsigned fl = p.flags[s];
     if ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi) return;
-    const unsigned t_lo = blockIdx.y * p.tile;
+    const unsigned t_lo = blockIdx.y * p.tile; // the host keeps p.tile a multiple of 128 for this kernel
     const unsigned t_hi = min(t_lo + p.tile, p.n_times);
     unsigned base = t_lo;
     if (AZ_FLAG_ECLASS(fl) == 0) {
-        __shared__ __attribute__((aligned(16))) float rows_stage[2 * 64 * 3];
+        __shared__ __attribute__((aligned(16))) float rows_stage[2 * 128 * 3];
         const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
         float *prow = reinterpret_cast<float *>(p.pos) + (size_t)s * p.n_times * 3;
         float *vrow = VEL ? reinterpret_cast<float *>(p.vel) + (size_t)s * p.n_times * 3 : nullptr;
         const bool staged = AZ_ROWS_LDS_STORE &&
                             (((reinterpret_cast<size_t>(prow) | (VEL ? reinterpret_cast<size_t>(vrow) : 0)) & 15u) == 0);
-        FastK32 k;
-        {
-            FastK k0;
-            az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k0);
-            az_fast_window(p.el, p.n_pad, s, fma((double)t_lo, p.uniform_step, p.times[0] + off),
-                           fma((double)(t_hi - 1), p.uniform_step, p.times[0] + off), 64.0 * p.uniform_step, k0);
-            FastK32 k1;
-            az_load_fast32(k0, k1);
-#define X(n) k.n##_ = az_uniform32(k1.n##_);
-            AZ_FASTK_COLD(X) AZ_FASTK_HOT(X)
-#undef X
-            k.sab64 = az_uniform(k1.sab64); k.cc1d = az_uniform(k1.cc1d); k.d2d = az_uniform(k1.d2d);
-            k.d3d = az_uniform(k1.d3d); k.d4d = az_uniform(k1.d4d);
-            k.sdA = az_uniform(k1.sdA); k.cdA = az_uniform(k1.cdA); k.sdW = az_uniform(k1.sdW);
-            k.cdW = az_uniform(k1.cdW); k.tmid = az_uniform(k1.tmid);
-            k.sdU = az_uniform(k1.sdU); k.cdU = az_uniform(k1.cdU); k.tc = az_uniform(k1.tc);
-        }
         const double step = p.uniform_step;
         const double t_first = p.times[0] + off;
-        FastCarry fc;
-        az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc, fc);
+        __shared__ float once_lds[F32_NUM];
+        FastK32Bcast k;
+        FastCarry32 fc;
+        const unsigned stage_w = az_lds_address(rows_stage) + lane * 24, stage_r = az_lds_address(rows_stage) + lane * 16;
+        {
+            const double w_a = fma((double)t_lo, step, t_first), w_b = fma((double)(t_hi - 1), step, t_first);
+            FastK k0, k1;
+            az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k0);   // increments of 64 grid steps ...
+            az_double_increments(k0);                           // ... of 128: one lane step
+            az_fast_window(p.el, p.n_pad, s, w_a, w_b, 128.0 * step, k0);
+            az_load_fast(p.el, p.n_pad, s, fl, p.inc, 1, k1);   // increments of one grid step
+            az_fast_window(p.el, p.n_pad, s, w_a, w_b, step, k1);
+            FastK32 kk;
+            az_load_fast32(k0, k1, step, kk);
+#define X(n) if (lane == 0) once_lds[F32_##n] = kk.n##_;
+            AZ_F32_ONCE(X)
+#undef X
+#define X(n) k.n##_ = az_uniform32(kk.n##_);
+            AZ_F32_MANY(X)
+#undef X
+#define U(n) k.n = az_uniform(kk.n);
+            U(sab64) U(sdU) U(cdU) U(tc) U(tmid) U(s1U) U(c1U)
+#undef U
+            az_wave_lds_fence();
+            // seed one lane step (128 grid steps) BEFORE this lane's first even grid point
+            FastCarry f0;
+            az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + 2 * lane) - 128.0, step, t_first), k.tc, f0);
+            az_seed_fast32(f0, k1, fc);
+        }
 #pragma unroll 1
-        for (; base < t_hi; base += 64) {
-            const unsigned i = base + lane;
-            const bool live = i < t_hi;
+        for (; base < t_hi; base += 128) {
+            const unsigned i = base + 2 * lane;
+            const bool live_a = i < t_hi, live_b = i + 1 < t_hi;
             const double t = fma((double)i, step, t_first);
-            float r[3], v[3];
+            // re-read the once-per-step constants where they are used (see k_rows_fast; the opaque zero lives in a
+            // VGPR here: DS addresses are VGPRs, and a scalar one is copied once per read)
+            unsigned zero = 0;
+            asm volatile("" : "+v"(zero));
+            k.once = once_lds + zero;
+            az_f2 r[3], v[3];
 #if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
-            r[0] = (float)t; r[1] = r[0] + 1.0f; r[2] = r[0] + 2.0f; v[0] = r[0] + 3.0f; v[1] = r[0] + 4.0f; v[2] = r[0] + 5.0f;
+            r[0] = az_splat2((float)t); r[1] = r[0] + 1.0f; r[2] = r[0] + 2.0f; v[0] = r[0] + 3.0f; v[1] = r[0] + 4.0f; v[2] = r[0] + 5.0f;
 #else
             const bool bad = az_sgp4_fast_step_f32<VEL>(k, p.g, t, fc, r, v);
-            if (az_any(bad && live)) break;
+            if (az_any(bad && live_a)) break;
 #endif
 #if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only (every component stays live) */
-            if (!(live && (r[0] + r[1] + r[2] + (VEL ? v[0] + v[1] + v[2] : 0.0f)) == 1.2345e30f)) continue;
+            if (!(live_a && (r[0].x + r[1].x + r[2].x + r[0].y + r[1].y + r[2].y +
+                             (VEL ? v[0].x + v[1].x + v[2].x + v[0].y + v[1].y + v[2].y : 0.0f)) == 1.2345e30f)) continue;
 #endif
-            if (staged && base + 64 <= t_hi) {
-                rows_stage[lane * 3 + 0] = r[0]; rows_stage[lane * 3 + 1] = r[1]; rows_stage[lane * 3 + 2] = r[2];
-                if (VEL) { rows_stage[192 + lane * 3 + 0] = v[0]; rows_stage[192 + lane * 3 + 1] = v[1]; rows_stage[192 + lane * 3 + 2] = v[2]; }
-                az_wave_lds_fence();
-                az_flush_stage(rows_stage, prow + (size_t)base * 3, lane);
-                if (VEL) az_flush_stage(rows_stage + 192, vrow + (size_t)base * 3, lane);
-                az_wave_lds_fence();
-            } else if (live) {
-                const az_f3s a = {r[0], r[1], r[2]};
-                __builtin_nontemporal_store(a, reinterpret_cast<az_f3s *>(prow + (size_t)i * 3));
+            if (staged && base + 128 <= t_hi) {
+                az_stage_pair3(stage_w, r);
+                az_flush_pair3(stage_r, prow + (size_t)base * 3, lane);
                 if (VEL) {
-                    const az_f3s b = {v[0], v[1], v[2]};
-                    __builtin_nontemporal_store(b, reinterpret_cast<az_f3s *>(vrow + (size_t)i * 3));
+                    az_stage_pair3(stage_w + 1536, v);
+                    az_flush_pair3(stage_r + 1536, vrow + (size_t)base * 3, lane);
+                }
+            } else {
+                if (live_a) {
+                    const az_f3s a = {r[0].x, r[1].x, r[2].x};
+                    __builtin_nontemporal_store(a, reinterpret_cast<az_f3s *>(prow + (size_t)i * 3));
+                    if (VEL) {
+                        const az_f3s b = {v[0].x, v[1].x, v[2].x};
+                        __builtin_nontemporal_store(b, reinterpret_cast<az_f3s *>(vrow + (size_t)i * 3));
+                    }
+                }
+                if (live_b) {
+                    const az_f3s a = {r[0].y, r[1].y, r[2].y};
+                    __builtin_nontemporal_store(a, reinterpret_cast<az_f3s *>(prow + (size_t)(i + 1) * 3));
+                    if (VEL) {
+                        const az_f3s b = {v[0].y, v[1].y, v[2].y};
+                        __builtin_nontemporal_store(b, reinterpret_cast<az_f3s *>(vrow + (size_t)(i + 1) * 3));
+                    }
                 }
             }
         }

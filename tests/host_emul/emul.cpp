@@ -59,9 +59,9 @@ void emul_propagate(const double* fields, unsigned flags, const double* grav6, c
 
 // the branch-free uniform-grid step (fast_step.h) as one lane of the lane = time kernel runs it: windows of 12
 // steps of `dt` minutes (a 768-point segment of k_rows_fast), each seeded one increment before its first step.
-// bad_out[i] = the step's validation predicate.  f32 = 1: the fp32-arithmetic form (fast_step_f32.h).
+// bad_out[i] = the step's validation predicate.
 static void emul_fast_run(const double* fields, unsigned flags, const double* grav6, double ts0, double dt, int n, int ecc,
-                          int f32, double* out6, int* bad_out)
+                          double* out6, int* bad_out)
 {
     AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
     double inc[2 * AZ_INC_NUM];
@@ -76,33 +76,64 @@ static void emul_fast_run(const double* fields, unsigned flags, const double* gr
         FastK k;
         az_load_fast(fields, 1, 0, flags, inc, 0, k);
         az_fast_window(fields, 1, 0, ts0 + w0 * dt, ts0 + (w1 - 1) * dt, dt, k);
-        FastK32 k32;
-        az_load_fast32(k, k32);
         FastCarry st;
         az_seed_fast(fields, 1, 0, ts0 + (w0 - 1) * dt, k.tc_, st);
         for (int i = w0; i < w1; ++i) {
-            if (f32) {
-                float r[3], v[3];
-                bad_out[i] = az_sgp4_fast_step_f32<true>(k32, g, ts0 + i * dt, st, r, v) ? 1 : 0;
-                for (int j = 0; j < 3; ++j) { out6[6*i + j] = r[j]; out6[6*i + 3 + j] = v[j]; }
-            } else {
-                double r[3], v[3];
-                bad_out[i] = (ecc ? az_sgp4_fast_step<true, true>(k, g, RotCoefLit(), ts0 + i * dt, st, r, v)
-                                  : az_sgp4_fast_step<true, false>(k, g, RotCoefLit(), ts0 + i * dt, st, r, v)) ? 1 : 0;
-                memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
-            }
+            double r[3], v[3];
+            bad_out[i] = (ecc ? az_sgp4_fast_step<true, true>(k, g, RotCoefLit(), ts0 + i * dt, st, r, v)
+                              : az_sgp4_fast_step<true, false>(k, g, RotCoefLit(), ts0 + i * dt, st, r, v)) ? 1 : 0;
+            memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
         }
     }
 }
 void emul_propagate_fast(const double* fields, unsigned flags, const double* grav6, double ts0, double dt, int n,
                          int ecc, double* out6, int* bad_out)
 {
-    emul_fast_run(fields, flags, grav6, ts0, dt, n, ecc, 0, out6, bad_out);
+    emul_fast_run(fields, flags, grav6, ts0, dt, n, ecc, out6, bad_out);
 }
-void emul_propagate_fast32(const double* fields, unsigned flags, const double* grav6, double ts0, double dt, int n,
-                           double* out6, int* bad_out)
+
+// the packed fp32 step (fast_step_f32.h) as one lane of k_rows_fast32 runs it: the lane produces the grid points
+// (2j, 2j+1) of a grid with step `step`, j = 0..n-1, one lane step (`lane_steps` grid steps; 128 in the kernel) apart;
+// windows of at most 6 lane steps (a 768-point segment) and ~3,000 minutes.  out6: 2n rows in the order
+// (even_0, odd_0, even_1, ...), bad_out: n.
+void emul_propagate_fast32(const double* fields, unsigned flags, const double* grav6, double ts0, double step, int lane_steps,
+                           int n, double* out6, int* bad_out)
 {
-    emul_fast_run(fields, flags, grav6, ts0, dt, n, 0, 1, out6, bad_out);
+    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
+    const double dt = step * lane_steps;
+    double inc[2 * AZ_INC_NUM];
+    const double rate[2] = {fields[F_mdot], fields[F_argpdot]};
+    // as k_prep_inc lays it out: [0] 64 grid steps (doubled below, as the kernel does), [1] one grid step
+    for (int a = 0; a < 2; ++a) {
+        az_sincos(rate[a] * dt * 0.5, inc[2 * a], inc[2 * a + 1]);
+        az_sincos(rate[a] * step, inc[AZ_INC_NUM + 2 * a], inc[AZ_INC_NUM + 2 * a + 1]);
+    }
+    int wlen = (int)(3000.0 / (dt < 0 ? -dt : dt));
+    wlen = wlen < 1 ? 1 : (wlen > 6 ? 6 : wlen);
+    for (int w0 = 0; w0 < n; w0 += wlen) {
+        const int w1 = (w0 + wlen < n) ? w0 + wlen : n;
+        const double w_a = ts0 + w0 * dt, w_b = ts0 + (w1 - 1) * dt + step;
+        FastK k0, k1;
+        az_load_fast(fields, 1, 0, flags, inc, 0, k0);
+        az_double_increments(k0);
+        az_fast_window(fields, 1, 0, w_a, w_b, dt, k0);
+        az_load_fast(fields, 1, 0, flags, inc, 1, k1);
+        az_fast_window(fields, 1, 0, w_a, w_b, step, k1);
+        FastK32 k32;
+        az_load_fast32(k0, k1, step, k32);
+        FastCarry f0;
+        az_seed_fast(fields, 1, 0, ts0 + (w0 - 1) * dt, k0.tc_, f0);
+        FastCarry32 st;
+        az_seed_fast32(f0, k1, st);
+        for (int i = w0; i < w1; ++i) {
+            az_f2 r[3], v[3];
+            bad_out[i] = az_sgp4_fast_step_f32<true>(k32, g, ts0 + i * dt, st, r, v) ? 1 : 0;
+            for (int j = 0; j < 3; ++j) {
+                out6[12*i + j] = r[j].x; out6[12*i + 3 + j] = v[j].x;
+                out6[12*i + 6 + j] = r[j].y; out6[12*i + 9 + j] = v[j].y;
+            }
+        }
+    }
 }
 
 void emul_sincos(double x, double* s, double* c) { az_sincos(x, *s, *c); }

@@ -183,7 +183,7 @@ def emul():
     E.emul_init.argtypes = [C.c_void_p] * 3
     E.emul_propagate.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     E.emul_propagate_fast.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    E.emul_propagate_fast32.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    E.emul_propagate_fast32.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     E.emul_sincos.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
     E.emul_rcp.restype = C.c_double
     E.emul_rcp.argtypes = [C.c_double]
@@ -290,15 +290,16 @@ def test_emulated_fast_step_matches_oracle(emul, orc, dt):
 
 
 def test_emulated_fp32_step_accuracy(emul, orc):
-    """fast_step_f32.h host-compiled (fp32 host arithmetic is IEEE like the device's; v_rcp_f32 stands in as 1/x):
-    metres / mm/s against the oracle over a 10,000-minute span."""
+    """fast_step_f32.h host-compiled (fp32 host arithmetic is IEEE like the device's; v_rcp_f32 stands in as 1/x;
+    the packed pair is a two-float struct): one lane of k_rows_fast32 -- grid points (2j, 2j+1), 128 one-minute grid
+    steps between lane steps -- over a 10,000-minute span: metres / mm/s against the oracle."""
     from astroz_amd import synth
     pairs = synth.synth_catalog(200, 0, seed=19)
     tles = [orc.parse_lines(a, b) for a, b in pairs]
     cat = orc.Catalog(tles, 1)
     g = _grav6(1)
     nf = emul.emul_num_fields()
-    n, dt = 157, 64.0
+    n, step, lane_steps = 79, 1.0, 128
     off = (synth.START_JD - cat.epoch_jd) * 1440.0
     worst_r = worst_v = 0.0
     accepted = 0
@@ -306,17 +307,19 @@ def test_emulated_fp32_step_accuracy(emul, orc):
         raw = np.array([t.epoch_jd, t.mm_revday, t.ecc, t.incl_deg, t.raan_deg, t.argp_deg, t.ma_deg, t.bstar])
         fields = np.zeros(nf)
         flags = emul.emul_init(raw.ctypes.data, g.ctypes.data, fields.ctypes.data)
-        out = np.zeros((n, 6))
+        out = np.zeros((n, 2, 6))
         bad = np.zeros(n, dtype=np.int32)
-        emul.emul_propagate_fast32(fields.ctypes.data, flags, g.ctypes.data, off[i], dt, n, out.ctypes.data, bad.ctypes.data)
-        for k in range(0, n, 4):
+        emul.emul_propagate_fast32(fields.ctypes.data, flags, g.ctypes.data, off[i], step, lane_steps, n,
+                                   out.ctypes.data, bad.ctypes.data)
+        for k in range(0, n, 3):
             if bad[k]:
                 continue
-            accepted += 1
-            _, r, v = cat.propagate_one(i, off[i] + k * dt)
-            worst_r = max(worst_r, np.linalg.norm(out[k, :3] - r))
-            worst_v = max(worst_v, np.linalg.norm(out[k, 3:] - v))
-    assert accepted > 4000
+            for half in (0, 1):
+                accepted += 1
+                _, r, v = cat.propagate_one(i, off[i] + k * step * lane_steps + half * step)
+                worst_r = max(worst_r, np.linalg.norm(out[k, half, :3] - r))
+                worst_v = max(worst_v, np.linalg.norm(out[k, half, 3:] - v))
+    assert accepted > 8000
     assert worst_r < 4e-3 and worst_v < 6e-6, (worst_r, worst_v)
 
 
