@@ -407,6 +407,23 @@ def main():
                                    "sample": "not timed for this flag (see the default run's cpu_baseline)"}
         except Exception as exc:
             out["parity"] = {"failed": repr(exc)}
+    elif sharded and gather:
+        # config 4: the gathered, catalog-ordered arrays on rank 0 against the oracle on rows spread over every
+        # rank's cells (checks the shard placement of the all-gather on the real interconnect)
+        try:
+            from oracle import oracle
+            rows = np.unique(np.linspace(0, n_total - 1, 16 * world * plan.n_chunks).astype(np.int64))
+            cat = oracle.Catalog.from_pairs([allp[i] for i in rows], oracle.WGS72)
+            offs = (synth.START_JD - cat.epoch_jd) * 1440.0
+            _, p0, v0 = cat.propagate(times, offs, layout=oracle.SAT_MAJOR, threads=usable_cpus())
+            idx = torch.as_tensor(rows, device=cuda)
+            full = sp.results()
+            out["parity"] = {"sample_sats": int(len(rows)), "sample": "rows spread over all (chunk, rank) cells of the gathered array on rank 0",
+                             "max_abs_dr_km": float(np.abs(full[0][idx].cpu().numpy() - p0).max())}
+            if vel_on:
+                out["parity"]["max_abs_dv_kms"] = float(np.abs(full[1][idx].cpu().numpy() - v0).max())
+        except Exception as exc:
+            out["parity"] = {"failed": repr(exc)}
     elif world == 1 and not a.no_cpu_baseline:
         try:
             cb, (n_s, p0, v0) = cpu_baseline(pairs, times, offsets, a.cpu_seconds, layout == _native.SAT_MAJOR)

@@ -520,6 +520,8 @@ def test_bench_config4_code_path_smoke(native):
     cfg = j["config"]
     assert cfg["gather"] is True and cfg["rccl_ranks"] == 1 and cfg["chunks"] >= 1
     assert cfg["t_total_ms"] > 0 and cfg["t_kernel_ms"] > 0 and j["value"] > 0 and j["n_gpus"] == 1
+    # the gathered arrays against the oracle, as the N > 1 runs report it
+    assert j["parity"]["max_abs_dr_km"] < TOL_R and j["parity"]["max_abs_dv_kms"] < TOL_V, j["parity"]
 
 
 def test_c_host_end_to_end(c_client, orc, golden, synth, tmp_path):
