@@ -130,6 +130,68 @@ def cpu_baseline(pairs, times, offsets, seconds, sat_major):
     }, (n_s, p, v)
 
 
+class PowerSampler:
+    """Socket power and shader clock of one GPU while the benchmark loop runs, read from the amdgpu hwmon files (no
+    subprocess): the row kernels run on the board's power limit, so the clock they get is part of the result
+    (DESIGN.md 4a).  Everything here is best effort: a missing file just leaves its field out."""
+
+    def __init__(self, torch, index, period_s=0.004):
+        import glob
+        import threading
+        self.period, self.samples, self._stop, self.dir = period_s, [], threading.Event(), None
+        cands = []
+        try:
+            pr = torch.cuda.get_device_properties(index)
+            bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            cands += glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf)
+        except Exception:
+            pass
+        if not cands and torch.cuda.device_count() == 1:
+            cands = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        for d in cands:
+            if self._read(d, ("power1_average", "power1_input")) is not None:
+                self.dir = d
+                break
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(d, names):
+        for n in names:
+            try:
+                with open(os.path.join(d, n)) as f:
+                    return float(f.read().strip())
+            except (OSError, ValueError):
+                continue
+        return None
+
+    def _run(self):
+        while not self._stop.wait(self.period):
+            self.samples.append((self._read(self.dir, ("power1_average", "power1_input")), self._read(self.dir, ("freq1_input",))))
+
+    def start(self):
+        if self.dir:
+            self.thread.start()
+        return self
+
+    def stop(self):
+        if not self.dir:
+            return None
+        self._stop.set()
+        self.thread.join(timeout=1.0)
+        pw = sorted(p for p, _ in self.samples if p)
+        ck = sorted(c for _, c in self.samples if c)
+        if not pw:
+            return None
+        out = {"socket_w_median": pw[len(pw) // 2] / 1e6, "socket_w_max": pw[-1] / 1e6, "samples": len(pw),
+               "window": "preconditioning + warm-up steps (the same kernels, immediately before the timed steps)"}
+        if ck:
+            out["sclk_mhz_median"] = ck[len(ck) // 2] / 1e6
+        cap = self._read(self.dir, ("power1_cap",))
+        if cap:
+            out["socket_w_limit"] = cap / 1e6
+        return out
+
+
 def csrc_fingerprint():
     """sha256 (16 hex digits) over the kernel sources: ties a committed PMC measurement to the build it was taken on."""
     import hashlib
@@ -244,6 +306,7 @@ def main():
     # 0.2-ms kernel end inside that transient unless W is in the hundreds, so the same step is first run back
     # to back for a fixed wall time; the W warm-up steps and the K timed steps follow immediately.
     n_pre = 0
+    sampler = PowerSampler(torch, local_rank).start() if rank == 0 else None
     t_pre = time.perf_counter()
     if sharded:
         # the step contains collectives: every rank must run the same number of them
@@ -266,6 +329,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
 
+    power = sampler.stop() if sampler else None   # (not sampled during the timed steps: nothing else runs there)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -384,6 +448,7 @@ def main():
             "avg_launch_ms": launch_s * 1e3, "first_launch_ms_hipevent": last_kernel_ms,
             "algorithmic_bytes_per_launch": bytes_per_launch,
         },
+        "power": power,
         "fp64_valu": {
             "achieved": tflops, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TF,
             "flops_per_propagation": FLOPS_PER_PROP,
