@@ -129,6 +129,30 @@ def test_fp32_arithmetic_vs_oracle(native, orc, synth):
     assert np.abs(q - p0).max() <= 0.5 * np.spacing(np.float32(np.abs(p0).max())) + 1e-6
 
 
+@pytest.mark.parametrize("n_times,vel", [(127, True), (129, False), (333, True), (1001, True), (2048, False)])
+def test_fp32_arithmetic_ragged_sizes(native, orc, synth, n_times, vel):
+    """The packed kernel carries two grid points per lane and 128 per wave iteration: odd and short grids end in a
+    half-filled lane and a partial iteration, and rows of an odd length are not 16-byte aligned (direct stores instead
+    of the LDS-staged ones).  Every element must be written (NaN-prefilled buffers) and within the fp32 gate."""
+    import torch
+    pairs = _mixed_class_pairs(synth, 300, seed=70 + n_times)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    times = 5.0 + np.arange(n_times, dtype=np.float64)
+    off = (synth.START_JD - dev.epochs) * 1440.0
+    _, p0, v0 = cat.propagate(times, off, layout=orc.SAT_MAJOR)
+    p32 = torch.full((dev.n, n_times, 3), float("nan"), dtype=torch.float32, device="cuda")
+    v32 = torch.full_like(p32, float("nan")) if vel else None
+    torch.cuda.synchronize()
+    dev.propagate_device(times, off, p32.data_ptr(), v32.data_ptr() if vel else None, layout=native.SAT_MAJOR, f32=True)
+    dev.synchronize()
+    p = p32.cpu().numpy().astype(np.float64)
+    assert np.isfinite(p).all() and np.linalg.norm(p - p0, axis=2).max() < F32_TOL_R
+    if vel:
+        v = v32.cpu().numpy().astype(np.float64)
+        assert np.isfinite(v).all() and np.linalg.norm(v - v0, axis=2).max() < F32_TOL_V
+
+
 def test_fp32_arithmetic_config5_geometry(native, orc, synth):
     """Config 5 geometry (10,000 one-minute steps, fp32 pos+vel, satellite-major) in the fp32-arithmetic mode:
     sampled rows against the oracle over the whole week, range properties and a bit-identical repeat."""
