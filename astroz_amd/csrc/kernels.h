@@ -151,7 +151,7 @@ __device__ __forceinline__ void az_epilogue(double r[3], double v[3], int mode, 
 //      read-modify-write at the memory side.
 //  sat-major (s, t, 3): rows are n_times*24 B apart; AZ_SM_CHUNK steps are staged and flushed as
 //      8-byte words that are contiguous along each satellite's row.
-#define AZ_TM_ROW 192 /* doubles per wave and per array in the time-major staging slice */
+#define AZ_TM_ROW 256 /* doubles per wave and per array in the time-major staging slice: a 1,536-byte row + 512 */
 #define AZ_SM_ROW (AZ_SM_CHUNK * 3 + 1) /* +1 double: 26-bank row stride, conflict-free ds_write_b64 */
 
 typedef double az_d2 __attribute__((ext_vector_type(2)));
@@ -181,6 +181,22 @@ __device__ __forceinline__ void az_wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// time-major staged stores, one call per step and array (see k_propagate): L = the 2,048-byte staging slice, row = this
+// step's row in global memory, pitch = doubles between consecutive rows, par = step parity within the tile
+__device__ __forceinline__ void az_tm_flush(const double *L, double *row, size_t pitch, unsigned lane, unsigned par, bool last)
+{
+    const az_d2 *lp = reinterpret_cast<const az_d2 *>(L); // 128 sixteen-byte pieces
+    az_d2 *g = reinterpret_cast<az_d2 *>(row);
+    if (par == 0u) {
+        AZ_ST2(g + lane, lp[32u + lane]);                             // row pieces 0..63 (staged from byte 512)
+        if (last && lane < 32u) AZ_ST2(g + 64u + lane, lp[96u + lane]); // no odd step follows: the tail now
+    } else {
+        az_d2 *gprev = reinterpret_cast<az_d2 *>(row - pitch);
+        AZ_ST2(lane < 32u ? gprev + (64u + lane) : g + (lane - 32u), lp[lane < 32u ? 96u + lane : lane - 32u]);
+        AZ_ST2(g + (32u + lane), lp[32u + lane]);                     // row pieces 32..95 (staged from byte 0)
+    }
 }
 
 // FRAME = false: TEME output, no epilogue code at all (keeps its registers and SGPRs out of the
@@ -256,30 +272,28 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
 #endif
         if (LAYOUT == 1) {
             if (dense) {
-                lds_p[lane * 3 + 0] = r[0];
-                lds_p[lane * 3 + 1] = r[1];
-                lds_p[lane * 3 + 2] = r[2];
+                // A row of 64 satellites is 1,536 bytes = one and a HALF 1-KB store instructions, and a half-filled
+                // store instruction costs the write path as much as a full one (tools/store_pattern_probe.hip: 4.8 TB/s
+                // with the half stores, 6.2 without).  Two consecutive rows make three full instructions:
+                //   even step:  row i   pieces  0..63                          (its last 512 B wait in LDS)
+                //   odd step :  row i-1 pieces 64..95 | row i pieces 0..31,    then row i pieces 32..95
+                // The staging slice is 2,048 bytes per array: an even step stages its row at byte 512, an odd one at
+                // byte 0, so the even row's tail [1536, 2048) survives the odd step's staging without a copy.
+                const unsigned par = (i - t0) & 1u; // wave-uniform
+                double *sp = lds_p + (par ? 0 : 64);
+                sp[lane * 3 + 0] = r[0];
+                sp[lane * 3 + 1] = r[1];
+                sp[lane * 3 + 2] = r[2];
                 if (VEL) {
-                    lds_v[lane * 3 + 0] = v[0];
-                    lds_v[lane * 3 + 1] = v[1];
-                    lds_v[lane * 3 + 2] = v[2];
+                    double *sv = lds_v + (par ? 0 : 64);
+                    sv[lane * 3 + 0] = v[0];
+                    sv[lane * 3 + 1] = v[1];
+                    sv[lane * 3 + 2] = v[2];
                 }
                 az_wave_lds_fence();
-#if defined(AZ_ABLATE) && AZ_ABLATE == 3 /* tuning experiment: all stores hit one L2-resident 1.5-MB window */
-                const size_t ob = ((((size_t)i * p.stride_sats + s_first) * 3) & 0x1ffffu) & ~1ull;
-#else
                 const size_t ob = ((size_t)i * p.stride_sats + s_first) * 3;
-#endif
-                az_d2 *gp = reinterpret_cast<az_d2 *>(p.pos + ob);
-                const az_d2 *lp = reinterpret_cast<const az_d2 *>(lds_p);
-                AZ_ST2(gp + lane, lp[lane]);
-                if (lane < 32) AZ_ST2(gp + 64 + lane, lp[64 + lane]);
-                if (VEL) {
-                    az_d2 *gv = reinterpret_cast<az_d2 *>(p.vel + ob);
-                    const az_d2 *lv = reinterpret_cast<const az_d2 *>(lds_v);
-                    AZ_ST2(gv + lane, lv[lane]);
-                    if (lane < 32) AZ_ST2(gv + 64 + lane, lv[64 + lane]);
-                }
+                az_tm_flush(lds_p, p.pos + ob, (size_t)p.stride_sats * 3, lane, par, i + 1 == t1);
+                if (VEL) az_tm_flush(lds_v, p.vel + ob, (size_t)p.stride_sats * 3, lane, par, i + 1 == t1);
                 az_wave_lds_fence();
             } else if (wr) {
 #if defined(AZ_ABLATE) && AZ_ABLATE == 3
