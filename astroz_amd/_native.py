@@ -28,7 +28,7 @@ EXPORTS = [
     "azh_constellation_from_tle_lines", "azh_constellation_from_elements", "azh_constellation_subset", "azh_constellation_free",
     "azh_num_satellites", "azh_num_sgp4", "azh_num_sdp4", "azh_get_epochs", "azh_get_status",
     "azh_get_field", "azh_propagate_host", "azh_propagate_device", "azh_propagate_device_cached", "azh_propagate_device_window",
-    "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile", "azh_set_timing", "azh_set_fast_path", "azh_set_f32_arithmetic",
+    "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile", "azh_set_timing", "azh_set_fast_path", "azh_set_tile_kernel", "azh_set_f32_arithmetic",
     "azh_last_kernel_ms", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
     "azh_screen_target_host", "azh_screen_target_device", "azh_coarse_screen_device", "azh_coarse_screen_host",
     "azh_screen_all_host", "azh_constellation_from_omm_json", "azh_propagate_one_device", "azh_selftest_math",
@@ -177,6 +177,8 @@ def lib():
     L.azh_set_timing.restype = i32
     L.azh_set_fast_path.argtypes = [vp, i32]
     L.azh_set_fast_path.restype = i32
+    L.azh_set_tile_kernel.argtypes = [vp, i32]
+    L.azh_set_tile_kernel.restype = i32
     L.azh_set_f32_arithmetic.argtypes = [vp, i32]
     L.azh_set_f32_arithmetic.restype = i32
     L.azh_last_kernel_ms.argtypes = [vp]
@@ -406,6 +408,9 @@ class DeviceConstellation:
 
     def set_fast_path(self, enabled):
         check(lib().azh_set_fast_path(self._h, 1 if enabled else 0), "azh_set_fast_path")
+
+    def set_tile_kernel(self, enabled):
+        check(lib().azh_set_tile_kernel(self._h, 1 if enabled else 0), "azh_set_tile_kernel")
 
     def set_timing(self, enabled):
         check(lib().azh_set_timing(self._h, 1 if enabled else 0), "azh_set_timing")

@@ -124,6 +124,8 @@ struct azh_constellation {
     int cached_mode = 0;
     hipStream_t s_main = nullptr, s_deep = nullptr, s_ecc = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+    unsigned off_cat = 0; // d_list + off_cat: near-earth members in plain catalog order (k_tiles_fast: runs of consecutive rows)
+    bool tile_kernel = true; // time-major output on uniform grids through k_tiles_fast (azh_set_tile_kernel)
     unsigned off_circ = 0, n_circ = 0; // d_list + off_circ: near-earth members in catalog order, [n_circ of eccentricity class 0 | the rest]
     bool timed = false;
     bool timing = true; // record the ev_t0/ev_t1 pair around every launch set (azh_set_timing)
@@ -284,6 +286,10 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
         for (size_t s = 0; s < n; ++s)
             if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && !(c->h_flags[s] & AZ_FLAG_DEEP) && AZ_FLAG_ECLASS(c->h_flags[s]) != 0)
                 list.push_back((unsigned)s);
+        // ... and once in plain catalog order (time-major tiles of 16 consecutive rows, k_tiles_fast)
+        c->off_cat = (unsigned)list.size();
+        for (size_t s = 0; s < n; ++s)
+            if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && !(c->h_flags[s] & AZ_FLAG_DEEP)) list.push_back((unsigned)s);
         if (c->d_list.ensure(list.size()) != AZ_OK ||
             !hip_ok(hipMemcpy(c->d_list.p, list.data(), sizeof(unsigned) * list.size(), hipMemcpyHostToDevice), "H2D list")) {
             rc = AZ_ERR_HIP;
@@ -442,6 +448,23 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const
         if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
     }
+}
+
+// time-major output of the near-earth members on a uniform grid: 16-satellite tiles of lane = time waves (k_tiles_fast),
+// then the generic kernel on whatever their validation rejected (24-byte pieces, row by row)
+void launch_tiles(const PropArgs &a0, bool vel, hipStream_t st)
+{
+    PropArgs a = a0;
+    const double span = 3000.0 / std::max(std::fabs(a.uniform_step), 1e-9); // window of the fast step, see launch_rows2
+    const unsigned cap = span >= 4.0e9 ? 0xffffffc0u : std::max(64u, (unsigned)span / 64u * 64u);
+    a.tile = std::min(rows_tile(std::max((a.n_list + 15u) / 16u, 1u) * 16u, a.n_times, a.tile_forced), cap);
+    dim3 grid(((a.n_list + 15u) / 16u + 7u) / 8u * 8u, (a.n_times + a.tile - 1) / a.tile);
+    if (vel) hipLaunchKernelGGL((k_tiles_fast<true>), grid, dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((k_tiles_fast<false>), grid, dim3(1024), 0, st, a);
+    a.tm_rows = 1;
+    dim3 rgrid(256, 4);
+    if (vel) hipLaunchKernelGGL((k_rows<true, false, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_rows<false, false, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
 }
 
 void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStream_t st, const EccSide &side = EccSide())
@@ -605,10 +628,14 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         a.n_list = c->n_sgp4;
         a.tile = auto_tile(c->n_sgp4, n_times, c->tile_sgp4, 8);
         a.tile_forced = c->tile_sgp4;
-        if (a.inc != nullptr && use_rows(a, layout, false)) {
+        const bool tiles = c->tile_kernel && a.inc != nullptr && layout == AZ_LAYOUT_TIME_MAJOR && !f32 && a.mode == AZ_OUT_TEME &&
+                           a.mask == nullptr && a.screen_target == nullptr && n_times >= 64 &&
+                           c->n < 5000000u; // (k_tiles_fast packs an output column, 3 n, into 24 bits)
+        if (tiles) a.list = c->d_list.p + c->off_cat; // plain catalog order; the redo items index this list
+        if (a.inc != nullptr && (tiles || use_rows(a, layout, false))) {
             // uniform grid, satellite-major rows: every near-earth member -> k_rows_fast (near-circular or
             // eccentric Kepler form by class); what its validation rejects comes back through the redo list
-            a.list = c->d_list.p + c->off_circ; // [class 0 | other classes], catalog order inside each
+            if (!tiles) a.list = c->d_list.p + c->off_circ; // [class 0 | other classes], catalog order inside each
             a.n_list = c->n_sgp4;
             a.n_circ = c->n_circ;
             if (c->n_sgp4 > 0) {
@@ -628,7 +655,8 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
                 c->redo_parity ^= 1u;
             }
         }
-        if (a.n_list > 0) launch_propagate(a, layout, d_vel != nullptr, false, st, EccSide{c->s_ecc, c->ev_fork2, c->ev_join2});
+        if (a.n_list > 0 && tiles) launch_tiles(a, d_vel != nullptr, st);
+        else if (a.n_list > 0) launch_propagate(a, layout, d_vel != nullptr, false, st, EccSide{c->s_ecc, c->ev_fork2, c->ev_join2});
         HIP_TRY(hipGetLastError());
     }
     if (c->n_bad > 0) {
@@ -877,6 +905,13 @@ int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t enabled)
 {
     if (!c) return AZ_ERR_NULL_POINTER;
     c->f32_arith = enabled != 0;
+    return AZ_OK;
+}
+
+int32_t azh_set_tile_kernel(azh_constellation *c, int32_t enabled)
+{
+    if (!c) return AZ_ERR_NULL_POINTER;
+    c->tile_kernel = enabled != 0;
     return AZ_OK;
 }
 

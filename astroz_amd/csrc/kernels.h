@@ -771,6 +771,143 @@ __global__ void __launch_bounds__(64, FRAME ? 2 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
     }
 }
 
+// TIME-MAJOR output from the lane = time arithmetic (uniform grid, TEME, fp64): a workgroup of 16 waves takes 16
+// consecutive slots of the catalog-ordered near-earth list, every wave runs one satellite exactly like k_rows_fast
+// (scalar operands, branch-free step, near-circular or eccentric Kepler form by the satellite's class), and the
+// workgroup transposes each 64-step iteration through LDS: 64 time rows x (16 satellites x 24 bytes), flushed as
+// 384-byte runs.  Positions and velocities of four time rows are 192 sixteen-byte pieces = three full store instructions
+// per wave.  Two tile buffers alternate, so one barrier per iteration is enough: a wave writes buffer (k+1)&1 only after
+// passing the barrier of iteration k, which every wave reaches after it has read buffer (k-1)&1 out.
+// The lane = satellite kernel (k_propagate) spends 23 % more instructions per propagation with every operand in a VGPR
+// or a per-lane LDS word; this one has k_rows_fast's instruction stream.  Validation failures go to the redo list like
+// there (the generic kernel then writes that satellite's 24-byte pieces row by row); until it has run, the tile holds
+// stale values for that satellite.
+#define AZ_TILE_SATS 16
+#define AZ_TILE_PITCH 49 /* doubles per staged time row: 48 + 1 (lane stride 98 dwords: ds_write_b64 conflict-free per half-wave) */
+template <bool VEL>
+__global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
+{
+    constexpr unsigned NA = VEL ? 2u : 1u;
+    __shared__ __attribute__((aligned(16))) double cold_all[AZ_TILE_SATS * (FC_NUM + RC_NUM)];
+    __shared__ __attribute__((aligned(16))) double tile[2 * NA * 64 * AZ_TILE_PITCH];
+    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    double *cold_lds = cold_all + w * (FC_NUM + RC_NUM);
+    // XCD-aware tile assignment (workgroup b runs on XCD b % 8; gridDim.x is a multiple of 8): every XCD takes a contiguous
+    // range of tiles, so the cache lines that two neighbouring tiles share at the ends of their 384-byte runs meet in ONE L2
+    const unsigned tile_id = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const unsigned slot0 = tile_id * AZ_TILE_SATS, slot = slot0 + w;
+    if (slot0 >= p.n_list) return; // padding workgroup (uniform over the workgroup)
+    const unsigned n_valid = min((unsigned)AZ_TILE_SATS, p.n_list - slot0);
+    const bool have = w < n_valid;
+    const unsigned s = p.list[have ? slot : slot0];
+    const unsigned fl = p.flags[s];
+    const unsigned s_first = p.list[slot0];
+    // a full tile of consecutive catalog rows inside the row window leaves as 16-byte pieces (384-byte runs); any other
+    // tile -- deep-space or failed members between its rows, the end of the list, a row window cutting through it --
+    // as 8-byte pieces at per-satellite columns
+    const bool contig = n_valid == AZ_TILE_SATS && (p.list[slot0 + n_valid - 1] - s_first) == n_valid - 1 &&
+                        s_first >= p.row_lo && s_first + n_valid <= p.row_hi;
+    const unsigned t_lo = blockIdx.y * p.tile, t_hi = min(t_lo + p.tile, p.n_times);
+    bool dead = !(have && s >= p.row_lo && s < p.row_hi);
+    const bool ecc = AZ_FLAG_ECLASS(fl) != 0; // wave-uniform
+    const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
+    const double step = p.uniform_step, t_first = p.times[0] + off;
+    FastKBcast k;
+    FastCarry fc;
+    if (!dead) {
+        if (lane == 0) az_rotcoef_store([&](int j, double x) { cold_lds[FC_NUM + j] = x; });
+        FastK k0;
+        az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k0);
+        az_fast_window(p.el, p.n_pad, s, fma((double)t_lo, step, t_first), fma((double)(t_hi - 1), step, t_first), 64.0 * step, k0);
+#define X(n) if (lane == 0) cold_lds[FC_##n] = k0.n##_;
+        AZ_FASTK_COLD(X)
+#undef X
+#define X(n) k.n##_ = az_uniform(k0.n##_);
+        AZ_FASTK_HOT(X)
+#undef X
+        az_wave_lds_fence();
+        az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, fc);
+    }
+    // This thread's share of a tile flush, fixed for the whole kernel.  contig: pieces q = 1024 m + tid, m < 3, of the
+    // 3,072 sixteen-byte pieces (positions: 64 rows x 24, then velocities); otherwise doubles e = 1024 m + tid, m < 6, of
+    // the 6,144.  Per entry: the LDS word (16 bits, 0xffff = nothing to store) and (velocities << 31 | time row << 24 |
+    // output column); the host keeps 3 n below 2^24.
+    unsigned f_lds[3], f_rc[6];
+    {
+        const unsigned tid = threadIdx.x;
+#pragma unroll
+        for (unsigned m = 0; m < 6; ++m) {
+            unsigned lds = 0xffffu, rc = 0;
+            if (contig) {
+                if (m < 3) {
+                    const unsigned q = 1024u * m + tid, arr = q / 1536u, pq = q - arr * 1536u, row = pq / 24u, col = pq - row * 24u;
+                    if (arr < NA) {
+                        lds = arr * (64u * AZ_TILE_PITCH) + row * AZ_TILE_PITCH + col * 2u;
+                        rc = (row << 24) | (arr << 31) | (s_first * 3u + col * 2u);
+                    }
+                }
+            } else {
+                const unsigned e = 1024u * m + tid, arr = e / 3072u, pe = e - arr * 3072u, row = pe / 48u, d = pe - row * 48u, j = d / 3u;
+                if (arr < NA && j < n_valid) {
+                    const unsigned sj = p.list[slot0 + j];
+                    if (sj >= p.row_lo && sj < p.row_hi) {
+                        lds = arr * (64u * AZ_TILE_PITCH) + row * AZ_TILE_PITCH + d;
+                        rc = (row << 24) | (arr << 31) | (sj * 3u + (d - j * 3u));
+                    }
+                }
+            }
+            if (m & 1u) f_lds[m >> 1] |= lds << 16;
+            else f_lds[m >> 1] = lds;
+            f_rc[m] = rc;
+        }
+    }
+    unsigned kiter = 0;
+#pragma unroll 1
+    for (unsigned base = t_lo; base < t_hi; base += 64, ++kiter) {
+        const unsigned i = base + lane;
+        const bool live = i < t_hi;
+        double r[3], v[3];
+        if (!dead) {
+            const double t = fma((double)i, step, t_first);
+            unsigned zero = 0;
+            asm volatile("" : "+s"(zero));
+            k.cold = cold_lds + zero;
+            const RotCoefLds rk{cold_lds + FC_NUM + zero};
+            const bool bad = ecc ? az_sgp4_fast_step<VEL, true>(k, p.g, rk, t, fc, r, v) : az_sgp4_fast_step<VEL, false>(k, p.g, rk, t, fc, r, v);
+            if (az_any(bad && live)) {
+                dead = true;
+                if (lane == 0) {
+                    const unsigned it = atomicAdd(p.redo_count, 1u);
+                    p.redo_items[3 * (size_t)it + 0] = slot;
+                    p.redo_items[3 * (size_t)it + 1] = base;
+                    p.redo_items[3 * (size_t)it + 2] = t_hi;
+                }
+            }
+        }
+        double *buf = tile + (kiter & 1u) * (NA * 64 * AZ_TILE_PITCH);
+        if (!dead) {
+            double *q = buf + lane * AZ_TILE_PITCH + w * 3;
+            q[0] = r[0]; q[1] = r[1]; q[2] = r[2];
+            if (VEL) {
+                q += 64 * AZ_TILE_PITCH;
+                q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
+            }
+        }
+        __syncthreads();
+        const size_t gbase = (size_t)base * p.stride_sats * 3;
+#pragma unroll
+        for (unsigned m = 0; m < 6; ++m) {
+            if (contig && m >= 3) break;
+            const unsigned lds = (f_lds[m >> 1] >> ((m & 1u) * 16u)) & 0xffffu;
+            const unsigned row = (f_rc[m] >> 24) & 63u;
+            if (lds == 0xffffu || base + row >= t_hi) continue;
+            double *g = ((f_rc[m] >> 31) ? p.vel : p.pos) + gbase + (size_t)row * p.stride_sats * 3 + (f_rc[m] & 0xffffffu);
+            if (contig) *reinterpret_cast<az_d2s *>(g) = *reinterpret_cast<const az_d2s *>(buf + lds);
+            else g[0] = buf[lds];
+        }
+    }
+}
+
 // Staging of the packed kernel, DS instructions written by hand.  Component j of a lane's two grid points sits in
 // one register pair while the row wants (x y z)(x y z): ds_write2_b32 puts the two halves three floats apart without
 // a register move (the compiler pairs NEIGHBOURING floats into 64-bit writes instead: twelve v_mov per iteration).
@@ -1022,7 +1159,12 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
 #endif
         // direct 24-byte (12-byte) pieces per lane, contiguous across the wave: this kernel is paced by its
         // arithmetic, and for it the LDS transpose of k_rows_fast measures slower (0.269 vs 0.262 ms)
-        if (live) {
+        if (live && redo && p.tm_rows) {
+            // redo pass behind the time-major tile kernel (k_tiles_fast): this lane's 24 bytes of time row i
+            const size_t ob = ((size_t)i * p.stride_sats + s) * 3;
+            az_put3(reinterpret_cast<out_t *>(p.pos) + ob, r);
+            if (VEL) az_put3(reinterpret_cast<out_t *>(p.vel) + ob, v);
+        } else if (live) {
             az_put3_stream(prow + (size_t)i * 3, r);
             if (VEL) az_put3_stream(vrow + (size_t)i * 3, v);
         }

@@ -74,6 +74,8 @@ def parse_args():
                     help="with fp32 outputs: fp64 arithmetic rounded at the store instead of the fp32-arithmetic kernel")
     ap.add_argument("--no-fast-path", action="store_true",
                     help="disable the branch-free uniform-grid step (A/B against the generic tier-voting loop)")
+    ap.add_argument("--no-tile-kernel", action="store_true",
+                    help="time-major layout: the lane = satellite kernel instead of the 16-satellite tile kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0)
     return ap.parse_args()
@@ -257,6 +259,8 @@ def main():
         dev.set_time_tile(a.tile, a.tile)
     if a.no_fast_path:
         dev.set_fast_path(False)
+    if a.no_tile_kernel:
+        dev.set_tile_kernel(False)
     if a.f32_rounded:
         dev.set_f32_arithmetic(False)
     n_local = dev.n
@@ -424,7 +428,9 @@ def main():
         if a.f32_out and not a.f32_rounded and not a.no_fast_path:
             kname = kname.replace("k_rows_fast<", "k_rows_fast32<")
     else:
-        kname = "k_propagate<time-major,%s> (lane = satellite)" % ("pos+vel" if vel_on else "pos")
+        kname = ("k_tiles_fast<%s> (16-satellite tiles of lane = time waves, LDS transpose) + k_rows redo pass"
+                 if not (a.no_fast_path or a.no_tile_kernel or a.f32_out) else "k_propagate<time-major,%s> (lane = satellite)") % (
+                     "pos+vel" if vel_on else "pos")
     out = {
         "metric": ("propagations/sec, 13,478 sats x 1,440 times, at 1/2/4/8 MI355X" if not a.config5_share else
                    "propagations/sec, config 5 (1M sats x 10,000 times, fp32, 8 MI355X): one GPU's 125,000-satellite share"),

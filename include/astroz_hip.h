@@ -297,6 +297,10 @@ int32_t azh_set_time_tile(azh_constellation *c, uint32_t sgp4_tile, uint32_t sdp
 /* enable (default) / disable the branch-free uniform-grid step (astroz_amd/csrc/fast_step.h).  Results
  * of the two paths agree to rounding; the switch exists so that tests can compare them. */
 int32_t azh_set_fast_path(azh_constellation *c, int32_t enabled);
+/* enable (default) / disable the 16-satellite tile kernel for time-major output on uniform grids (k_tiles_fast: lane =
+ * time arithmetic, transposed through LDS); disabled, the lane = satellite kernel serves that layout.  Results of the
+ * two agree to rounding; the switch exists so that tests and benchmarks can compare them. */
+int32_t azh_set_tile_kernel(azh_constellation *c, int32_t enabled);
 /* enable (default) / disable the hipEvent pair recorded around every propagate call; disabling it
  * removes two event records per call from tight replay loops (azh_last_kernel_ms then returns -1) */
 int32_t azh_set_timing(azh_constellation *c, int32_t enabled);

@@ -578,3 +578,58 @@ def test_c_host_end_to_end(c_client, orc, golden, synth, tmp_path):
     assert np.array_equal(got[..., 0].astype(np.uint8), re_)
     ok = re_ == 0
     assert np.abs(got[..., 1:4] - rp)[ok].max() < 1e-6 and np.abs(got[..., 4:7] - rv)[ok].max() < 1e-9
+
+
+@pytest.mark.parametrize("n_near,n_deep,n_times,stride_pad,vel", [(333, 0, 200, 0, True), (1000, 37, 1441, 5, True), (47, 3, 64, 0, False),
+                                                               (2050, 0, 777, 0, True)])
+def test_time_major_tile_kernel(native, orc, synth, n_near, n_deep, n_times, stride_pad, vel):
+    """k_tiles_fast (time-major output from lane = time waves, 16-satellite tiles transposed through LDS) against the
+    oracle and against the lane = satellite kernel: catalogs that are not a multiple of 16, grids that are not a
+    multiple of 64, mixed eccentricity classes inside a tile, deep-space members breaking the runs of consecutive rows,
+    a padded row stride, row windows, and members that fail validation (redo pass writing 24-byte pieces)."""
+    import torch
+    pairs = _mixed_class_pairs(synth, n_near, 90 + n_near)
+    if n_deep:
+        deep = synth.synth_catalog(n_near=0, n_deep=n_deep, seed=7)
+        rng = np.random.default_rng(3)
+        for d in deep:
+            pairs.insert(int(rng.integers(0, len(pairs))), d)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    times = 3.0 + np.arange(n_times, dtype=np.float64)
+    off = (synth.START_JD - dev.epochs) * 1440.0
+    off[::97] += 25000.0   # a few members far from epoch: validation failures -> redo pass
+    e0, p0, v0 = cat.propagate(times, off, layout=orc.TIME_MAJOR, velocities=vel)
+    stride = dev.n + stride_pad
+    ok = torch.as_tensor((e0 == 0).T.copy(), device="cuda")[:, :, None]
+
+    def run(tiles, windows=None):
+        dev.set_tile_kernel(tiles)
+        p = torch.full((n_times, stride, 3), float("nan"), dtype=torch.float64, device="cuda")
+        v = torch.full_like(p, float("nan")) if vel else None
+        dev.propagate_device(times, off, p.data_ptr(), v.data_ptr() if vel else None, layout=native.TIME_MAJOR, stride=stride)
+        if windows:
+            p.fill_(float("nan"))
+            if vel:
+                v.fill_(float("nan"))
+            for lo, hi in windows:
+                dev.propagate_device_window(lo, hi, p.data_ptr(), v.data_ptr() if vel else None, layout=native.TIME_MAJOR, stride=stride)
+        dev.synchronize()
+        return p, v
+
+    pt, vt = run(True)
+    pl, vl = run(False)
+    for got_p, got_v in ((pt, vt), (pl, vl)):
+        gp = got_p[:, :dev.n]
+        assert not bool(torch.isnan(gp).any())
+        assert float(((gp - torch.as_tensor(p0, device="cuda")) * ok).abs().max()) < TOL_R
+        if vel:
+            assert float(((got_v[:, :dev.n] - torch.as_tensor(v0, device="cuda")) * ok).abs().max()) < TOL_V
+    if stride_pad:
+        assert bool(torch.isnan(pt[:, dev.n:]).all())          # the padding columns are never written
+    # row windows that cut through tiles
+    cut = [(0, 7), (7, 100), (100, dev.n // 2 + 3), (dev.n // 2 + 3, 10**6)]
+    pw, vw = run(True, cut)
+    assert torch.equal(pw[:, :dev.n], pt[:, :dev.n])
+    if vel:
+        assert torch.equal(vw[:, :dev.n], vt[:, :dev.n])
