@@ -21,7 +21,7 @@ for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write", "pmc_grbm", "sq", "sq2"
         q = ("select kernel_name, counter_name, sum(value), count(*), avg(duration), max(vgpr_count), max(sgpr_count), "
              "max(lds_block_size), max(scratch_size), max(grid_size), max(workgroup_size) from counters_collection group by 1,2")
         for r in cur.execute(q):
-            if "k_propagate" in r[0] or "k_rows" in r[0]:
+            if "k_propagate" in r[0] or "k_rows" in r[0] or "k_tiles" in r[0]:
                 vals[(r[0], r[1])] = r[2:]
 kern = sorted(set(k for k, _ in vals))
 for k in kern:
