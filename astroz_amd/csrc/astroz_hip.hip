@@ -458,13 +458,25 @@ void launch_tiles(const PropArgs &a0, bool vel, hipStream_t st)
     const double span = 3000.0 / std::max(std::fabs(a.uniform_step), 1e-9); // window of the fast step, see launch_rows2
     const unsigned cap = span >= 4.0e9 ? 0xffffffc0u : std::max(64u, (unsigned)span / 64u * 64u);
     a.tile = std::min(rows_tile(std::max((a.n_list + 15u) / 16u, 1u) * 16u, a.n_times, a.tile_forced), cap);
+    const bool ecef = a.mode == AZ_OUT_ECEF; // the Greenwich-angle table of a time segment is staged in LDS
+    if (ecef) a.tile = std::min(a.tile, (unsigned)AZ_TILE_SEG_MAX);
     dim3 grid(((a.n_list + 15u) / 16u + 7u) / 8u * 8u, (a.n_times + a.tile - 1) / a.tile);
-    if (vel) hipLaunchKernelGGL((k_tiles_fast<true>), grid, dim3(1024), 0, st, a);
-    else hipLaunchKernelGGL((k_tiles_fast<false>), grid, dim3(1024), 0, st, a);
+    if (ecef) {
+        if (vel) hipLaunchKernelGGL((k_tiles_fast<true, true>), grid, dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((k_tiles_fast<false, true>), grid, dim3(1024), 0, st, a);
+    } else {
+        if (vel) hipLaunchKernelGGL((k_tiles_fast<true, false>), grid, dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((k_tiles_fast<false, false>), grid, dim3(1024), 0, st, a);
+    }
     a.tm_rows = 1;
     dim3 rgrid(256, 4);
-    if (vel) hipLaunchKernelGGL((k_rows<true, false, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_rows<false, false, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
+    if (ecef) {
+        if (vel) hipLaunchKernelGGL((k_rows<true, true, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_rows<false, true, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
+    } else {
+        if (vel) hipLaunchKernelGGL((k_rows<true, false, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_rows<false, false, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
+    }
 }
 
 void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStream_t st, const EccSide &side = EccSide())
@@ -628,7 +640,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         a.n_list = c->n_sgp4;
         a.tile = auto_tile(c->n_sgp4, n_times, c->tile_sgp4, 8);
         a.tile_forced = c->tile_sgp4;
-        const bool tiles = c->tile_kernel && a.inc != nullptr && layout == AZ_LAYOUT_TIME_MAJOR && !f32 && a.mode == AZ_OUT_TEME &&
+        const bool tiles = c->tile_kernel && a.inc != nullptr && layout == AZ_LAYOUT_TIME_MAJOR && !f32 && a.mode != AZ_OUT_GEODETIC &&
                            a.mask == nullptr && a.screen_target == nullptr && n_times >= 64 &&
                            c->n < 5000000u; // (k_tiles_fast packs an output column, 3 n, into 24 bits)
         if (tiles) a.list = c->d_list.p + c->off_cat; // plain catalog order; the redo items index this list

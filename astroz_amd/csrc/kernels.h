@@ -783,13 +783,17 @@ __global__ void __launch_bounds__(64, FRAME ? 2 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
 // there (the generic kernel then writes that satellite's 24-byte pieces row by row); until it has run, the tile holds
 // stale values for that satellite.
 #define AZ_TILE_SATS 16
+#define AZ_TILE_SEG_MAX 1024 /* longest time segment of an ECEF launch (its Greenwich-angle table sits in LDS) */
 #define AZ_TILE_PITCH 49 /* doubles per staged time row: 48 + 1 (lane stride 98 dwords: ds_write_b64 conflict-free per half-wave) */
-template <bool VEL>
+template <bool VEL, bool ECEF = false>
 __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
 {
     constexpr unsigned NA = VEL ? 2u : 1u;
     __shared__ __attribute__((aligned(16))) double cold_all[AZ_TILE_SATS * (FC_NUM + RC_NUM)];
     __shared__ __attribute__((aligned(16))) double tile[2 * NA * 64 * AZ_TILE_PITCH];
+    // ECEF output: (sin,cos) of the Greenwich angle of this segment's time steps, staged once (a load inside the loop would
+    // wait for the stores in flight); geodetic output stays with the lane = satellite kernel
+    __shared__ double gst[ECEF ? 2 * AZ_TILE_SEG_MAX : 2];
     const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     double *cold_lds = cold_all + w * (FC_NUM + RC_NUM);
     // XCD-aware tile assignment (workgroup b runs on XCD b % 8; gridDim.x is a multiple of 8): every XCD takes a contiguous
@@ -809,6 +813,13 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
                         s_first >= p.row_lo && s_first + n_valid <= p.row_hi;
     const unsigned t_lo = blockIdx.y * p.tile, t_hi = min(t_lo + p.tile, p.n_times);
     bool dead = !(have && s >= p.row_lo && s < p.row_hi);
+    if (ECEF) {
+        for (unsigned j = threadIdx.x; j < t_hi - t_lo; j += 1024u) {
+            gst[2 * j] = p.sin_g[t_lo + j];
+            gst[2 * j + 1] = p.cos_g[t_lo + j];
+        }
+        __syncthreads();
+    }
     const bool ecc = AZ_FLAG_ECLASS(fl) != 0; // wave-uniform
     const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
     const double step = p.uniform_step, t_first = p.times[0] + off;
@@ -874,6 +885,12 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
             k.cold = cold_lds + zero;
             const RotCoefLds rk{cold_lds + FC_NUM + zero};
             const bool bad = ecc ? az_sgp4_fast_step<VEL, true>(k, p.g, rk, t, fc, r, v) : az_sgp4_fast_step<VEL, false>(k, p.g, rk, t, fc, r, v);
+            if (ECEF) {
+                const unsigned jj = min(i, t_hi - 1) - t_lo;
+                const double sg = gst[2 * jj], cg = gst[2 * jj + 1];
+                az_to_ecef(r, sg, cg);
+                if (VEL) az_to_ecef(v, sg, cg);
+            }
             if (az_any(bad && live)) {
                 dead = true;
                 if (lane == 0) {

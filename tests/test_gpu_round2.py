@@ -627,6 +627,22 @@ def test_time_major_tile_kernel(native, orc, synth, n_near, n_deep, n_times, str
             assert float(((got_v[:, :dev.n] - torch.as_tensor(v0, device="cuda")) * ok).abs().max()) < TOL_V
     if stride_pad:
         assert bool(torch.isnan(pt[:, dev.n:]).all())          # the padding columns are never written
+    # ECEF output (the default of the high-level propagate()): the tile kernel rotates by the Greenwich angle before
+    # the transpose; geodetic output stays with the lane = satellite kernel -- both against the oracle
+    for mode, omode in ((native.OUT_ECEF, orc.ECEF), (native.OUT_GEODETIC, orc.GEODETIC)):
+        _, q0, w0 = cat.propagate(times, off, layout=orc.TIME_MAJOR, velocities=vel, mode=omode, reference_jd=synth.START_JD)
+        dev.set_tile_kernel(True)
+        pe = torch.full((n_times, stride, 3), float("nan"), dtype=torch.float64, device="cuda")
+        ve = torch.full_like(pe, float("nan")) if vel else None
+        dev.propagate_device(times, off, pe.data_ptr(), ve.data_ptr() if vel else None, layout=native.TIME_MAJOR, stride=stride,
+                             mode=mode, reference_jd=synth.START_JD)
+        dev.synchronize()
+        dq = ((pe[:, :dev.n] - torch.as_tensor(q0, device="cuda")) * ok).abs()
+        if mode == native.OUT_GEODETIC:
+            dq[..., 1] = torch.minimum(dq[..., 1], 2 * np.pi - dq[..., 1])   # longitude wraps
+        assert float(dq.max()) < TOL_R, (mode, float(dq.max()))
+        if vel and mode == native.OUT_ECEF:
+            assert float(((ve[:, :dev.n] - torch.as_tensor(w0, device="cuda")) * ok).abs().max()) < TOL_V
     # row windows that cut through tiles
     cut = [(0, 7), (7, 100), (100, dev.n // 2 + 3), (dev.n // 2 + 3, 10**6)]
     pw, vw = run(True, cut)
