@@ -1236,6 +1236,9 @@ __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
     out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + (size_t)s * p.n_times * 3 : nullptr;
     double best_d2 = __builtin_inf();
     unsigned best_t = 0xffffffffu;
+    Sdp4Acc acc; // resonance accelerations of this lane's current integrator state (no state yet)
+    acc.atime = __builtin_nan("");
+    acc.xndt = acc.xnddt = acc.xldot = 0.0;
 #pragma unroll 1
     for (unsigned base = t_lo; base < t_hi; base += 64) {
         const unsigned i = base + lane;
@@ -1266,7 +1269,9 @@ __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
             cy.xni = e(H_no_unkozai);
         }
         double r[3], v[3];
-        int rc = az_sdp4_step<VEL>(e, cold, p.g, rk, t, cy, r, v);
+        const bool res = irez != 0; // wave-uniform
+        if (res) az_resonance_cached(e, cold, t, cy, acc);
+        int rc = az_sdp4_step<VEL>(e, cold, p.g, rk, t, cy, r, v, res ? &acc : nullptr);
         if (SINK == AZ_SINK_SCREEN) {
             const double *q = p.screen_target + (size_t)(live ? i : t_hi - 1) * 3;
             const double dx = q[0] - r[0], dy = q[1] - r[1], dz = q[2] - r[2];

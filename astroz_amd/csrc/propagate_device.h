@@ -491,11 +491,58 @@ AZ_DEVICE void az_resonance_advance(const Lane &e, const Cold &cold, double t, S
     }
 }
 
+// The accelerations depend on the integrator state only, and the state changes every 720 minutes: a lane that
+// walks a time grid keeps them next to the atime they belong to (the state after k integrator steps is a pure function of
+// k, so an equal atime means an equal state) and re-evaluates only when its state moved -- two iterations in eleven on a
+// one-minute grid instead of every step (3 sincos per evaluation for synchronous members, 10 for half-day ones).
+struct Sdp4Acc {
+    double atime, xndt, xnddt, xldot;
+};
+// cy: the chunk's seed on entry, this lane's integrator state for time t on return (reference restart rule and stepping,
+// src/Sdp4.zig L786-801); acc: the accelerations at that state.  One evaluation site serves the steps and the final state.
+template <class Lane, class Cold>
+AZ_DEVICE void az_resonance_cached(const Lane &e, const Cold &cold, double t, Sdp4Carry &cy, Sdp4Acc &acc)
+{
+    if (cy.atime == 0.0 || t * cy.atime <= 0.0 || fabs(t) < fabs(cy.atime)) {
+        cy.atime = 0.0;
+        cy.xni = e(H_no_unkozai);
+        cy.xli = e(H_xlamo);
+    }
+    bool have = (cy.atime == acc.atime);
+    double xndt = acc.xndt, xnddt = acc.xnddt, xldot = acc.xldot;
+    const double delt = (t > 0.0) ? AZ_STEPP : -AZ_STEPP;
+    for (;;) {
+        const bool adv = fabs(t - cy.atime) >= AZ_STEPP;
+        if (!az_any(adv | !have)) break;
+        if (az_any(!have)) {
+            double a, b, c;
+            az_resonance_accel(e, cold, cy.xli, cy.xni, cy.atime, a, b, c);
+            if (!have) {
+                xndt = a;
+                xnddt = b;
+                xldot = c;
+            }
+            have = true;
+        }
+        if (adv) {
+            cy.xli += xldot * delt + xndt * AZ_STEP2;
+            cy.xni += xndt * delt + xnddt * AZ_STEP2;
+            cy.atime += delt;
+            have = false;
+        }
+    }
+    acc.atime = cy.atime;
+    acc.xndt = xndt;
+    acc.xnddt = xnddt;
+    acc.xldot = xldot;
+}
+
 // one deep-space propagation; returns 0 / 1 (eccentricity) / 6 (decayed) per the scalar
-// reference path (src/Sdp4.zig L914-921, L937-938, L967).
+// reference path (src/Sdp4.zig L914-921, L937-938, L967).  pre != nullptr: cy is already this lane's integrator state
+// for t and *pre the accelerations at it (az_resonance_cached).
 template <bool VEL, class Lane, class Cold>
 AZ_DEVICE int az_sdp4_step(const Lane &e, const Cold &cold, const AzGrav &g, const RotK &rk, double t,
-                           Sdp4Carry &cy, double r[3], double v[3])
+                           Sdp4Carry &cy, double r[3], double v[3], const Sdp4Acc *pre = nullptr)
 {
     const double t2 = t * t;
     const double tempa = 1.0 - e(H_cc1) * t;
@@ -514,9 +561,15 @@ AZ_DEVICE int az_sdp4_step(const Lane &e, const Cold &cold, const AzGrav &g, con
     double a23 = e(H_a_base); // (xke/nm)^(2/3)
     if (az_any(e.irez != 0)) {
         const bool res = e.irez != 0;
-        az_resonance_advance(e, cold, t, cy);
         double xndt, xnddt, xldot;
-        az_resonance_accel(e, cold, cy.xli, cy.xni, cy.atime, xndt, xnddt, xldot);
+        if (pre != nullptr) {
+            xndt = pre->xndt;
+            xnddt = pre->xnddt;
+            xldot = pre->xldot;
+        } else {
+            az_resonance_advance(e, cold, t, cy);
+            az_resonance_accel(e, cold, cy.xli, cy.xni, cy.atime, xndt, xnddt, xldot);
+        }
         if (res) {
             const double ft = t - cy.atime;
             nm = cy.xni + xndt * ft + xnddt * ft * ft * 0.5;

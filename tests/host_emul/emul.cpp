@@ -136,6 +136,33 @@ void emul_propagate_fast32(const double* fields, unsigned flags, const double* g
     }
 }
 
+// the generic deep-space step as one lane of k_rows_deep runs it: per iteration the lane starts from a chunk seed (the
+// integrator state at seed_t[i], what k_deep_seed prepares), brings it to its own time with the cached accelerations
+// (az_resonance_cached) and runs az_sdp4_step on the prepared state
+void emul_propagate_deep_cached(const double* fields, unsigned flags, const double* grav6, const double* ts, const double* seed_t,
+                                int n, double* out6, int* rc_out, int* evals_out)
+{
+    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
+    Sdp4Lane e; double cold_store[D_NUM];
+    const ColdLds cold{cold_store};
+    az_load_sdp4(fields, 1, 0, flags, e, cold);
+    Sdp4Acc acc{__builtin_nan(""), 0.0, 0.0, 0.0};
+    int evals = 0;
+    for (int i = 0; i < n; ++i) {
+        Sdp4Carry cy{0.0, e(H_xlamo), e(H_no_unkozai)};
+        if (e.irez != 0) az_resonance_advance(e, cold, seed_t[i], cy);
+        double r[3], v[3];
+        const double before = acc.atime;
+        if (e.irez != 0) az_resonance_cached(e, cold, ts[i], cy, acc);
+        if (!(before == acc.atime)) ++evals;
+        int rc = az_sdp4_step<true>(e, cold, g, az_rotk(), ts[i], cy, r, v, e.irez != 0 ? &acc : nullptr);
+        if (rc) { r[0]=r[1]=r[2]=v[0]=v[1]=v[2]=0.0; }
+        memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
+        rc_out[i] = rc;
+    }
+    *evals_out = evals;
+}
+
 void emul_sincos(double x, double* s, double* c) { az_sincos(x, *s, *c); }
 double emul_rcp(double x) { return az_rcp(x); }
 double emul_rsqrt(double x) { return az_rsqrt(x); }

@@ -184,6 +184,7 @@ def emul():
     E.emul_propagate.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     E.emul_propagate_fast.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     E.emul_propagate_fast32.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    E.emul_propagate_deep_cached.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     E.emul_sincos.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
     E.emul_rcp.restype = C.c_double
     E.emul_rcp.argtypes = [C.c_double]
@@ -286,6 +287,55 @@ def test_emulated_fast_step_matches_oracle(emul, orc, dt):
                 worst_v = max(worst_v, np.abs(out[k, 3:] - v).max())
     assert accepted > 0.8 * total, (accepted, total)
     assert ecc_total > 0 and ecc_accepted > 0.7 * ecc_total, (ecc_accepted, ecc_total)
+    assert worst_r < 1e-6 and worst_v < 1e-9, (worst_r, worst_v)
+
+
+def test_emulated_deep_step_with_cached_resonance_accelerations(emul, orc):
+    """k_rows_deep keeps the resonance accelerations next to the integrator state they belong to and re-evaluates them
+    only when the state moves (az_resonance_cached).  One lane, host-compiled, against the oracle: a one-minute-grid lane
+    walking away from and towards epoch with kernel-style chunk seeds, and a random walk with arbitrary seeds (restart
+    rule); the accelerations must be evaluated far less often than once per step on the regular walks."""
+    from astroz_amd import synth
+    pairs = synth.synth_catalog(0, 120, seed=31)
+    tles = [orc.parse_lines(a, b) for a, b in pairs]
+    cat = orc.Catalog(tles, 1)
+    g = _grav6(1)
+    nf = emul.emul_num_fields()
+    rng = np.random.default_rng(4)
+    worst_r = worst_v = 0.0
+    resonant = 0
+    for i, t in enumerate(tles):
+        raw = np.array([t.epoch_jd, t.mm_revday, t.ecc, t.incl_deg, t.raan_deg, t.argp_deg, t.ma_deg, t.bstar])
+        fields = np.zeros(nf)
+        flags = emul.emul_init(raw.ctypes.data, g.ctypes.data, fields.ctypes.data)
+        if flags & 0xff:
+            continue
+        irez = (flags >> 10) & 3
+        base = float(rng.uniform(-3000.0, 3000.0))
+        walks = []
+        fwd = base + 64.0 * np.arange(60)                      # lane 0 of consecutive 64-minute chunks, ascending
+        seeds = np.where(fwd * (fwd + 63.0) <= 0.0, 0.0, np.where(np.abs(fwd + 63.0) < np.abs(fwd), fwd + 63.0, fwd))
+        walks.append((fwd, seeds, True))
+        bwd = fwd[::-1].copy()                                  # the same chunks, descending
+        walks.append((bwd, seeds[::-1].copy(), True))
+        rnd = rng.uniform(-20000.0, 20000.0, 60)                # arbitrary times, arbitrary seeds: restart rule
+        walks.append((rnd, rng.uniform(-20000.0, 20000.0, 60), False))
+        for ts, sd, regular in walks:
+            out = np.zeros((len(ts), 6))
+            rc = np.zeros(len(ts), dtype=np.int32)
+            evals = C.c_int(0)
+            emul.emul_propagate_deep_cached(fields.ctypes.data, flags, g.ctypes.data, np.ascontiguousarray(ts).ctypes.data,
+                                            np.ascontiguousarray(sd).ctypes.data, len(ts), out.ctypes.data, rc.ctypes.data, C.byref(evals))
+            for k in range(0, len(ts), 3):
+                orc_rc, r, v = cat.propagate_one(i, ts[k])
+                assert orc_rc == rc[k]
+                if orc_rc == 0:
+                    worst_r = max(worst_r, np.abs(out[k, :3] - r).max())
+                    worst_v = max(worst_v, np.abs(out[k, 3:] - v).max())
+            if irez and regular:
+                assert evals.value <= len(ts) // 4 + 3, (i, irez, evals.value)   # one state per 720 minutes, not per step
+        resonant += bool(irez)
+    assert resonant > 20
     assert worst_r < 1e-6 and worst_v < 1e-9, (worst_r, worst_v)
 
 
