@@ -8,8 +8,13 @@ gfx950 HIP kernels behind ``libastroz_hip.so`` (C ABI in ``include/astroz_hip.h`
 
 Element text goes to the library as it is: TLE text is read by the library's fixed-column reader, OMM JSON by
 its OMM reader (full JSON precision; the reference's Python layer re-renders OMM as 69-column text first and
-loses digits there).  This package never opens a network connection: ``source`` is text or a local path
-(the reference also resolves CelesTrak group names and URLs -- fetch the text yourself and pass it in).
+loses digits there).
+
+Network sources are OPT-IN.  Like the reference, ``source`` may also be a URL or a CelesTrak group name and
+``norad_id=`` a catalog number (or a list), but nothing is downloaded unless the caller allows it: pass
+``fetch=callable(url) -> str`` (or install one with :func:`set_fetcher`), or ``allow_network=True`` to use the
+built-in ``urllib`` fetcher.  Without either such a source raises ``ValueError`` naming the URL it would have
+fetched.  The fetched text goes to the same native readers as any other text.
 """
 import os
 from datetime import datetime, timezone
@@ -24,21 +29,71 @@ __version__ = "0.2.0"
 _UNIX_EPOCH_JD = 2440587.5
 
 
-def _as_text(source):
-    """The element text behind `source`: the string itself when it already is element data, else the
-    contents of the local file it names."""
+_CELESTRAK_GP = "https://celestrak.org/NORAD/elements/gp.php"
+_fetcher = None
+
+
+def set_fetcher(fn):
+    """Install the process-wide fetcher used for URL / CelesTrak-group / ``norad_id`` sources: ``fn(url) -> str``
+    (``None`` removes it).  Returns the previous one."""
+    global _fetcher
+    prev, _fetcher = _fetcher, fn
+    return prev
+
+
+def celestrak_url(group=None, norad_id=None, fmt="tle"):
+    """The CelesTrak GP query for a group name (``"starlink"``, ``"active"``, ...) or catalog number(s)."""
+    if (group is None) == (norad_id is None):
+        raise ValueError("exactly one of group / norad_id")
+    if norad_id is not None:
+        ids = norad_id if isinstance(norad_id, (list, tuple)) else [norad_id]
+        return "%s?CATNR=%s&FORMAT=%s" % (_CELESTRAK_GP, ",".join(str(int(i)) for i in ids), fmt)
+    return "%s?GROUP=%s&FORMAT=%s" % (_CELESTRAK_GP, str(group).strip().lower(), fmt)
+
+
+def _urllib_fetch(url):
+    import urllib.request
+    req = urllib.request.Request(url, headers={"User-Agent": "astroz_amd/%s" % __version__})
+    with urllib.request.urlopen(req, timeout=60) as resp:
+        return resp.read().decode("utf-8")
+
+
+def _download(url, fetch, allow_network):
+    fn = fetch or _fetcher or (_urllib_fetch if allow_network else None)
+    if fn is None:
+        raise ValueError("this source needs a download (%s): pass fetch=callable(url) -> str, install one with "
+                         "astroz_amd.set_fetcher, or pass allow_network=True" % url)
+    text = fn(url)
+    if not isinstance(text, str) or not text.strip():
+        raise ValueError("the fetcher returned no element text for %s" % url)
+    return text
+
+
+def _as_text(source, norad_id=None, fetch=None, allow_network=False):
+    """The element text behind `source`: the string itself when it already is element data, the contents of the
+    local file it names, or -- opt-in, see the module docstring -- what a URL / CelesTrak group name / `norad_id`
+    resolves to (reference: bindings/python/astroz/__init__.py L163-181)."""
+    if norad_id is not None:
+        return _download(celestrak_url(norad_id=norad_id), fetch, allow_network)
+    if source is None:
+        raise ValueError("Must specify 'source' or 'norad_id'")
     if not isinstance(source, str):
-        raise TypeError("source must be a string: TLE text, OMM JSON text, or a local file path")
+        raise TypeError("source must be a string: TLE text, OMM JSON text, a local file path, a URL or a CelesTrak group")
     head = source.lstrip()[:1]
     if head in ("{", "["):
         return source
-    if "\n" not in source and len(source) < 4096 and os.path.isfile(source):
+    one_line = "\n" not in source and len(source) < 4096
+    if one_line and source.lower().startswith(("http://", "https://")):
+        return _download(source, fetch, allow_network)
+    if one_line and os.path.isfile(source):
         with open(source, "r", encoding="utf-8") as fh:
             return fh.read()
     if any(ln.lstrip().startswith("1 ") for ln in source.splitlines()):
         return source
-    raise ValueError("source is neither TLE text, OMM JSON, nor an existing local file "
-                     "(astroz_amd does not fetch CelesTrak groups or URLs)")
+    name = source.strip()
+    if one_line and name and all(c.isalnum() or c in "-_" for c in name):
+        return _download(celestrak_url(group=name), fetch, allow_network)
+    raise ValueError("source is neither TLE text, OMM JSON, an existing local file, a URL nor a CelesTrak group name")
 
 
 def _is_json(text):
@@ -127,17 +182,14 @@ class Sgp4Constellation:
 class Constellation:
     """Pre-parsed, device-resident orbital elements for repeated propagation and screening.
 
-    ``source``: raw TLE text, raw OMM JSON (object or array), or a local file holding either.
+    ``source``: raw TLE text, raw OMM JSON (object or array), a local file holding either, or -- with ``fetch=`` /
+    ``allow_network=True`` / :func:`set_fetcher` -- a URL or CelesTrak group name; ``norad_id=`` likewise.
     Output ordering follows the reference: near-earth satellites first ``[0, n_sgp4)``, deep-space after
     (reference __init__.py L374-393) -- but the deep-space rows ARE propagated here (the reference leaves them
     unwritten, L509-530).  The gravity model is WGS84, the default of the reference's ``from_tle_text``."""
 
-    def __init__(self, source=None, *, norad_id=None, gravity_model=WGS84, device=0):
-        if norad_id is not None:
-            raise ValueError("norad_id lookups need a CelesTrak download: fetch the elements and pass the text")
-        if source is None:
-            raise ValueError("Must specify 'source'")
-        text = _as_text(source)
+    def __init__(self, source=None, *, norad_id=None, gravity_model=WGS84, device=0, fetch=None, allow_network=False):
+        text = _as_text(source, norad_id, fetch, allow_network)
         build = _native.DeviceConstellation.from_omm_json if _is_json(text) else _native.DeviceConstellation.from_tle_text
         try:
             full = build(text, gravity_model, device)
@@ -180,13 +232,15 @@ def _minutes_and_offsets(const, times, start_time):
     return minutes, (start - const._dev.epochs) * 1440.0, start
 
 
-def propagate(source, times, *, start_time=None, output="ecef", velocities=False, norad_id=None):
+def propagate(source, times, *, start_time=None, output="ecef", velocities=False, norad_id=None, fetch=None,
+              allow_network=False):
     """Propagate satellites to ``times`` (minutes from ``start_time``, default now).
 
     Returns positions ``(n_times, n_satellites, 3)`` [km; or (lat rad, lon rad, alt km) for
     ``output="geodetic"`` -- radians, as the reference's kernel emits (Constellation.zig L497)], plus
     velocities ``(n_times, n_satellites, 3)`` km/s if ``velocities=True``.  Reference: __init__.py L411-532."""
-    const = source if isinstance(source, Constellation) else Constellation(source, norad_id=norad_id)
+    const = source if isinstance(source, Constellation) else Constellation(source, norad_id=norad_id, fetch=fetch,
+                                                                           allow_network=allow_network)
     if output not in _native.OUTPUT_MODES:
         raise ValueError("output must be 'ecef', 'teme', or 'geodetic'")
     minutes, offsets, start = _minutes_and_offsets(const, times, start_time)
@@ -198,7 +252,7 @@ def propagate(source, times, *, start_time=None, output="ecef", velocities=False
     return (pos, vel) if velocities else pos
 
 
-def screen(source, times, threshold=10.0, *, target=None, start_time=None, norad_id=None):
+def screen(source, times, threshold=10.0, *, target=None, start_time=None, norad_id=None, fetch=None, allow_network=False):
     """Screen a constellation for conjunction events (reference __init__.py L535-658).
 
     ``target`` set: fused propagate+screen on the GPU against that satellite; returns
@@ -208,7 +262,8 @@ def screen(source, times, threshold=10.0, *, target=None, start_time=None, norad
     closer than ``threshold`` km at a grid time, sorted by (t, s, other).  Positions stay in HBM.
     Deep-space members take part in both modes (the reference's fused routine covers pure-SGP4
     constellations only and falls back to propagate-then-screen otherwise, L655-658)."""
-    const = source if isinstance(source, Constellation) else Constellation(source, norad_id=norad_id)
+    const = source if isinstance(source, Constellation) else Constellation(source, norad_id=norad_id, fetch=fetch,
+                                                                           allow_network=allow_network)
     minutes, offsets, start = _minutes_and_offsets(const, times, start_time)
     if target is not None:
         return const._dev.screen_target(minutes, int(target), float(threshold), offsets, reference_jd=start)
@@ -229,4 +284,4 @@ def coarse_screen(positions, num_sats, threshold, valid_mask=None):
 
 
 __all__ = ["__version__", "Tle", "Sgp4Constellation", "Constellation", "propagate", "screen", "coarse_screen",
-           "WGS72", "WGS84"]
+           "set_fetcher", "celestrak_url", "WGS72", "WGS84"]

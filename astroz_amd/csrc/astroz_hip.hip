@@ -130,7 +130,8 @@ struct azh_constellation {
     bool timed = false;
     bool timing = true; // record the ev_t0/ev_t1 pair around every launch set (azh_set_timing)
     unsigned tile_sgp4 = 0, tile_sdp4 = 0;
-    bool f32_arith = true; // fp32 outputs: fp32 arithmetic where fast_step_f32.h applies (azh_set_f32_arithmetic)
+    bool f32_arith = false; // fp32 outputs: false (default) = fp64 arithmetic rounded once at the store; true = packed fp32
+                            // arithmetic where fast_step_f32.h applies (opt-in: azh_set_f32_arithmetic, metres / mm/s)
     bool fast_path = true; // use the branch-free uniform-grid step where it applies (azh_set_fast_path)
 };
 
@@ -1622,6 +1623,13 @@ int32_t azh_group_propagate_allgather(azh_group *g, const double *times, size_t 
             azh_constellation *c = g->shard[d];
             if (set_device(c) != AZ_OK) { rc = AZ_ERR_HIP; break; }
             const size_t cnt = g->cell_hi(k, d) - g->cell_lo(k, d);
+            if (cnt < g->rows) {
+                // a partial (or empty) cell: the all-gather still moves `rows` rows of it -- its padding rows are zeros,
+                // not whatever an earlier call left in the grow-only buffers
+                const size_t at = (k * g->rows + cnt) * row, len = (g->rows - cnt) * row * sizeof(double);
+                if (!hip_ok(hipMemsetAsync(c->d_host_pos.p + at, 0, len, c->s_main), "memset pad") ||
+                    (d_vel && !hip_ok(hipMemsetAsync(c->d_host_vel.p + at, 0, len, c->s_main), "memset pad"))) { rc = AZ_ERR_HIP; break; }
+            }
             if (cnt) rc = launch_all(c, c->d_host_pos.p, d_vel ? c->d_host_vel.p : nullptr, AZ_LAYOUT_SAT_MAJOR, 0, nullptr,
                                      c->s_main, 0, k * g->rows, k * g->rows + cnt);
             if (rc != AZ_OK) break;

@@ -236,7 +236,9 @@ int parse_omm_object(JsonCursor &c, TleRecord &r)
             if (!c.string(key) || !c.eat(':') || !c.value(val, is_str)) return -999;
             const bool null = !is_str && val == "null";
             double d = 0.0;
-            const bool num = !is_str && !null && to_double(val, d);
+            // numeric fields also arrive as JSON strings (Space-Track style: "MEAN_MOTION":"15.5"); the reference's
+            // std.json accepts string tokens for f64 / u32 fields (src/Tle.zig parseOmm), so does this reader
+            const bool num = !null && !val.empty() && to_double(val, d);
             auto want = [&](double &dst, unsigned bit) { if (!num) rc = -999; else { dst = d; seen |= bit; } };
             if (key == "EPOCH") { if (!is_str) rc = -999; else { int e = parse_iso_epoch(val, r); if (e) rc = e; seen |= K_EPOCH; } }
             else if (key == "MEAN_MOTION") want(r.mm_revday, K_MM);

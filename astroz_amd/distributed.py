@@ -152,6 +152,7 @@ class ShardedPropagator:
         # local blocks (what the kernels write) and the gathered, catalog-ordered result
         self.local = [torch.zeros((cap, n_times, 3), dtype=dtype, device=self.device) for _ in range(n_arr)]
         self.full = [torch.empty((plan.padded, n_times, 3), dtype=dtype, device=self.device) for _ in range(n_arr)]
+        self._ordered = False
         if self.cuda:
             self.compute = torch.cuda.Stream(device=self.device)
             self.comm = torch.cuda.Stream(device=self.device)
@@ -180,6 +181,13 @@ class ShardedPropagator:
         """Propagate the shard (all chunks) and, if `gather`, all-gather every chunk.  Asynchronous on
         CUDA: call :meth:`wait` (or synchronize) before reading ``results()``."""
         torch = self.torch
+        if self.cuda and not self._ordered:
+            # first step: three streams have touched what the kernels are about to use -- the zero-fill of the local
+            # blocks (torch's current stream at construction), the input staging of the caller's propagate_device call
+            # (the handle's own stream or the one the caller passed) and this object's compute stream.  One device-wide
+            # wait orders them all; later steps are ordered by the stream waits below.
+            torch.cuda.synchronize(self.device)
+            self._ordered = True
         if self.cuda:
             # the next step's kernels must not overwrite local blocks the previous gathers still read
             self.compute.wait_stream(self.comm)

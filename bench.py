@@ -69,13 +69,18 @@ def parse_args():
                          "satellites (16 = 128-byte aligned rows)")
     ap.add_argument("--config5-share", action="store_true",
                     help="BASELINE config 5, one GPU's share: 125,000 synthetic satellites (seed 20260927) x 10,000 one-minute "
-                         "steps, fp32 pos+vel (30 GB), fp32 arithmetic where it applies; parity on sampled rows")
-    ap.add_argument("--f32-rounded", action="store_true",
-                    help="with fp32 outputs: fp64 arithmetic rounded at the store instead of the fp32-arithmetic kernel")
+                         "steps, fp32 pos+vel (30 GB); fp64 arithmetic rounded at the store unless --f32-arith; parity on sampled rows")
+    ap.add_argument("--f32-arith", action="store_true",
+                    help="with fp32 outputs: opt into the packed-fp32-arithmetic kernel (4 m / 6 mm/s) instead of the default "
+                         "fp64 arithmetic rounded once at the store (0.25 m / 0.24 mm/s)")
     ap.add_argument("--no-fast-path", action="store_true",
                     help="disable the branch-free uniform-grid step (A/B against the generic tier-voting loop)")
     ap.add_argument("--no-tile-kernel", action="store_true",
                     help="time-major layout: the lane = satellite kernel instead of the 16-satellite tile kernel")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default run only: skip the `secondary` block (the other configurations of BASELINE.json, each a "
+                         "few steps, timed after the headline region)")
+    ap.add_argument("--secondary-skip", default="", help="comma-separated keys of secondary workloads to skip (e.g. config5_share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=5.0)
     return ap.parse_args()
@@ -194,6 +199,163 @@ class PowerSampler:
         return out
 
 
+def _sample_rows(n, k):
+    return np.unique(np.linspace(0, n - 1, k).astype(np.int64))
+
+
+def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
+    """The non-headline configurations, each a few steps, run AFTER the headline's timed region on the same device
+    and stream (the headline fields never depend on anything here).  One entry per workload: ms_per_step (HIP events
+    on the launch stream around K back-to-back steps after W warm-ups), value, HBM roofline fraction of the step, and
+    parity against the fp64 oracle on rows spread over the catalog (all times).  A failing entry reports the
+    exception and never takes the bench line down."""
+    from oracle import oracle
+    sptr = stream.cuda_stream
+    res = []
+
+    def timed(fn, warm, steps):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(steps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    def case(key, workload, kernel, dev, pairs, n_times, *, layout, vel=True, f32=False, mode=0, steps=20, warm=5,
+             cold=False, rows=16, ref_jd=0.0, arith32=False):
+        if key in skip:
+            return
+        ent = {"key": key, "workload": workload, "kernel": kernel}
+        try:
+            n = dev.n
+            dev.set_f32_arithmetic(arith32)
+            times = np.arange(n_times, dtype=np.float64)
+            offs = (synth.START_JD - dev.epochs) * 1440.0
+            shape = (n_times, n, 3) if layout == _native.TIME_MAJOR else (n, n_times, 3)
+            odt = torch.float32 if f32 else torch.float64
+            pos = torch.empty(shape, dtype=odt, device=cuda)
+            v = torch.empty(shape, dtype=odt, device=cuda) if vel else None
+            pp, vp = pos.data_ptr(), (v.data_ptr() if vel else None)
+            dev.propagate_device(times, offs, pp, vp, mode=mode, reference_jd=ref_jd, layout=layout, stream=sptr, f32=f32)
+            torch.cuda.synchronize()
+            ms = timed(lambda: dev.propagate_device_cached(pp, vp, layout=layout, stream=sptr, f32=f32), warm, steps)
+            props = n * n_times
+            nbytes = props * (BYTES_OUT_PV if vel else BYTES_OUT_P) * (0.5 if f32 else 1.0) + n_times * 8 + n * ELEM_BYTES_PER_SAT
+            ent.update({"ms_per_step": ms, "value": props / (ms / 1e3), "unit": "propagations/s", "steps": steps, "warmup": warm,
+                        "n_sats": n, "n_times": n_times, "dtype_out": "f32" if f32 else "f64",
+                        "roofline": {"bound": "hbm", "achieved": nbytes / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}})
+            if cold:
+                # a NEW time grid every call: input staging (H2D of times/offsets), k_prep_inc, k_deep_seed and the step
+                # itself, host wall clock around call + synchronize
+                cs = []
+                for j in range(5):
+                    tj = times + 0.25 * (j + 1)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    dev.propagate_device(tj, offs, pp, vp, mode=mode, reference_jd=ref_jd, layout=layout, stream=sptr, f32=f32)
+                    torch.cuda.synchronize()
+                    cs.append((time.perf_counter() - t0) * 1e3)
+                ent["cold_grid_call_ms"] = {"median": sorted(cs)[len(cs) // 2], "min": min(cs),
+                                            "what": "first call on a new time grid: H2D staging + k_prep_inc + k_deep_seed + the step, "
+                                                    "host wall clock incl. the final synchronize"}
+                dev.propagate_device(times, offs, pp, vp, mode=mode, reference_jd=ref_jd, layout=layout, stream=sptr, f32=f32)
+                torch.cuda.synchronize()
+            # parity on sampled rows, all times
+            rws = _sample_rows(n, rows)
+            cat = oracle.Catalog.from_pairs([pairs[i] for i in rws], oracle.WGS72)
+            _, p0, v0 = cat.propagate(times, offs[rws], mode=mode, reference_jd=ref_jd, layout=oracle.SAT_MAJOR,
+                                      threads=usable_cpus())
+            idx = torch.as_tensor(rws, device=cuda)
+            take = (lambda x: x[:, idx].permute(1, 0, 2)) if layout == _native.TIME_MAJOR else (lambda x: x[idx])
+            gp = take(pos).cpu().numpy().astype(np.float64)
+            if mode == 2:
+                # geodetic rows are (lat rad, lon rad, alt km): longitude differences modulo 2 pi
+                d = gp - p0
+                d[..., 1] = (d[..., 1] + np.pi) % (2 * np.pi) - np.pi
+                ent["parity"] = {"rows": int(len(rws)), "max_abs_dlatlon_rad": float(np.abs(d[..., :2]).max()),
+                                 "max_abs_dalt_km": float(np.abs(d[..., 2]).max())}
+            else:
+                ent["parity"] = {"rows": int(len(rws)), "max_abs_dr_km": float(np.abs(gp - p0).max())}
+            if vel:
+                ent["parity"]["max_abs_dv_kms"] = float(np.abs(take(v).cpu().numpy().astype(np.float64) - v0).max())
+            del pos, v
+        except Exception as exc:
+            ent["failed"] = repr(exc)
+        res.append(ent)
+
+    TM, SM = _native.TIME_MAJOR, _native.SAT_MAJOR
+    ref_jd = synth.START_JD
+    n2 = dev2.n
+    case("config2_pos_only", "config 2, positions only (%d x 1,440, fp64 TEME, satellite-major)" % n2,
+         "k_rows_fast<pos> + redo", dev2, pairs2, 1440, layout=SM, vel=False)
+    case("config2_time_major", "config 2, TIME-major output (the reference benchmark's physical layout, api.py L304-314), fp64 TEME pos+vel",
+         "k_tiles_fast<pos+vel> + redo", dev2, pairs2, 1440, layout=TM)
+    case("config2_ecef_time_major", "config 2, ECEF time-major (the default of the reference's high-level propagate(), "
+         "Constellation.zig L489-506), fp64 pos+vel", "k_tiles_fast<pos+vel,ECEF> + redo", dev2, pairs2, 1440, layout=TM, mode=1, ref_jd=ref_jd)
+    case("config2_ecef_sat_major", "config 2, ECEF satellite-major, fp64 pos+vel", "k_rows_fast<pos+vel,FRAME> + redo",
+         dev2, pairs2, 1440, layout=SM, mode=1, ref_jd=ref_jd)
+    case("config2_geodetic_time_major", "config 2, geodetic (lat, lon [rad], alt km) time-major, positions only",
+         "k_propagate<time-major,pos,FRAME> (lane = satellite)", dev2, pairs2, 1440, layout=TM, vel=False, mode=2, ref_jd=ref_jd, steps=10)
+    dev3 = pairs3 = None
+    if not {"config3_sat_major", "config3_time_major"} <= set(skip):
+        pairs3 = synth.synth_catalog(n_near=13478, n_deep=1522, seed=20260926)
+        dev3 = _native.DeviceConstellation.from_tle_lines(pairs3, _native.WGS72, cuda.index or 0)
+        dev3.set_timing(False)
+    if dev3 is not None:
+        case("config3_sat_major", "config 3: 13,478 near-earth + 1,522 deep-space SDP4 x 1,440, fp64 TEME pos+vel, satellite-major "
+             "(steady: resonance seeds of the grid cached in the handle; cold_grid_call_ms: a new grid every call)",
+             "k_rows_fast + k_rows_deep + redo (+ k_deep_seed, k_prep_inc on a new grid)", dev3, pairs3, 1440, layout=SM, cold=True, rows=48)
+        case("config3_time_major", "config 3, TIME-major output, fp64 TEME pos+vel",
+             "k_tiles_fast + deep-space rows + redo", dev3, pairs3, 1440, layout=TM, rows=48)
+        dev3.close()
+    if "one_satellite" not in skip:
+        ent = {"key": "one_satellite", "kernel": "k_one_satellite",
+               "workload": "one satellite (ISS-like, near-earth) x 10,000,000 times through azh_propagate_one_device: device-resident "
+                           "tsince in, pos+vel out (reference: 30.8 M/s single-thread sgp4_array, README.md L25-33)"}
+        try:
+            n = 10_000_000
+            ts = torch.linspace(0.0, 14400.0, n, dtype=torch.float64, device=cuda)
+            po = torch.empty((n, 3), dtype=torch.float64, device=cuda)
+            ve = torch.empty((n, 3), dtype=torch.float64, device=cuda)
+            ms = timed(lambda: dev2.propagate_one_device(0, ts.data_ptr(), n, po.data_ptr(), ve.data_ptr(), None, sptr), 2, 5)
+            nbytes = n * 56.0
+            ent.update({"ms_per_step": ms, "value": n / (ms / 1e3), "unit": "propagations/s",
+                        "roofline": {"bound": "hbm", "achieved": nbytes / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}})
+            cat = oracle.Catalog.from_pairs([pairs2[0]], oracle.WGS72)
+            pick = _sample_rows(n, 4096)
+            tsel = ts[torch.as_tensor(pick, device=cuda)].cpu().numpy()
+            _, p0, v0 = cat.propagate(tsel, None, layout=oracle.SAT_MAJOR)
+            ent["parity"] = {"points": int(len(pick)),
+                             "max_abs_dr_km": float(np.abs(po[torch.as_tensor(pick, device=cuda)].cpu().numpy() - p0[0]).max()),
+                             "max_abs_dv_kms": float(np.abs(ve[torch.as_tensor(pick, device=cuda)].cpu().numpy() - v0[0]).max())}
+            del ts, po, ve
+        except Exception as exc:
+            ent["failed"] = repr(exc)
+        res.append(ent)
+    if not {"config5_share", "config5_share_f32arith"} <= set(skip):
+        try:
+            pairs5 = synth.synth_catalog(n_near=125000, n_deep=0, seed=20260927)
+            dev5 = _native.DeviceConstellation.from_tle_lines(pairs5, _native.WGS72, cuda.index or 0)
+            dev5.set_timing(False)
+            c5 = "config 5, ONE GPU's share of 8: 125,000 synthetic satellites (seed 20260927) x 10,000 one-minute steps, fp32 pos+vel (30 GB), satellite-major, "
+            case("config5_share", c5 + "DEFAULT arithmetic: fp64, every component rounded once at the store",
+                 "k_rows_fast<SINK_F32> (+ eccentric members, redo)", dev5, pairs5, 10000, layout=SM, f32=True, steps=5, warm=2, rows=24)
+            case("config5_share_f32arith", c5 + "OPT-IN packed fp32 arithmetic (azh_set_f32_arithmetic(c, 1): 4 m / 6 mm/s)",
+                 "k_rows_fast32 (+ eccentric members, redo)", dev5, pairs5, 10000, layout=SM, f32=True, steps=5, warm=2, rows=24,
+                 arith32=True)
+            dev5.close()
+        except Exception as exc:
+            res.append({"key": "config5_share", "failed": repr(exc)})
+    return res
+
+
 def csrc_fingerprint():
     """sha256 (16 hex digits) over the kernel sources: ties a committed PMC measurement to the build it was taken on."""
     import hashlib
@@ -261,8 +423,7 @@ def main():
         dev.set_fast_path(False)
     if a.no_tile_kernel:
         dev.set_tile_kernel(False)
-    if a.f32_rounded:
-        dev.set_f32_arithmetic(False)
+    dev.set_f32_arithmetic(bool(a.f32_arith))
     n_local = dev.n
     offsets = (synth.START_JD - dev.epochs) * 1440.0
     layout = _native.TIME_MAJOR if a.layout == "time" else _native.SAT_MAJOR
@@ -374,6 +535,38 @@ def main():
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
         kernel_only_ms = float(kt[0])
 
+    # config 4, the alternative DESIGN.md 6 recommends to consumers that need everything everywhere: every GPU propagates
+    # the FULL catalog itself ("replicate": zero bytes moved), timed the same way (barrier, events, max over ranks)
+    replicate_ms = None
+    if sharded:
+        dev_full = _native.DeviceConstellation.from_tle_lines(allp, _native.WGS72, local_rank)
+        dev_full.set_timing(False)
+        offs_full = (synth.START_JD - dev_full.epochs) * 1440.0
+        fp, fv = sp.full[0].data_ptr(), (sp.full[1].data_ptr() if vel_on else None)   # (padded >= n_total) x n_times x 3
+        dev_full.propagate_device(times, offs_full, fp, fv, layout=_native.SAT_MAJOR, stream=sptr)
+        for _ in range(max(5, a.warmup // 4)):
+            dev_full.propagate_device_cached(fp, fv, layout=_native.SAT_MAJOR, stream=sptr)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        r0 = torch.cuda.Event(enable_timing=True)
+        r1 = torch.cuda.Event(enable_timing=True)
+        r0.record(stream)
+        for _ in range(a.steps):
+            dev_full.propagate_device_cached(fp, fv, layout=_native.SAT_MAJOR, stream=sptr)
+        r1.record(stream)
+        torch.cuda.synchronize()
+        rt = torch.tensor([r0.elapsed_time(r1) / a.steps], dtype=torch.float64, device=cuda)
+        dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+        replicate_ms = float(rt[0])
+        if gather:
+            # leave the gathered result of the sharded pipeline in sp.full for the parity check below
+            sp.compute.wait_stream(stream)
+            step()
+            drain()
+            torch.cuda.synchronize()
+            dist.barrier()
+
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -393,11 +586,21 @@ def main():
     # (separate --pmc passes, tools/profile.sh) and committed under profiles/ together with a fingerprint of
     # the kernel sources it was measured on; a stale measurement is not reported
     traffic = None
+    valu_issue = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
         if (pm.get("csrc_sha16") == csrc_fingerprint() and world == 1 and layout == _native.SAT_MAJOR and vel_on and
                 a.sats == 13478 and n_times == 1440 and not a.deep and not a.f32_out and not a.no_fast_path):
             traffic = pm["hbm_bytes_per_launch"]
+            if pm.get("valu_wave_insts_per_launch"):
+                # VALU issue-slot utilisation of the step: one wave instruction occupies its SIMD's issue port for 4 cycles
+                # (16 lanes/cycle); 1,024 SIMDs; shader clock = the median sampled right before the timed steps
+                wi = float(pm["valu_wave_insts_per_launch"])
+                sclk = (power or {}).get("sclk_mhz_median") or 2400.0
+                valu_issue = {"valu_wave_insts_per_launch": wi, "valu_insts_per_propagation": wi * 64.0 / local_props,
+                              "sclk_mhz": sclk, "issue_slot_frac": wi * 4.0 / (1024.0 * launch_s * sclk * 1e6),
+                              "source": "SQ_INSTS_VALU summed over the step's kernels (rocprofv3 --pmc pass stamped in "
+                                        "profiles/latest_pmc.json) x 4 clk / (1,024 SIMDs x avg_launch x shader clock)"}
     except (OSError, ValueError, KeyError):
         pass
 
@@ -405,8 +608,9 @@ def main():
         wl = "config 5, ONE GPU's share of 8: %d synthetic satellites (seed 20260927) x %d one-minute steps" % (a.sats, n_times)
         par = "single GPU (1/8 of the 1M-satellite job; shards are independent, no gather)"
     elif world == 1:
-        wl = "config 2: %d-sat synthetic active catalog (SGP4 near-earth%s) x %d one-minute steps" % (
-            a.sats, " + %d deep-space SDP4" % a.deep if a.deep else "", n_times)
+        wl = ("config 3: %d-sat synthetic catalog (%d SGP4 near-earth + %d deep-space SDP4) x %d one-minute steps" % (
+            a.sats + a.deep, a.sats, a.deep, n_times)) if a.deep else (
+            "config 2: %d-sat synthetic active catalog (SGP4 near-earth) x %d one-minute steps" % (a.sats, n_times))
         par = "single GPU"
     elif sharded:
         wl = "config 4: the %d-sat synthetic catalog%s x %d one-minute steps, block-cyclic satellite shards over %d GPUs%s" % (
@@ -418,14 +622,14 @@ def main():
         wl = "WEAK scaling (--scaling weak): %d GPUs x an own %d-sat synthetic catalog x %d one-minute steps, no gather" % (
             world, a.sats + a.deep, n_times)
         par = "independent catalogs x%d, no data-path collective" % world
-    arith = "fp64 arithmetic" if not a.f32_out or a.f32_rounded or a.no_fast_path or layout != _native.SAT_MAJOR else \
+    arith = "fp64 arithmetic" if not a.f32_out or not a.f32_arith or a.no_fast_path or layout != _native.SAT_MAJOR else \
         "fp32 arithmetic with fp64 phase and radius chains (near-circular members; fp64 for the rest)"
     wl += ", %s, %s TEME %s, %s-major device-resident output" % (
         arith, "fp32-stored" if a.f32_out else "fp64", "pos+vel" if vel_on else "pos only", a.layout)
     if layout == _native.SAT_MAJOR:
         kname = ("k_rows_fast<%s> (branch-free uniform-grid step, one wave per satellite row, lane = time) + k_rows redo pass"
                  if not a.no_fast_path else "k_rows<%s> (one wave per satellite row, lane = time)") % ("pos+vel" if vel_on else "pos")
-        if a.f32_out and not a.f32_rounded and not a.no_fast_path:
+        if a.f32_out and a.f32_arith and not a.no_fast_path:
             kname = kname.replace("k_rows_fast<", "k_rows_fast32<")
     else:
         kname = ("k_tiles_fast<%s> (16-satellite tiles of lane = time waves, LDS transpose) + k_rows redo pass"
@@ -444,6 +648,9 @@ def main():
             **({"t_kernel_ms": kernel_only_ms, "t_allgather_ms": max(elapsed / a.steps * 1e3 - kernel_only_ms, 0.0),
                 "t_total_ms": elapsed / a.steps * 1e3, "rccl_ranks": world, "chunks": plan.n_chunks,
                 "kernel_only_value": props_per_step / (kernel_only_ms / 1e3),
+                "t_replicate_ms": replicate_ms, "replicate_value": props_per_step / (replicate_ms / 1e3),
+                "replicate_note": "every GPU propagates the FULL catalog itself (no shards, zero bytes moved): the same "
+                                  "deliverable as the gathered run -- the full arrays on every GPU",
                 "gather_bytes_per_gpu": (plan.padded - plan.local_capacity()) * n_times * 3 * 8 * (2 if vel_on else 1)}
                if kernel_only_ms is not None else {}),
             "parallelism": par,
@@ -455,10 +662,12 @@ def main():
             "algorithmic_bytes_per_launch": bytes_per_launch,
         },
         "power": power,
+        "valu_issue": valu_issue,
         "fp64_valu": {
-            "achieved": tflops, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TF,
+            "achieved": tflops, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
             "flops_per_propagation": FLOPS_PER_PROP,
-            "note": "algorithmic flops of the reference formulation (405+44K, K=4); this kernel executes fewer",
+            "note": "rate x the algorithmic flops of the REFERENCE formulation (405+44K, K=4) -- informational; this kernel "
+                    "executes far fewer instructions, see valu_issue for the issue-slot utilisation it actually reaches",
         },
     }
 
@@ -506,6 +715,14 @@ def main():
         except Exception as exc:  # the baseline must never take the bench line down
             out["cpu_baseline"] = {"value": None, "unit": "propagations/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (exc,)}
+    default_workload = (world == 1 and not sharded and not a.config5_share and a.sats == 13478 and n_times == 1440 and not a.deep and
+                        vel_on and not a.f32_out and a.layout == "sat" and not a.no_fast_path and not a.tile)
+    if default_workload and not a.no_secondary:
+        try:
+            out["secondary"] = run_secondary(torch, _native, synth, cuda, stream, dev, pairs,
+                                             skip=tuple(k for k in a.secondary_skip.split(",") if k))
+        except Exception as exc:   # never takes the headline down
+            out["secondary"] = [{"failed": repr(exc)}]
     print(json.dumps(out))
     if world > 1 or a.force_sharded:
         dist.destroy_process_group()

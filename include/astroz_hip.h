@@ -194,10 +194,14 @@ int32_t azh_propagate_device_window(azh_constellation *c, size_t row_lo, size_t 
                                     int32_t layout, size_t out_stride_sats, uint8_t *d_err, void *stream);
 /* fp32 OUTPUT variants (BASELINE config 5: 1M satellites x 10,000 steps would be 480 GB in fp64); d_pos/d_vel
  * are float arrays of the same shapes.  No reference counterpart (astroz is fp64 only).  Arithmetic:
- *   default                      fp32 arithmetic with fp64 phase and radius chains (astroz_amd/csrc/fast_step_f32.h)
- *                                for near-circular members on uniform grids, satellite-major TEME: positions within
- *                                metres and velocities within mm/s of the fp64 result; everything else as below;
- *   azh_set_f32_arithmetic(c,0)  fp64 arithmetic throughout, every component rounded once when it is stored. */
+ *   default                      fp64 arithmetic throughout, every component rounded ONCE when it is stored: the result is
+ *                                float32(fp64 result), half an fp32 ulp from the fp64 path (0.25 m, 0.24 mm/s in LEO);
+ *   azh_set_f32_arithmetic(c,1)  opt-in: packed fp32 arithmetic with fp64 phase and radius chains
+ *                                (astroz_amd/csrc/fast_step_f32.h) for near-circular members on uniform grids,
+ *                                satellite-major TEME -- 1.6x the rate of the default, positions within 4 m and velocities
+ *                                within 6 mm/s of the fp64 result (measured 2.4 m / 4.0 mm/s over 10,000-minute spans; the
+ *                                reference's own SIMD-vs-scalar bar is 1 mm/s, which fp32 ARITHMETIC cannot meet: one fp32
+ *                                rounding of a 7.5 km/s component is already 0.24 mm/s).  Everything else as the default. */
 int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t enabled);
 int32_t azh_propagate_device_f32(azh_constellation *c, const double *times_min, size_t n_times,
                                  const double *epoch_offsets_min, float *d_pos, float *d_vel, int32_t output_mode,
@@ -251,8 +255,11 @@ int32_t azh_screen_all_host(azh_constellation *c, const double *times_min, size_
  *                                  (n_sats, n_times, 3) host arrays over its own PCIe link: no collective;
  *   azh_group_propagate_allgather  the full TEME arrays resident on EVERY device: d_pos[i] / d_vel[i] are device
  *                                  buffers on devices[i] of azh_group_padded_rows() x n_times x 3 doubles (rows beyond
- *                                  n_sats are padding); RCCL all-gathers over xGMI (librccl is loaded on first use),
- *                                  chunk k in flight while chunk k+1 is propagated.  Synchronous. */
+ *                                  n_sats are padding and arrive as zeros); RCCL all-gathers over xGMI (librccl is
+ *                                  loaded on first use), chunk k in flight while chunk k+1 is propagated.  Synchronous.
+ * epoch_offsets_min (both calls): NULL, or azh_group_num_satellites() doubles indexed by catalog row -- like the reference's
+ * epochOffsets slice (src/Constellation.zig L541-552) it carries no length of its own here: a shorter array is read out of
+ * bounds (the Python wrapper checks the length before the call). */
 typedef struct azh_group azh_group;
 int32_t azh_group_create_from_tle_text(const char *text, size_t len, int32_t grav, const int32_t *devices,
                                        int32_t n_devices, int32_t n_chunks, azh_group **out);

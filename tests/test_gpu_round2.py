@@ -109,6 +109,7 @@ def test_fp32_arithmetic_vs_oracle(native, orc, synth):
     p32 = torch.full((dev.n, len(times), 3), float("nan"), dtype=torch.float32, device="cuda")
     v32 = torch.full_like(p32, float("nan"))
     torch.cuda.synchronize()
+    dev.set_f32_arithmetic(True)    # opt-in: the default for fp32 outputs is fp64 arithmetic rounded at the store
     dev.propagate_device(times, off, p32.data_ptr(), v32.data_ptr(), layout=native.SAT_MAJOR, f32=True)
     dev.synchronize()
     p, v = p32.cpu().numpy().astype(np.float64), v32.cpu().numpy().astype(np.float64)
@@ -144,6 +145,7 @@ def test_fp32_arithmetic_ragged_sizes(native, orc, synth, n_times, vel):
     p32 = torch.full((dev.n, n_times, 3), float("nan"), dtype=torch.float32, device="cuda")
     v32 = torch.full_like(p32, float("nan")) if vel else None
     torch.cuda.synchronize()
+    dev.set_f32_arithmetic(True)
     dev.propagate_device(times, off, p32.data_ptr(), v32.data_ptr() if vel else None, layout=native.SAT_MAJOR, f32=True)
     dev.synchronize()
     p = p32.cpu().numpy().astype(np.float64)
@@ -165,6 +167,7 @@ def test_fp32_arithmetic_config5_geometry(native, orc, synth):
     p32 = torch.empty((n, len(times), 3), dtype=torch.float32, device="cuda")
     v32 = torch.empty_like(p32)
     torch.cuda.synchronize()
+    dev.set_f32_arithmetic(True)
     dev.propagate_device(times, off, p32.data_ptr(), v32.data_ptr(), layout=native.SAT_MAJOR, f32=True)
     dev.synchronize()
     chk1 = (p32.double().sum().item(), v32.double().sum().item())

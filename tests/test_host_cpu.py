@@ -40,6 +40,38 @@ def test_header_symbols_exported(native):
     assert L.astroz_version() == 0x000300
 
 
+def _c_prototypes(hdr):
+    """{name: parameter count} of the function declarations of a C header (comments stripped)."""
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b((?:azh|coords)_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_zig_shim_matches_header():
+    """bindings/zig/astroz_hip.zig (the FFI shim of INTEGRATION.md 1; Zig is not installed here, so it cannot be
+    compiled) declares exactly the azh_* / coords_* entry points of include/astroz_hip.h, each with the header's
+    parameter count, and maps every AZ_ERR_* code."""
+    hdr = open(os.path.join(ROOT, "include", "astroz_hip.h")).read()
+    zig = open(os.path.join(ROOT, "bindings", "zig", "astroz_hip.zig")).read()
+    want = _c_prototypes(hdr)
+    assert len(want) >= 45
+    got = {}
+    for m in re.finditer(r'pub extern "c" fn ([a-z0-9_]+)\((.*?)\)\s*[^;]*;', zig, flags=re.S):
+        args = m.group(2).strip()
+        got[m.group(1)] = 0 if not args else len(re.findall(r"\b[a-z_0-9]+\s*:", args))
+    assert set(got) == set(want), (sorted(set(want) - set(got)), sorted(set(got) - set(want)))
+    bad = {k: (want[k], got[k]) for k in want if want[k] != got[k]}
+    assert not bad, bad
+    for code in re.findall(r"AZ_ERR_[A-Z_]+\s*=\s*(-\d+)", hdr):
+        assert re.search(r"%s\s*=>" % re.escape(code), zig) or code == "-999", code
+    # the INTEGRATION.md example maps errors through the shim's check(), not to one catch-all
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "hip.check(" in integ and "return Error.OutOfMemory; // AZ_ERR_*" not in integ
+
+
 def test_tle_ingest_matches_oracle(native, orc, golden):
     L = native.lib()
     for l1, l2 in golden["G9_structural"]["tles"]:
@@ -144,8 +176,29 @@ def test_text_front_ends(native, golden):
             native.parse_element_text(bad)
     from datetime import datetime, timezone
     assert az._jd_of(datetime(2000, 1, 1, 12, tzinfo=timezone.utc)) == 2451545.0
+    # Space-Track style OMM: numeric fields as JSON strings parse like bare numbers
+    import json as _json
+    rec = _json.loads(golden["G8b_omm"]["cases"][0]["json"])
+    rec0 = rec[0] if isinstance(rec, list) else rec
+    as_str = {k: (str(v) if isinstance(v, (int, float)) and not isinstance(v, bool) else v) for k, v in rec0.items()}
+    assert np.array_equal(native.parse_element_text(_json.dumps(as_str)), native.parse_element_text(_json.dumps(rec0)))
     with pytest.raises(ValueError):
-        az._as_text("starlink")        # no CelesTrak group lookups: this package never fetches
+        native.parse_element_text(_json.dumps(dict(rec0, MEAN_MOTION="fifteen")))
+    # network sources are opt-in (module docstring): without a fetcher they raise, naming the URL; with one the text
+    # it returns is what the native readers get
+    with pytest.raises(ValueError, match="GROUP=starlink"):
+        az._as_text("starlink")
+    with pytest.raises(ValueError, match="CATNR=25544"):
+        az._as_text(None, norad_id=25544)
+    seen = []
+    got = az._as_text("https://example.invalid/x.tle", fetch=lambda url: seen.append(url) or text)
+    assert got == text and seen == ["https://example.invalid/x.tle"]
+    prev = az.set_fetcher(lambda url: text)
+    try:
+        assert az._as_text("active") == text and az._as_text(None, norad_id=[25544, 48274]) == text
+    finally:
+        az.set_fetcher(prev)
+    assert az.celestrak_url(norad_id=[25544, 48274]).endswith("CATNR=25544,48274&FORMAT=tle")
 
 
 def test_synthetic_catalog_is_valid(orc):
