@@ -102,8 +102,17 @@ struct azh_constellation {
     unsigned n_sgp4 = 0, n_sdp4 = 0, n_bad = 0;
     // per-call scratch
     DevBuf<double> d_times, d_offsets, d_sin, d_cos, d_seeds;
-    DevBuf<unsigned> d_redo;    // k_rows_fast -> k_rows redo list: [0],[1] item counters (alternating launches), [4..] (slot, first, end) triples
-    unsigned redo_parity = 0;
+    // window plans of the staged uniform grid (k_plan_windows), one per launch shape: [0] row kernels (64 grid points per
+    // lane step), [1] the packed fp32 row kernel (128), [2] the time-major tile kernel.  redo: [0],[1] item counters
+    // (alternating launches, re-armed to the number of static items), [2] number of static items (windows the validation
+    // bounds reject), [4..] (list slot, first grid point, end) triples -- static items first, dynamic ones behind
+    struct FastPlan {
+        bool valid = false;
+        unsigned tile_c = 0, tile_e = 0, n_list = 0, n_seg = 0, parity = 0;
+        DevBuf<double> win;
+        DevBuf<unsigned char> flag;
+        DevBuf<unsigned> redo;
+    } plan[3];
     DevBuf<double> d_inc;       // uniform grids: per-satellite rotation increments (k_prep_inc), [2 * AZ_INC_NUM][n_pad]
     double uniform_step = 0.0;  // step of the staged grid if it is uniform, else 0
     DevBuf<double> d_tgt, d_part_d2, d_out_d; // fused screen: target track, partial minima, results
@@ -152,7 +161,7 @@ void destroy(azh_constellation *c)
     c->d_cos.release();
     c->d_seeds.release();
     c->d_inc.release();
-    c->d_redo.release();
+    for (auto &pl : c->plan) { pl.win.release(); pl.flag.release(); pl.redo.release(); }
     c->d_tgt.release();
     c->d_part_d2.release();
     c->d_out_d.release();
@@ -392,59 +401,90 @@ struct EccSide {
     hipEvent_t fork = nullptr, join = nullptr;
 };
 
+// launch shape of the fast kernels on a uniform grid: time-segment lengths of the near-circular and the eccentric launch,
+// which kernel family (= which window plan: 0 rows, 1 packed fp32 rows, 2 time-major tiles)
+struct FastShape {
+    unsigned tile_c = 0, tile_e = 0;
+    bool packed32 = false;
+    int kind = 0;
+};
+// a wave's time window must stay short enough for the window-centred constants of the fast step (the node moves
+// ~6e-5 rad/min: +-1,500 minutes keep it inside the 1/8-rad rotation tier)
+unsigned fast_window_cap(double step)
+{
+    const double span = 3000.0 / std::max(std::fabs(step), 1e-9);
+    return span >= 4.0e9 ? 0xffffffc0u : std::max(64u, (unsigned)span / 64u * 64u);
+}
+FastShape fast_shape_rows(const PropArgs &a, unsigned n_sgp4, unsigned n_circ)
+{
+    FastShape f;
+    const unsigned cap = fast_window_cap(a.uniform_step);
+    const unsigned n_ecc = n_sgp4 - n_circ;
+    // eccentric members: few rows, finer time segments so that they still fill the chip when they run alone
+    f.tile_e = std::min(rows_tile(std::max(n_ecc, 1u), a.n_times, 256), cap);
+    f.tile_c = std::min(rows_tile(n_sgp4, a.n_times, a.tile_forced), cap);
+    // packed fp32 kernel: a lane carries two grid points, a wave iteration 128 (windows shorter than that -- grid
+    // steps beyond ~23 minutes -- keep the fp64 kernel with rounded stores)
+    f.packed32 = a.f32 && a.mode == AZ_OUT_TEME && a.arith32 && cap >= 128u;
+    if (f.packed32) f.tile_c = std::max(128u, f.tile_c / 128u * 128u);
+    f.kind = f.packed32 ? 1 : 0;
+    return f;
+}
+FastShape fast_shape_tiles(const PropArgs &a, unsigned n_sgp4)
+{
+    FastShape f;
+    unsigned tile = std::min(rows_tile(std::max((n_sgp4 + 15u) / 16u, 1u) * 16u, a.n_times, a.tile_forced), fast_window_cap(a.uniform_step));
+    if (a.mode == AZ_OUT_ECEF) tile = std::min(tile, (unsigned)AZ_TILE_SEG_MAX); // the Greenwich-angle table of a time segment is staged in LDS
+    f.tile_c = f.tile_e = tile;
+    f.kind = 2;
+    return f;
+}
+
 template <bool VEL, bool FRAME>
-void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const EccSide &side = EccSide())
+void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const EccSide &side = EccSide(), const FastShape *shape = nullptr)
 {
     if (deep) {
         if (a.f32) hipLaunchKernelGGL((k_rows_deep<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_rows_deep<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
-    } else if (a.redo_items != nullptr) {
-        // uniform grid: the branch-free kernels -- eccentric members first (few rows, finer time segments so that
-        // they still fill the chip), then the near-circular bulk; what their validation rejects (an angle outside
-        // its tier: well under one per cent of the segments) is listed and handed to the generic kernel
+    } else if (a.redo_items != nullptr && shape != nullptr) {
+        // uniform grid: the branch-free kernels.  The near-circular bulk runs alone on the launch stream; beside it, on the
+        // side stream, the eccentric members (few rows) and then the generic kernel over the redo list -- the windows the
+        // plan's validation bounds rejected (static, known before any kernel runs: well under one per cent of the segments)
+        // plus whatever the eccentric form's Newton validation handed over.  Nothing follows the bulk launch on its stream:
+        // round 2's redo pass (12 us + two launch gaps per step) waited for it.
         PropArgs e = a, c = a;
         e.list = a.list + a.n_circ;
         e.n_list = a.n_list - a.n_circ;
         c.n_list = a.n_circ;
-        // a wave's time window must stay short enough for the window-centred constants of the fast step (the node
-        // moves ~6e-5 rad/min: +-1,500 minutes keep it inside the 1/8-rad rotation tier)
-        const double span = 3000.0 / std::max(std::fabs(a.uniform_step), 1e-9);
-        const unsigned cap = span >= 4.0e9 ? 0xffffffc0u : std::max(64u, (unsigned)span / 64u * 64u);
-        e.tile = std::min(rows_tile(std::max(e.n_list, 1u), a.n_times, 256), cap);
-        c.tile = std::min(a.tile, cap);
-        // packed fp32 kernel: a lane carries two grid points, a wave iteration 128 (windows shorter than that -- grid
-        // steps beyond ~23 minutes -- keep the fp64 kernel with rounded stores)
-        const bool packed32 = a.f32 && !FRAME && a.arith32 && cap >= 128u;
-        if (packed32) c.tile = std::max(128u, c.tile / 128u * 128u);
+        e.tile = shape->tile_e;
+        c.tile = shape->tile_c;
+        const bool packed32 = shape->packed32 && !FRAME;
         dim3 egrid((e.n_list + 7) / 8 * 8, (a.n_times + e.tile - 1) / e.tile);
         dim3 cgrid((c.n_list + 7) / 8 * 8, (a.n_times + c.tile - 1) / c.tile);
         dim3 rgrid(256, 4);
         // redo items carry (list slot, first, end): slots of the eccentric launch are offset into the common list
         e.redo_slot0 = a.n_circ;
-        // the eccentric launch is a single short generation of waves: on the same stream it would cost its whole
-        // latency (30 us); on the side stream it runs underneath the bulk launch
-        const bool beside = side.stream != nullptr && e.n_list && c.n_list;
+        const bool beside = side.stream != nullptr && c.n_list;
         hipStream_t se = beside ? side.stream : st;
         if (beside) {
             (void)hipEventRecord(side.fork, st);
             (void)hipStreamWaitEvent(se, side.fork, 0);
         }
-        if (a.f32) {
-            if (e.n_list) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32, true>), egrid, dim3(64), 0, se, e);
-            if (c.n_list) {
-                if (packed32) hipLaunchKernelGGL((k_rows_fast32<VEL>), cgrid, dim3(64), 0, st, c);
-                else hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32, false>), cgrid, dim3(64), 0, st, c);
-            }
-        } else {
-            if (e.n_list) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F64, true>), egrid, dim3(64), 0, se, e);
-            if (c.n_list) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F64, false>), cgrid, dim3(64), 0, st, c);
+        if (e.n_list) {
+            if (a.f32) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32, true>), egrid, dim3(64), 0, se, e);
+            else hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F64, true>), egrid, dim3(64), 0, se, e);
+        }
+        if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32, true>), rgrid, dim3(64), 0, se, a);
+        else hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64, true>), rgrid, dim3(64), 0, se, a);
+        if (c.n_list) {
+            if (packed32) hipLaunchKernelGGL((k_rows_fast32<VEL>), cgrid, dim3(64), 0, st, c);
+            else if (a.f32) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32, false>), cgrid, dim3(64), 0, st, c);
+            else hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F64, false>), cgrid, dim3(64), 0, st, c);
         }
         if (beside) {
             (void)hipEventRecord(side.join, se);
             (void)hipStreamWaitEvent(st, side.join, 0);
         }
-        if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32, true>), rgrid, dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
     } else {
         if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
@@ -453,14 +493,11 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const
 
 // time-major output of the near-earth members on a uniform grid: 16-satellite tiles of lane = time waves (k_tiles_fast),
 // then the generic kernel on whatever their validation rejected (24-byte pieces, row by row)
-void launch_tiles(const PropArgs &a0, bool vel, hipStream_t st)
+void launch_tiles(const PropArgs &a0, bool vel, hipStream_t st, const FastShape &shape)
 {
     PropArgs a = a0;
-    const double span = 3000.0 / std::max(std::fabs(a.uniform_step), 1e-9); // window of the fast step, see launch_rows2
-    const unsigned cap = span >= 4.0e9 ? 0xffffffc0u : std::max(64u, (unsigned)span / 64u * 64u);
-    a.tile = std::min(rows_tile(std::max((a.n_list + 15u) / 16u, 1u) * 16u, a.n_times, a.tile_forced), cap);
-    const bool ecef = a.mode == AZ_OUT_ECEF; // the Greenwich-angle table of a time segment is staged in LDS
-    if (ecef) a.tile = std::min(a.tile, (unsigned)AZ_TILE_SEG_MAX);
+    a.tile = shape.tile_c;
+    const bool ecef = a.mode == AZ_OUT_ECEF;
     dim3 grid(((a.n_list + 15u) / 16u + 7u) / 8u * 8u, (a.n_times + a.tile - 1) / a.tile);
     if (ecef) {
         if (vel) hipLaunchKernelGGL((k_tiles_fast<true, true>), grid, dim3(1024), 0, st, a);
@@ -480,7 +517,8 @@ void launch_tiles(const PropArgs &a0, bool vel, hipStream_t st)
     }
 }
 
-void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStream_t st, const EccSide &side = EccSide())
+void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStream_t st, const EccSide &side = EccSide(),
+                      const FastShape *shape = nullptr)
 {
     const bool frame = a.mode != AZ_OUT_TEME;
     if (use_rows(a, layout, deep)) {
@@ -493,11 +531,11 @@ void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStr
             if (deep) hipLaunchKernelGGL((k_rows_deep<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);
             else hipLaunchKernelGGL((k_rows<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);
         } else if (frame) {
-            if (vel) launch_rows2<true, true>(b, grid, deep, st, side);
-            else launch_rows2<false, true>(b, grid, deep, st, side);
+            if (vel) launch_rows2<true, true>(b, grid, deep, st, side, shape);
+            else launch_rows2<false, true>(b, grid, deep, st, side, shape);
         } else {
-            if (vel) launch_rows2<true, false>(b, grid, deep, st, side);
-            else launch_rows2<false, false>(b, grid, deep, st, side);
+            if (vel) launch_rows2<true, false>(b, grid, deep, st, side, shape);
+            else launch_rows2<false, false>(b, grid, deep, st, side, shape);
         }
         return;
     }
@@ -543,6 +581,7 @@ int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, 
     c->cached_n_times = (unsigned)n_times;
     c->cached_mode = mode;
     c->seeds_valid = false; // new time grid / offsets
+    for (auto &pl : c->plan) pl.valid = false;
     // uniform grid?  times[i] == times[0] + i*step up to the rounding of the grid itself: the fast step
     // (fast_step.h) then advances its carried angles by per-satellite constant rotations
     c->uniform_step = 0.0;
@@ -586,6 +625,44 @@ int32_t prepare_deep(azh_constellation *c, PropArgs &d, hipStream_t st, bool row
         c->seeds_rows = rows;
     }
     d.seeds = c->d_seeds.p;
+    return AZ_OK;
+}
+
+// the window plan of the staged grid for one launch shape (k_plan_windows): built on first use, kept until the next staging
+int32_t ensure_plan(azh_constellation *c, PropArgs &a, const FastShape &shape, hipStream_t st)
+{
+    azh_constellation::FastPlan &pl = c->plan[shape.kind];
+    const unsigned n_list = a.n_list;
+    const unsigned n_seg = (a.n_times + std::min(shape.tile_c, shape.tile_e) - 1) / std::min(shape.tile_c, shape.tile_e);
+    if (!pl.valid || pl.tile_c != shape.tile_c || pl.tile_e != shape.tile_e || pl.n_list != n_list) {
+        // every wave of the eccentric launch may file one dynamic item; static items: at most one per (slot, segment)
+        const size_t items = (size_t)n_list * n_seg + ((size_t)a.n_times + 63) / 64 * n_list;
+        if (pl.redo.cap < 4 + 3 * items || pl.win.cap < (size_t)n_list * n_seg * AZ_PLAN_NUM) HIP_TRY(hipStreamSynchronize(st)); // (launches in flight use the old buffers)
+        if (pl.redo.ensure(4 + 3 * items) != AZ_OK || pl.win.ensure((size_t)n_list * n_seg * AZ_PLAN_NUM) != AZ_OK ||
+            pl.flag.ensure((size_t)n_list * n_seg) != AZ_OK)
+            return AZ_ERR_HIP;
+        HIP_TRY(hipMemsetAsync(pl.redo.p, 0, 4 * sizeof(unsigned), st));
+        PlanArgs q{};
+        q.el = a.el; q.flags = a.flags; q.n_pad = a.n_pad; q.list = a.list; q.n_list = n_list; q.n_circ = a.n_circ;
+        q.n_times = a.n_times; q.tile_c = shape.tile_c; q.tile_e = shape.tile_e; q.by_flags = shape.kind == 2 ? 1u : 0u;
+        q.times = a.times; q.offsets = a.offsets; q.inc = a.inc; q.step = a.uniform_step; q.dt_mult = shape.kind == 1 ? 128.0 : 64.0;
+        q.win = pl.win.p; q.flag = pl.flag.p;
+        q.redo_static = pl.redo.p + 2; q.redo_c0 = pl.redo.p; q.redo_c1 = pl.redo.p + 1; q.redo_items = pl.redo.p + 4;
+        q.g = a.g;
+        hipLaunchKernelGGL(k_plan_windows, dim3((n_list + 255) / 256, n_seg), dim3(256), 0, st, q);
+        hipLaunchKernelGGL(k_plan_arm, dim3(1), dim3(64), 0, st, q.redo_static, q.redo_c0, q.redo_c1);
+        HIP_TRY(hipGetLastError());
+        pl.valid = true;
+        pl.tile_c = shape.tile_c; pl.tile_e = shape.tile_e; pl.n_list = n_list; pl.n_seg = n_seg; pl.parity = 0;
+    }
+    a.plan_win = pl.win.p;
+    a.plan_flag = pl.flag.p;
+    a.plan_stride = n_list;
+    a.redo_static = pl.redo.p + 2;
+    a.redo_count = pl.redo.p + pl.parity;
+    a.redo_next = pl.redo.p + (pl.parity ^ 1u);
+    a.redo_items = pl.redo.p + 4;
+    pl.parity ^= 1u;
     return AZ_OK;
 }
 
@@ -645,31 +722,20 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
                            a.mask == nullptr && a.screen_target == nullptr && n_times >= 64 &&
                            c->n < 5000000u; // (k_tiles_fast packs an output column, 3 n, into 24 bits)
         if (tiles) a.list = c->d_list.p + c->off_cat; // plain catalog order; the redo items index this list
-        if (a.inc != nullptr && (tiles || use_rows(a, layout, false))) {
-            // uniform grid, satellite-major rows: every near-earth member -> k_rows_fast (near-circular or
-            // eccentric Kepler form by class); what its validation rejects comes back through the redo list
+        FastShape shape;
+        const bool fast = a.inc != nullptr && (tiles || use_rows(a, layout, false));
+        if (fast) {
+            // uniform grid: every near-earth member -> the branch-free kernels (near-circular or eccentric Kepler form by
+            // class), windows prepared and validated once per staged grid by the plan; what the plan rejects and what the
+            // eccentric form's Newton validation hands over comes back through the redo list
             if (!tiles) a.list = c->d_list.p + c->off_circ; // [class 0 | other classes], catalog order inside each
             a.n_list = c->n_sgp4;
             a.n_circ = c->n_circ;
-            if (c->n_sgp4 > 0) {
-                // every wave of the fast launches may file one item; their segments are never shorter than 64 points
-                const size_t segs = ((size_t)n_times + 63) / 64;
-                if (!c->d_redo.p) {
-                    if (c->d_redo.ensure(4 + 3 * segs * c->n_sgp4) != AZ_OK) return AZ_ERR_HIP;
-                    HIP_TRY(hipMemsetAsync(c->d_redo.p, 0, 4 * sizeof(unsigned), st)); // the redo kernel re-arms it
-                } else if (c->d_redo.cap < 4 + 3 * segs * c->n_sgp4) {
-                    HIP_TRY(hipStreamSynchronize(st));
-                    if (c->d_redo.ensure(4 + 3 * segs * c->n_sgp4) != AZ_OK) return AZ_ERR_HIP;
-                    HIP_TRY(hipMemsetAsync(c->d_redo.p, 0, 4 * sizeof(unsigned), st));
-                }
-                a.redo_count = c->d_redo.p + c->redo_parity;
-                a.redo_next = c->d_redo.p + (c->redo_parity ^ 1u);
-                a.redo_items = c->d_redo.p + 4;
-                c->redo_parity ^= 1u;
-            }
+            shape = tiles ? fast_shape_tiles(a, c->n_sgp4) : fast_shape_rows(a, c->n_sgp4, c->n_circ);
+            if (int32_t rc = ensure_plan(c, a, shape, st); rc != AZ_OK) return rc;
         }
-        if (a.n_list > 0 && tiles) launch_tiles(a, d_vel != nullptr, st);
-        else if (a.n_list > 0) launch_propagate(a, layout, d_vel != nullptr, false, st, EccSide{c->s_ecc, c->ev_fork2, c->ev_join2});
+        if (a.n_list > 0 && tiles) launch_tiles(a, d_vel != nullptr, st, shape);
+        else if (a.n_list > 0) launch_propagate(a, layout, d_vel != nullptr, false, st, EccSide{c->s_ecc, c->ev_fork2, c->ev_join2}, fast ? &shape : nullptr);
         HIP_TRY(hipGetLastError());
     }
     if (c->n_bad > 0) {

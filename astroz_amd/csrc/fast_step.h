@@ -33,6 +33,7 @@ enum FastCold {
 };
 // everything in registers (lane = satellite kernels, host emulation)
 struct FastK {
+    static constexpr bool SCALAR = false;
 #define X(n) double n##_;
     AZ_FASTK_COLD(X) AZ_FASTK_HOT(X)
 #undef X
@@ -44,6 +45,7 @@ struct FastK {
 // on the critical path stay in (scalar) registers, the 16 once-per-step ones are LDS words read by all
 // lanes at once (broadcast ds_read: no VALU slot, no register residency)
 struct FastKBcast {
+    static constexpr bool SCALAR = true; // the hot constants are wave-uniform (SGPR pairs)
     const double *cold;
 #define X(n) double n##_;
     AZ_FASTK_HOT(X)
@@ -60,6 +62,7 @@ struct FastKBcast {
 // (cold[k * AZ_COLD_STRIDE], conflict-free ds_read_b64) -- 32 VGPRs less, which is what keeps k_propagate's fast
 // loop free of scratch spills (a spilled register's reload waits on vmcnt, i.e. on the output stores in flight)
 struct FastKCol {
+    static constexpr bool SCALAR = false;
     const double *cold;
 #define X(n) double n##_;
     AZ_FASTK_HOT(X)
@@ -169,13 +172,13 @@ AZ_DEVICE void az_rot_apply2(double &s, double &c, double p, double q)
 // where it likes: lane = satellite kernels, host emulation) or LDS words read by all lanes at once.  v_fma_f64
 // takes no 64-bit literal and one scalar operand, so a Horner chain's constants otherwise end up parked in VGPRs
 // for the whole loop -- 8 coefficients = 16 VGPRs, a sixth wave per SIMD in k_rows_fast.
-enum RotCoef { RC_n6, RC_p24, RC_p120, RC_n720, RC_n5040, RC_p40320, RC_p362880, RC_n3628800, RC_NUM };
+enum RotCoef { RC_n6, RC_p24, RC_p120, RC_n720, RC_n5040, RC_p40320, RC_p362880, RC_n3628800, RC_p8, RC_NUM };
 struct RotCoefLit {
     AZ_MEMBER double operator()(int k) const
     {
         return k == RC_n6 ? -1.0 / 6.0 : k == RC_p24 ? 1.0 / 24.0 : k == RC_p120 ? 1.0 / 120.0 : k == RC_n720 ? -1.0 / 720.0
              : k == RC_n5040 ? -1.0 / 5040.0 : k == RC_p40320 ? 1.0 / 40320.0 : k == RC_p362880 ? 1.0 / 362880.0
-             : -1.0 / 3628800.0;
+             : k == RC_n3628800 ? -1.0 / 3628800.0 : 0.125;
     }
 };
 struct RotCoefLds {
@@ -235,28 +238,104 @@ AZ_DEVICE void az_pq_med(double d, const RC &k, double &p, double &q)
     p = d * fma(d2, p, 1.0);
 }
 
+
+// (s,c) <- (sin,cos)(angle + delta) for a carried pair and its constant increment (sd,cd) = (sin,cos)(delta).
+// SCALAR (one satellite per wave: sd, cd are SGPR pairs): written out as four in-place instructions.  Left to the
+// compiler the same four operations come out as v_fmac (VOP2: the addend is the destination), whose result lands in
+// the product's register, so that every loop-carried pair costs two v_mov_b64 per iteration to get back into place.
+template <bool SCALAR>
+AZ_DEVICE void az_pair_advance(double &s, double &c, double sd, double cd)
+{
+#ifndef AZ_HOST_EMUL
+    if (SCALAR) {
+        double m, m2;
+        asm("v_mul_f64 %2, %1, %4\n\t"
+            "v_mul_f64 %3, %0, %4\n\t"
+            "v_fma_f64 %0, %0, %5, %2\n\t"
+            "v_fma_f64 %1, %1, %5, -%3"
+            : "+v"(s), "+v"(c), "=&v"(m), "=&v"(m2)
+            : "s"(sd), "s"(cd));
+        return;
+    }
+#endif
+    const double ns = fma(s, cd, c * sd);
+    c = fma(c, cd, -(s * sd));
+    s = ns;
+}
+
+// (p,q) for |d| <= 1/16 where the rotated pair is only ever used scaled by the eccentricity (< 0.004 in the
+// near-circular form): sin to d^5, cos to d^4 -- truncation d^7/5040 < 7.4e-13 and d^6/720 < 8.3e-11, times 0.004
+template <class RC>
+AZ_DEVICE void az_pq_ecc_scaled(double d, const RC &k, double &p, double &q)
+{
+    const double d2 = d * d;
+    q = d2 * fma(d2, k(RC_p24), -0.5);
+    p = d * fma(d2, fma(d2, k(RC_p120), k(RC_n6)), 1.0);
+}
+// (p,q) for |d| <= 0.0041 (the first Kepler correction of a near-circular orbit, el/(1 - el)): sin to d^3, cos to d^4
+// (d^5/120 < 9.7e-15, d^6/720 < 6.6e-18)
+template <class RC>
+AZ_DEVICE void az_fpq_milli(double d, const RC &k, double &p, double &q)
+{
+    const double d2 = d * d;
+    q = d2 * fma(d2, k(RC_p24), -0.5);
+    p = fma(d2 * k(RC_n6), d, d);
+}
+
 // validation thresholds of the fast step
 #define AZ_FAST_EL2 1.6e-5
 #define AZ_FAST_TEMP2 6.0e-4
 
-// one near-earth propagation on a uniform grid; returns true when an assumption of the fast path does
-// not hold for this lane (the caller must then discard r/v and use az_sgp4_step)
+// Validation, once per time window instead of once per step.  The step below is straight-line code for the case
+// "every small angle sits inside its polynomial tier, the orbit is near-circular (ECC = false)".  Each of those
+// conditions is bounded here rigorously over the whole window [t_a, t_b] of tsince values from the satellite's
+// constants alone (triangle inequalities: |cos| <= 1, |t| <= T, monotone reciprocal bounds), so a window that passes
+// cannot violate any of them at any step, and the loop carries no compare, no vote and no branch for them (round 2
+// voted on six compares per step).  A window that fails goes to the generic kernel as a whole; the bounds are a few
+// per cent wider than the quantities themselves, which moves well under 1 % more segments there.
+// ECC = true additionally validates its Newton iteration per step (az_sgp4_fast_step's return value).
+template <bool ECC>
+AZ_DEVICE bool az_fast_window_ok(const FastK &k, const AzGrav &g, double t_a, double t_b)
+{
+    const double T = fmax(fabs(t_a), fabs(t_b));
+    const double ae = fabs(k.eta_);
+    // th = xmcof ((1 + eta cos M)^3 - (1 + eta cos mo)^3) + omgcof t
+    const double th = fma(fabs(k.xmcof_), ae * fma(2.0 * ae, ae, 6.0), fabs(k.omgcof_) * T);
+    // tempa = 1 - t (cc1 + t (d2 + t (d3 + t d4)))
+    const double da = T * fma(T, fma(T, fma(T, fabs(k.d4_), fabs(k.d3_)), fabs(k.d2_)), fabs(k.cc1_));
+    const double em = fabs(k.ecb_) + fma(fabs(k.bc4_), T, fabs(k.bc5_));
+    bool ok = (th <= AZ_ROT_16TH) & (da <= 0.25) & (em <= 0.9);
+    const double sam = k.sab_ * (1.0 - da);                  // sqrt(am) >= sam
+    const double inv_am = 1.0 / (sam * sam);                 // 1/am <= inv_am
+    const double temp = inv_am / fma(-em, em, 1.0);          // temp = 1/(am (1 - em^2))
+    const double el = fma(temp, fabs(k.aycof_), em);         // el <= em + temp |aycof|
+    const double el2 = el * el;
+    if (!ECC) ok &= el2 <= AZ_FAST_EL2;
+    ok &= el2 <= 0.81;
+    // eps = temp xlcof axnl + nl2 (t - tc)^2 + t^3 (nl3 + t (nl4 + t nl5))
+    const double dc = fmax(fabs(t_a - k.tc_), fabs(t_b - k.tc_));
+    const double eps = fma(temp * fabs(k.xlcof_), em, fma(fabs(k.nl2_) * dc, dc, T * T * T * fma(T, fma(T, fabs(k.nl5_), fabs(k.nl4_)), fabs(k.nl3_))));
+    ok &= eps <= AZ_ROT_MED;
+    const double inv_pl = inv_am / (1.0 - el2);
+    const double temp2 = g.half_j2 * inv_pl * inv_pl;
+    ok &= temp2 <= AZ_FAST_TEMP2;
+    // a_nd = k_node temp2 sin2u + nodedot (t - tmid) + xnodcf t^2
+    const double a_nd = fma(fabs(k.k_node_), temp2, fma(fabs(k.nodedot_), 0.5 * fabs(t_b - t_a), fabs(k.xnodcf_) * T * T));
+    ok &= a_nd <= AZ_ROT_MED;
+    return ok; // (every comparison is false for a NaN operand)
+}
+
+// one near-earth propagation on a uniform grid, inside a window az_fast_window_ok accepted.  Returns true when
+// the eccentric form's Newton iteration left its assumptions for this lane (ECC = true only; the caller must then
+// discard r/v and use az_sgp4_step); the near-circular form always returns false.
 template <bool VEL, bool ECC = false, class K = FastK, class RC = RotCoefLit>
 AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, double t, FastCarry &st, double r[3],
                                   double v[3])
 {
     // advance the carried pairs by their constant increments
-    {
-        const double nsA = fma(st.sA, k.cdA(), st.cA * k.sdA());
-        st.cA = fma(st.cA, k.cdA(), -(st.sA * k.sdA()));
-        st.sA = nsA;
-        const double nsW = fma(st.sW, k.cdW(), st.cW * k.sdW());
-        st.cW = fma(st.cW, k.cdW(), -(st.sW * k.sdW()));
-        st.sW = nsW;
-        const double nsU = fma(st.sU, k.cdU(), st.cU * k.sdU());
-        st.cU = fma(st.cU, k.cdU(), -(st.sU * k.sdU()));
-        st.sU = nsU;
-    }
+    az_pair_advance<K::SCALAR>(st.sA, st.cA, k.sdA(), k.cdA());
+    az_pair_advance<K::SCALAR>(st.sW, st.cW, k.sdW(), k.cdW());
+    az_pair_advance<K::SCALAR>(st.sU, st.cU, k.sdU(), k.cdU());
     const double sA = st.sA, cA = st.cA;
     const double t2 = t * t;
 
@@ -267,9 +346,10 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, doub
     // no_unkozai * templ without the part carried by U: kappa (t - tc)^2 + t^3 (nl3 + t (nl4 + t nl5))
     const double dtc = t - k.tc();
     const double nl = fma(k.nl2() * dtc, dtc, t2 * (t * fma(t, fma(t, k.nl5(), k.nl4()), k.nl3())));
-    bool bad = !(fabs(th) <= AZ_ROT_16TH);
+    bool bad = false;
     double p, q;
-    az_pq_16th(th, rk, p, q);
+    if (ECC) az_pq_16th(th, rk, p, q);
+    else az_pq_ecc_scaled(th, rk, p, q);                       // M + th and W - th only enter scaled by em < 0.004
     const double smm = fma(cA, p, fma(sA, q, sA));            // sin(M + th)
     const double sw = fma(-st.cW, p, fma(st.sW, q, st.sW));   // (sin,cos)(W - th)
     const double cw = fma(st.sW, p, fma(st.cW, q, st.cW));
@@ -285,12 +365,11 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, doub
 
     const double axnl = em * cw;
     const double aynl = fma(em, sw, temp * k.aycof());
-    // u0 = U + (rest of no*templ) + temp*xlcof*axnl
+    // u0 = U + (rest of no*templ) + temp*xlcof*axnl: |.| <= 1/8, sin to d^7 and cos to d^8 (d^9/9! < 2.1e-14)
     double s = st.sU, c = st.cU;
     {
         const double eps = fma(temp * k.xlcof(), axnl, nl);
-        bad |= !(fabs(eps) <= AZ_ROT_MED);
-        az_pq_med(eps, rk, p, q);
+        az_pq_16th(eps, rk, p, q);
         az_rot_apply2(s, c, p, q);
     }
 
@@ -299,10 +378,9 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, doub
     if (!ECC) {
         // Kepler, near-circular form (see az_kepler_posvel): Newton step from E0 = u, chord step with the
         // same reciprocal, first-order rotation by the second correction
-        bad |= !(el2 <= AZ_FAST_EL2);
         const double rden = az_rcp1(fma(-s, aynl, fma(-c, axnl, 1.0)));
         const double d0 = fma(axnl, s, -(aynl * c)) * rden;
-        az_fpq_small(d0, rk, p, q); // |d0| <= el/(1-el) < 2^-7
+        az_fpq_milli(d0, rk, p, q); // |d0| <= el/(1-el) < 0.0041
         az_rot_apply2(s, c, p, q);
         const double d1 = fma(axnl, s, fma(-aynl, c, -d0)) * rden;
         {
@@ -313,11 +391,13 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, doub
         ecose = fma(axnl, c, aynl * s);
         esine = fma(axnl, s, -(aynl * c));
         ome = 1.0 - ecose;
-        inv_ome = fma(rden, fma(-ome, rden, 1.0), rden);
-        inv_ome = fma(inv_ome, fma(-ome, inv_ome, 1.0), inv_ome);
+        // 1/(1 - ecose) from the reciprocal of the Newton step (1 - ecose before the two rotations: off by
+        // x ~ el (d0 + d1) <= 1.7e-5 relative): rden (1 + x + x^2), x = 1 - ome rden   (x^3 < 5e-15)
+        const double x = fma(-ome, rden, 1.0);
+        inv_ome = fma(rden, fma(x, x, x), rden);
         betal = fma(el2, fma(el2, -0.125, -0.5), 1.0);    // sqrt(1-x)   (- x^3/16)
-        inv_omel2 = fma(el2, el2 + 1.0, 1.0);             // 1/(1-x)     (+ x^3 < 4.1e-15)
-        inv_1pb = fma(el2, fma(el2, 0.0625, 0.125), 0.5); // 1/(1+betal) (+ 5x^3/128)
+        inv_omel2 = el2 + 1.0;                            // 1/(1-x): x^2 < 2.6e-10 relative on the J2 terms (< 1e-3)
+        inv_1pb = fma(el2, rk(RC_p8), 0.5);               // 1/(1+betal): x^2/16 < 1.6e-11, times esine < 0.004
     } else {
         // Kepler, any near-earth eccentricity (el < ~0.33): five Newton trips on E - aynl cosE + axnl sinE = u
         // carrying eps = E - u and rotating (sinE, cosE) by each correction, with the rotation tier FIXED per
@@ -367,17 +447,15 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, doub
     const double inv_pl = inv_am * inv_omel2;
     const double temp1 = g.half_j2 * inv_pl;
     const double temp2 = temp1 * inv_pl;
-    bad |= !(temp2 <= AZ_FAST_TEMP2);
 
     const double mrt = fma(rl, fma(k.k_mrt() * temp2, betal, 1.0), k.k_c2u() * temp1 * cos2u);
     const double t2s = temp2 * sin2u;
     // J2 short-period corrections as tiny rotations (each bounded by 1.5 temp2 <= 9e-4); the node's own motion
     // about the window centre, nodedot (t - tmid) + xnodcf t^2, rides on the node correction
     const double a_nd = fma(k.k_node(), t2s, fma(k.nodedot(), t - k.tmid(), k.xnodcf() * t2));
-    bad |= !(fabs(a_nd) <= AZ_ROT_MED);
     double ssu = sinu, csu = cosu, sn = k.sOc(), cn = k.cOc(), si = k.sinio(), ci = k.cosio();
     az_rotate_tiny2(ssu, csu, k.k_su() * t2s, rk);
-    az_pq_med(a_nd, rk, p, q); // J2 correction + the node's motion across the window (up to ~0.03 rad over +-400 min)
+    az_pq_16th(a_nd, rk, p, q); // J2 correction + the node's motion across the window (up to ~0.03 rad over +-400 min; <= 1/8)
     az_rot_apply2(sn, cn, p, q);
     az_rotate_tiny2(si, ci, k.k_inc() * temp2 * cos2u, rk);
 

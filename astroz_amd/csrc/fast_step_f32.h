@@ -41,8 +41,6 @@ AZ_DEVICE az_f2 az_fma2(az_f2 a, az_f2 b, float c) { return az_fma2(a, b, az_spl
 AZ_DEVICE az_f2 az_fma2(float a, az_f2 b, float c) { return az_fma2(az_splat2(a), b, az_splat2(c)); }
 AZ_DEVICE az_f2 az_rcp2(az_f2 a) { az_f2 r; r.x = az_rcp32(a.x); r.y = az_rcp32(a.y); return r; }
 AZ_DEVICE az_f2 az_cvt2(double a, double b) { az_f2 r; r.x = (float)a; r.y = (float)b; return r; }
-// !(|a| <= lim) in either half (NaN counts as out of range)
-AZ_DEVICE bool az_out2(az_f2 a, float lim) { return !(fabsf(a.x) <= lim) | !(fabsf(a.y) <= lim); }
 
 // per-satellite constants of the packed step.  Used once per step (LDS candidates) / several times (registers):
 #define AZ_F32_ONCE(X) \
@@ -157,8 +155,10 @@ AZ_DEVICE void az_rot32_small(az_f2 &s, az_f2 &c, az_f2 d)
 
 // One lane step = the two grid points ta and ta + step1.  st: the carried pairs (advanced here by one lane step
 // first, as in az_sgp4_fast_step).  r, v: component j of the even / odd point in r[j].x / r[j].y.
+// Only inside a window az_fast_window_ok<false> accepted (fast_step.h: the bounds are on the fp64 quantities; the fp32
+// ones differ from them by roundings, and no tier has a cliff at its threshold).
 template <bool VEL, class K>
-AZ_DEVICE bool az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, FastCarry32 &st, az_f2 r[3], az_f2 v[3])
+AZ_DEVICE void az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, FastCarry32 &st, az_f2 r[3], az_f2 v[3])
 {
     {
         const az_f2 nsA = az_fma2(k.cdA32(), st.sA, k.sdA32() * st.cA);
@@ -184,7 +184,6 @@ AZ_DEVICE bool az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, Fas
     // 1 - tempa = t (cc1 + t (d2 + t (d3 + t d4))) is small (1e-3 after a week): fp32 is plenty for it
     const az_f2 dev = t * az_fma2(t, az_fma2(t, az_fma2(k.d4(), t, k.d3()), k.d2()), k.cc1());
     const az_f2 nl = az_fma2(k.nl2() * dtc, dtc, t2 * (t * az_fma2(t, az_fma2(k.nl5(), t, k.nl4()), k.nl3())));
-    bool bad = az_out2(th, (float)AZ_ROT_16TH);
     // M + th and W - th: both pairs only enter through eccentricity-scaled terms (x 0.004), |th| <= 1/16:
     // sin th = th - th^3/6 (error 8e-9), cos th = 1 - th^2/2 (error 6e-7 x 0.004), one polynomial for both
     const az_f2 th2 = th * th;
@@ -212,14 +211,12 @@ AZ_DEVICE bool az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, Fas
     az_f2 c = az_cvt2(st.cU, fma(st.cU, k.c1U, -(st.sU * k.s1U)));
     {
         const az_f2 eps = az_fma2(k.xlcof() * temp, axnl, nl);
-        bad |= az_out2(eps, (float)AZ_ROT_MED);
         az_rot32_med(s, c, eps);
     }
 
     // Kepler, near-circular: one Newton step from E0 = u (the next correction, (el/2) d0^2 <= 3.2e-8, is below
     // fp32 resolution)
     const az_f2 el2 = az_fma2(axnl, axnl, aynl * aynl);
-    bad |= !(el2.x <= (float)AZ_FAST_EL2) | !(el2.y <= (float)AZ_FAST_EL2);
     const az_f2 rden = az_rcp2(az_fma2(-s, aynl, az_fma2(-c, axnl, 1.0f)));
     const az_f2 d0 = az_fma2(axnl, s, -(aynl * c)) * rden;
     az_rot32_small(s, c, d0);
@@ -240,7 +237,6 @@ AZ_DEVICE bool az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, Fas
     const az_f2 inv_pl = inv_am * inv_omel2;
     const az_f2 temp1 = (float)g.half_j2 * inv_pl;
     const az_f2 temp2 = temp1 * inv_pl;
-    bad |= !(temp2.x <= (float)AZ_FAST_TEMP2) | !(temp2.y <= (float)AZ_FAST_TEMP2);
 
     // mrt = rl (1 + k_mrt temp2 betal) + k_c2u temp1 cos2u, rl = am (1 - ecose): fp64 (cancellation-free, but the
     // result is the radius itself: an fp32 chain here costs a metre); the two corrections are small and enter as fp32
@@ -253,7 +249,6 @@ AZ_DEVICE bool az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, Fas
     const az_f2 rs = az_cvt2(mrt_a * g.radius_km, mrt_b * g.radius_km);
     const az_f2 t2s = temp2 * sin2u;
     const az_f2 a_nd = az_fma2(k.k_node(), t2s, az_fma2(k.nodedot(), az_splat2((float)(ta - k.tmid)) + lane01, k.xnodcf() * t2));
-    bad |= az_out2(a_nd, (float)AZ_ROT_MED);
     az_f2 ssu = sinu, csu = cosu, sn = az_splat2(k.sOc()), cn = az_splat2(k.cOc()), si = az_splat2(k.sinio()),
           ci = az_splat2(k.cosio());
     az_rot32_tiny(ssu, csu, k.k_su() * t2s);
@@ -280,5 +275,4 @@ AZ_DEVICE bool az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, Fas
         v[1] = az_fma2(mvt, uy, rvdot * vy);
         v[2] = az_fma2(mvt, uz, rvdot * vz);
     }
-    return bad;
 }

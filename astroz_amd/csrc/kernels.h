@@ -87,10 +87,19 @@ struct PropArgs {
     unsigned n_circ;     // row kernels on a uniform grid: list = [n_circ members of eccentricity class 0 | the rest]
     unsigned redo_slot0; // added to a k_rows_fast launch's list slots when it files redo items (sub-list launches)
     unsigned *redo_count;
-    unsigned *redo_next; // the other launch parity's counter (zeroed by the redo pass for the launch after this one)
+    unsigned *redo_next; // the other launch parity's counter (re-armed by the redo pass for the launch after this one)
     unsigned *redo_items;
+    // the window plan of the staged grid (k_plan_windows): per (time segment, list slot) the window constants of the fast
+    // step and whether its validation bounds hold; rejected windows are items [0, *redo_static) of the redo list
+    const double *plan_win;         // [n_seg][plan_stride][AZ_PLAN_NUM]
+    const unsigned char *plan_flag; // [n_seg][plan_stride]: AZ_PLAN_OK | AZ_PLAN_TC
+    unsigned plan_stride;
+    const unsigned *redo_static;
     AzGrav g;
 };
+enum { AZ_PLAN_sOc, AZ_PLAN_cOc, AZ_PLAN_sdU, AZ_PLAN_cdU, AZ_PLAN_s1U, AZ_PLAN_c1U, AZ_PLAN_NUM };
+#define AZ_PLAN_OK 1u /* the fast step's validation bounds hold over this window (az_fast_window_ok) */
+#define AZ_PLAN_TC 2u /* the drag phase is expanded about the window centre (tc = tmid), else tc = 0 */
 
 // one result vector -> memory, fp64 or fp32
 template <class T>
@@ -392,10 +401,12 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
     // angle inside its usual tier; one vote per step, the generic loop takes over on a violation.
     if (!DEEP && p.inc != nullptr && p.uniform_step != 0.0 && !az_any(AZ_FLAG_ECLASS(fl) != 0)) {
         FastKCol k;
+        bool window_ok;
         {
             FastK k0;
             az_load_fast(p.el, p.n_pad, s, fl, p.inc, 1, k0);
             az_fast_window(p.el, p.n_pad, s, p.times[t0] + off, p.times[t1 - 1] + off, p.uniform_step, k0);
+            window_ok = !az_any(in_range && !az_fast_window_ok<false>(k0, p.g, p.times[t0] + off, p.times[t1 - 1] + off));
             static_assert((int)FC_NUM <= (int)C_NUM, "the fast step's cold constants share the generic step's LDS columns");
 #define X(n) cold[FC_##n * AZ_COLD_STRIDE] = k0.n##_;
             AZ_FASTK_COLD(X)
@@ -409,14 +420,13 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
         FastCarry fc;
         az_seed_fast(p.el, p.n_pad, s, p.times[t0] + off - p.uniform_step, k.tc_, fc);
 #pragma unroll 1
-        for (; i < t1; ++i) {
+        for (; window_ok && i < t1; ++i) {
             const double t = time_at(i);
             double r[3], v[3];
 #if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
             r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
 #else
-            const bool bad = az_sgp4_fast_step<VEL, false>(k, p.g, RotCoefLit(), t, fc, r, v);
-            if (az_any(bad && in_range)) break;
+            az_sgp4_fast_step<VEL, false>(k, p.g, RotCoefLit(), t, fc, r, v); // (validated for the whole tile above)
 #endif
             emit(i, r, v, 0);
         }
@@ -567,6 +577,82 @@ __global__ void __launch_bounds__(64) k_one_satellite(const double *el, const un
     }
 }
 
+// Window plan of a staged uniform grid, once per (grid, launch shape): one lane per (list slot, time segment) evaluates
+// what every wave of the row / tile kernels used to redo at its start -- the window-centred constants of the fast step
+// (fast_step.h: az_fast_window) and its validation bounds (az_fast_window_ok) -- and files the windows the bounds reject
+// as the STATIC part of the redo list.  The fast kernels then read four scalars and a flag per wave (no sincos, no
+// divisions, no compares, no vote), never file class-0 items themselves, and the generic pass over the rejected windows
+// no longer depends on them: it runs beside the bulk launch instead of after it.
+//   slots [0, n_circ): near-circular form, segments of tile_c points; the rest: eccentric form, tile_e; TILES: the class
+//   is the satellite's own (k_tiles_fast: catalog-ordered list, one tile length).  dt_mult: grid steps per lane step
+//   (64; 128 for the packed fp32 kernel, which also needs the one-grid-step increment of U).
+struct PlanArgs {
+    const double *el;
+    const unsigned *flags;
+    size_t n_pad;
+    const unsigned *list;
+    unsigned n_list, n_circ, n_times, tile_c, tile_e, by_flags;
+    const double *times, *offsets, *inc;
+    double step, dt_mult;
+    double *win;
+    unsigned char *flag;
+    unsigned *redo_static, *redo_c0, *redo_c1, *redo_items;
+    AzGrav g;
+};
+__global__ void __launch_bounds__(256) k_plan_windows(PlanArgs a)
+{
+    const unsigned slot = blockIdx.x * 256 + threadIdx.x;
+    const unsigned seg = blockIdx.y;
+    if (slot >= a.n_list) return;
+    const unsigned s = a.list[slot];
+    const unsigned fl = a.flags[s];
+    const bool ecc = a.by_flags ? AZ_FLAG_ECLASS(fl) != 0 : slot >= a.n_circ;
+    const unsigned tile = ecc ? a.tile_e : a.tile_c;
+    const unsigned t_lo = seg * tile;
+    if (t_lo >= a.n_times) return;
+    const unsigned t_hi = min(t_lo + tile, a.n_times);
+    const double t_first = a.times[0] + (a.offsets ? a.offsets[s] : 0.0);
+    const double w_a = fma((double)t_lo, a.step, t_first), w_b = fma((double)(t_hi - 1), a.step, t_first);
+    FastK k0, k1;
+    az_load_fast(a.el, a.n_pad, s, fl, a.inc, 0, k0);
+    const double dt_mult = ecc ? 64.0 : a.dt_mult; // (eccentric members always take the fp64 row kernel: 64 grid points per lane step)
+    if (dt_mult == 128.0) az_double_increments(k0);
+    az_fast_window(a.el, a.n_pad, s, w_a, w_b, dt_mult * a.step, k0);
+    az_load_fast(a.el, a.n_pad, s, fl, a.inc, 1, k1);
+    az_fast_window(a.el, a.n_pad, s, w_a, w_b, a.step, k1);
+    // a class the form cannot take (an eccentric member in the near-circular list) is rejected like a failed bound
+    bool ok = ecc ? az_fast_window_ok<true>(k0, a.g, w_a, w_b) : az_fast_window_ok<false>(k0, a.g, w_a, w_b);
+    if (!ecc && AZ_FLAG_ECLASS(fl) != 0) ok = false;
+    const size_t at = (size_t)seg * a.n_list + slot;
+    double *w = a.win + at * AZ_PLAN_NUM;
+    w[AZ_PLAN_sOc] = k0.sOc_; w[AZ_PLAN_cOc] = k0.cOc_; w[AZ_PLAN_sdU] = k0.sdU_; w[AZ_PLAN_cdU] = k0.cdU_;
+    w[AZ_PLAN_s1U] = k1.sdU_; w[AZ_PLAN_c1U] = k1.cdU_;
+    a.flag[at] = (unsigned char)((ok ? AZ_PLAN_OK : 0u) | (k0.tc_ != 0.0 ? AZ_PLAN_TC : 0u));
+    if (!ok) {
+        const unsigned k = atomicAdd(a.redo_static, 1u);
+        a.redo_items[3 * (size_t)k + 0] = slot;
+        a.redo_items[3 * (size_t)k + 1] = t_lo;
+        a.redo_items[3 * (size_t)k + 2] = t_hi;
+    }
+}
+// after k_plan_windows: both dynamic counters start behind the static items
+__global__ void k_plan_arm(unsigned *redo_static, unsigned *c0, unsigned *c1)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *c0 = *c1 = *redo_static;
+}
+// window constants of one wave's segment from the plan (wave-uniform scalar loads)
+template <class K>
+__device__ __forceinline__ bool az_plan_window(const PropArgs &p, unsigned seg, unsigned slot, double w_a, double w_b, K &k0)
+{
+    const size_t at = (size_t)seg * p.plan_stride + slot;
+    const double *w = p.plan_win + at * AZ_PLAN_NUM;
+    const unsigned f = p.plan_flag[at];
+    k0.tmid_ = 0.5 * (w_a + w_b);
+    k0.tc_ = (f & AZ_PLAN_TC) ? k0.tmid_ : 0.0;
+    k0.sOc_ = w[AZ_PLAN_sOc]; k0.cOc_ = w[AZ_PLAN_cOc]; k0.sdU_ = w[AZ_PLAN_sdU]; k0.cdU_ = w[AZ_PLAN_cdU];
+    return (f & AZ_PLAN_OK) != 0;
+}
+
 // Satellite-major output, near-earth: ONE WAVE PER SATELLITE ROW, lane = time.
 // The row (s, :, :) is contiguous in memory, so with lane = time a wave's 64 results of one
 // iteration are 1,536 contiguous bytes per array -- perfectly coalesced without any staging.  All
@@ -591,6 +677,15 @@ AZ_DEVICE float az_uniform32(float x)
 #else
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
 #endif
+}
+// p, as an LDS address held in a VGPR that the compiler cannot see through (loads through it are not hoisted out of a
+// loop, and stay ds_read with immediate offsets from this one base)
+__device__ __forceinline__ const double *az_opaque_lds(const double *p)
+{
+    typedef __attribute__((address_space(3))) const double lds_cdouble;
+    lds_cdouble *q = (lds_cdouble *)p;
+    asm volatile("" : "+v"(q));
+    return (const double *)q;
 }
 // once-per-step constants of a lane = time kernel: one LDS word per constant, read by all 64 lanes
 // at once (broadcast ds_read_b64: no VALU slot, no SGPRs -- the 33 uniform doubles of a satellite do
@@ -709,7 +804,8 @@ __global__ void __launch_bounds__(64, FRAME ? 2 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
     const unsigned t_lo = blockIdx.y * p.tile;
     const unsigned t_hi = min(t_lo + p.tile, p.n_times);
     unsigned base = t_lo;
-    if (ECC || AZ_FLAG_ECLASS(fl) == 0) { // (the near-circular instantiation hands a stray eccentric member to the redo list)
+    bool window_ok;
+    {
         __shared__ __attribute__((aligned(16))) double cold_lds[FC_NUM + RC_NUM];
         __shared__ __attribute__((aligned(16))) out_t rows_stage[AZ_ROWS_LDS_STORE ? 2 * 64 * 3 : 4];
         const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
@@ -722,8 +818,11 @@ __global__ void __launch_bounds__(64, FRAME ? 2 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
         {
             FastK k0;
             az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k0);
-            az_fast_window(p.el, p.n_pad, s, fma((double)t_lo, p.uniform_step, p.times[0] + off),
-                           fma((double)(t_hi - 1), p.uniform_step, p.times[0] + off), 64.0 * p.uniform_step, k0);
+            const double w_a = fma((double)t_lo, p.uniform_step, p.times[0] + off), w_b = fma((double)(t_hi - 1), p.uniform_step, p.times[0] + off);
+            // window constants and the verdict of the validation bounds: prepared once per staged grid (k_plan_windows); a
+            // rejected window is already on the redo list
+            window_ok = az_plan_window(p, blockIdx.y, row + p.redo_slot0, w_a, w_b, k0);
+            if (!window_ok) return;
 #define X(n) if (lane == 0) cold_lds[FC_##n] = k0.n##_;
             AZ_FASTK_COLD(X)
 #undef X
@@ -738,16 +837,17 @@ __global__ void __launch_bounds__(64, FRAME ? 2 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
         // seed one increment (64 grid steps) BEFORE this lane's first grid point
         az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, fc);
 #pragma unroll 1
-        for (; base < t_hi; base += 64) {
+        for (; window_ok && base < t_hi; base += 64) {
             const unsigned i = base + lane;
             const bool live = i < t_hi;
             const double t = fma((double)i, step, t_first);
-            // the cold constants are re-read from LDS where they are used: an opaque zero in the address keeps
-            // the compiler from hoisting 16 loop-invariant loads into 32 VGPRs
-            unsigned zero = 0;
-            asm volatile("" : "+s"(zero));
-            k.cold = cold_lds + zero;
-            const RotCoefLds rk{cold_lds + FC_NUM + zero};
+            // the cold constants are re-read from LDS where they are used: an address the compiler cannot see through
+            // keeps it from hoisting 16 loop-invariant loads into 32 VGPRs.  The opaque value is the LDS byte address of
+            // the table itself, in a VGPR: DS addresses are VGPRs, and from one VGPR base every read is an immediate
+            // offset (round 2's opaque scalar zero cost an s_add + v_mov per read: twelve VALU slots per iteration)
+            const double *cold_now = az_opaque_lds(cold_lds);
+            k.cold = cold_now;
+            const RotCoefLds rk{cold_now + FC_NUM};
             double r[3], v[3];
 #if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
             r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
@@ -762,8 +862,9 @@ __global__ void __launch_bounds__(64, FRAME ? 2 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
             az_rows_store<VEL>(staged, base + 64 <= t_hi, live, lane, rows_stage, prow, vrow, base, r, v);
         }
     }
-    if (base < t_hi && lane == 0) {
-        // rest of the segment -> generic kernel (one item: list slot, first grid point, end)
+    if (ECC && base < t_hi && lane == 0) {
+        // the eccentric form's Newton iteration left its tiers: rest of the segment -> generic kernel (one item: list slot,
+        // first grid point, end), behind the static items of the plan
         const unsigned k = atomicAdd(p.redo_count, 1u);
         p.redo_items[3 * (size_t)k + 0] = row + p.redo_slot0;
         p.redo_items[3 * (size_t)k + 1] = base;
@@ -829,7 +930,9 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
         if (lane == 0) az_rotcoef_store([&](int j, double x) { cold_lds[FC_NUM + j] = x; });
         FastK k0;
         az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k0);
-        az_fast_window(p.el, p.n_pad, s, fma((double)t_lo, step, t_first), fma((double)(t_hi - 1), step, t_first), 64.0 * step, k0);
+        const double w_a = fma((double)t_lo, step, t_first), w_b = fma((double)(t_hi - 1), step, t_first);
+        // (a window the plan rejected is a static item of the redo list: the generic kernel writes that satellite's pieces)
+        if (!az_plan_window(p, blockIdx.y, slot, w_a, w_b, k0)) dead = true;
 #define X(n) if (lane == 0) cold_lds[FC_##n] = k0.n##_;
         AZ_FASTK_COLD(X)
 #undef X
@@ -880,10 +983,9 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
         double r[3], v[3];
         if (!dead) {
             const double t = fma((double)i, step, t_first);
-            unsigned zero = 0;
-            asm volatile("" : "+s"(zero));
-            k.cold = cold_lds + zero;
-            const RotCoefLds rk{cold_lds + FC_NUM + zero};
+            const double *cold_now = az_opaque_lds(cold_lds);
+            k.cold = cold_now;
+            const RotCoefLds rk{cold_now + FC_NUM};
             const bool bad = ecc ? az_sgp4_fast_step<VEL, true>(k, p.g, rk, t, fc, r, v) : az_sgp4_fast_step<VEL, false>(k, p.g, rk, t, fc, r, v);
             if (ECEF) {
                 const unsigned jj = min(i, t_hi - 1) - t_lo;
@@ -984,15 +1086,21 @@ __global__ void __launch_bounds__(64, AZ_ROWSF32_WAVES) k_rows_fast32(PropArgs p
         __shared__ float once_lds[F32_NUM];
         FastK32Bcast k;
         FastCarry32 fc;
+        bool window_ok;
         const unsigned stage_w = az_lds_address(rows_stage) + lane * 24, stage_r = az_lds_address(rows_stage) + lane * 16;
         {
             const double w_a = fma((double)t_lo, step, t_first), w_b = fma((double)(t_hi - 1), step, t_first);
             FastK k0, k1;
             az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k0);   // increments of 64 grid steps ...
             az_double_increments(k0);                           // ... of 128: one lane step
-            az_fast_window(p.el, p.n_pad, s, w_a, w_b, 128.0 * step, k0);
+            window_ok = az_plan_window(p, blockIdx.y, row + p.redo_slot0, w_a, w_b, k0);
+            if (!window_ok) return;                             // (a static item of the redo list)
             az_load_fast(p.el, p.n_pad, s, fl, p.inc, 1, k1);   // increments of one grid step
-            az_fast_window(p.el, p.n_pad, s, w_a, w_b, step, k1);
+            {
+                const double *w = p.plan_win + ((size_t)blockIdx.y * p.plan_stride + row + p.redo_slot0) * AZ_PLAN_NUM;
+                k1.sdU_ = w[AZ_PLAN_s1U]; k1.cdU_ = w[AZ_PLAN_c1U];
+                k1.tc_ = k0.tc_; k1.tmid_ = k0.tmid_; k1.sOc_ = k0.sOc_; k1.cOc_ = k0.cOc_;
+            }
             FastK32 kk;
             az_load_fast32(k0, k1, step, kk);
 #define X(n) if (lane == 0) once_lds[F32_##n] = kk.n##_;
@@ -1011,7 +1119,7 @@ __global__ void __launch_bounds__(64, AZ_ROWSF32_WAVES) k_rows_fast32(PropArgs p
             az_seed_fast32(f0, k1, fc);
         }
 #pragma unroll 1
-        for (; base < t_hi; base += 128) {
+        for (; window_ok && base < t_hi; base += 128) {
             const unsigned i = base + 2 * lane;
             const bool live_a = i < t_hi, live_b = i + 1 < t_hi;
             const double t = fma((double)i, step, t_first);
@@ -1024,8 +1132,7 @@ __global__ void __launch_bounds__(64, AZ_ROWSF32_WAVES) k_rows_fast32(PropArgs p
 #if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
             r[0] = az_splat2((float)t); r[1] = r[0] + 1.0f; r[2] = r[0] + 2.0f; v[0] = r[0] + 3.0f; v[1] = r[0] + 4.0f; v[2] = r[0] + 5.0f;
 #else
-            const bool bad = az_sgp4_fast_step_f32<VEL>(k, p.g, t, fc, r, v);
-            if (az_any(bad && live_a)) break;
+            az_sgp4_fast_step_f32<VEL>(k, p.g, t, fc, r, v);
 #endif
 #if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only (every component stays live) */
             if (!(live_a && (r[0].x + r[1].x + r[2].x + r[0].y + r[1].y + r[2].y +
@@ -1057,12 +1164,6 @@ __global__ void __launch_bounds__(64, AZ_ROWSF32_WAVES) k_rows_fast32(PropArgs p
                 }
             }
         }
-    }
-    if (base < t_hi && lane == 0) {
-        const unsigned k = atomicAdd(p.redo_count, 1u);
-        p.redo_items[3 * (size_t)k + 0] = row + p.redo_slot0;
-        p.redo_items[3 * (size_t)k + 1] = base;
-        p.redo_items[3 * (size_t)k + 2] = t_hi;
     }
 }
 
@@ -1197,7 +1298,7 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     // two item counters used alternately: this launch consumed redo_count, the NEXT launch's k_rows_fast (ordered
     // after this kernel on the stream) appends through redo_next, which is re-armed here.  (An arrival counter
     // with "last one out resets" serialises one atomic per workgroup on a single address: measured 100 us.)
-    if (redo && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) *p.redo_next = 0u;
+    if (redo && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0) *p.redo_next = *p.redo_static; // dynamic items go behind the plan's static ones
 }
 
 // Deep-space rows, satellite-major output (and the fused screen): ONE WAVE PER SATELLITE, lane = time,

@@ -76,16 +76,58 @@ static void emul_fast_run(const double* fields, unsigned flags, const double* gr
         FastK k;
         az_load_fast(fields, 1, 0, flags, inc, 0, k);
         az_fast_window(fields, 1, 0, ts0 + w0 * dt, ts0 + (w1 - 1) * dt, dt, k);
+        const bool win_bad = ecc ? !az_fast_window_ok<true>(k, g, ts0 + w0 * dt, ts0 + (w1 - 1) * dt)
+                                 : !az_fast_window_ok<false>(k, g, ts0 + w0 * dt, ts0 + (w1 - 1) * dt);
         FastCarry st;
         az_seed_fast(fields, 1, 0, ts0 + (w0 - 1) * dt, k.tc_, st);
         for (int i = w0; i < w1; ++i) {
             double r[3], v[3];
-            bad_out[i] = (ecc ? az_sgp4_fast_step<true, true>(k, g, RotCoefLit(), ts0 + i * dt, st, r, v)
-                              : az_sgp4_fast_step<true, false>(k, g, RotCoefLit(), ts0 + i * dt, st, r, v)) ? 1 : 0;
+            // the kernels never run the step in a window the bounds reject: report the whole window as bad
+            bad_out[i] = ((ecc ? az_sgp4_fast_step<true, true>(k, g, RotCoefLit(), ts0 + i * dt, st, r, v)
+                               : az_sgp4_fast_step<true, false>(k, g, RotCoefLit(), ts0 + i * dt, st, r, v)) || win_bad) ? 1 : 0;
             memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
         }
     }
 }
+// k_rows_fast as the kernel runs one satellite row: time segments of `tile` grid points (a multiple of 64), one window
+// set-up and validation per segment over ALL its grid points, lane l producing points t_lo + l + 64 j with increments of
+// 64 grid steps.  out6: n_times rows; bad_out[i] = 1 where the point belongs to a rejected segment (window bounds) or,
+// eccentric form, follows a rejected step of its segment (the kernel hands the rest of the segment to the generic path).
+void emul_rows_fast(const double* fields, unsigned flags, const double* grav6, double t_first, double step, int n_times, int tile,
+                    int ecc, double* out6, int* bad_out)
+{
+    AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
+    double inc[2 * AZ_INC_NUM];
+    const double rate[2] = {fields[F_mdot], fields[F_argpdot]};
+    for (int which = 0; which < 2; ++which)
+        for (int a = 0; a < 2; ++a)
+            az_sincos(rate[a] * (which == 0 ? 64.0 * step : step), inc[AZ_INC_NUM * which + 2 * a], inc[AZ_INC_NUM * which + 2 * a + 1]);
+    for (int t_lo = 0; t_lo < n_times; t_lo += tile) {
+        const int t_hi = t_lo + tile < n_times ? t_lo + tile : n_times;
+        FastK k;
+        az_load_fast(fields, 1, 0, flags, inc, 0, k);
+        const double w_a = fma((double)t_lo, step, t_first), w_b = fma((double)(t_hi - 1), step, t_first);
+        az_fast_window(fields, 1, 0, w_a, w_b, 64.0 * step, k);
+        const bool ok = ecc ? az_fast_window_ok<true>(k, g, w_a, w_b) : az_fast_window_ok<false>(k, g, w_a, w_b);
+        int first_bad_base = ok ? t_hi : t_lo; // the wave leaves the loop at the first iteration any live lane rejects
+        for (int lane = 0; lane < 64 && ok; ++lane) {
+            FastCarry st;
+            az_seed_fast(fields, 1, 0, fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, st);
+            for (int base = t_lo; base < t_hi; base += 64) {
+                const int i = base + lane;
+                double r[3], v[3];
+                const double t = fma((double)i, step, t_first);
+                const bool bad = ecc ? az_sgp4_fast_step<true, true>(k, g, RotCoefLit(), t, st, r, v)
+                                     : az_sgp4_fast_step<true, false>(k, g, RotCoefLit(), t, st, r, v);
+                if (i >= t_hi) break;
+                if (bad && base < first_bad_base) first_bad_base = base;
+                memcpy(out6 + 6 * (size_t)i, r, 24); memcpy(out6 + 6 * (size_t)i + 3, v, 24);
+            }
+        }
+        for (int i = t_lo; i < t_hi; ++i) bad_out[i] = (t_lo + (i - t_lo) / 64 * 64 >= first_bad_base) ? 1 : 0;
+    }
+}
+
 void emul_propagate_fast(const double* fields, unsigned flags, const double* grav6, double ts0, double dt, int n,
                          int ecc, double* out6, int* bad_out)
 {
@@ -117,6 +159,7 @@ void emul_propagate_fast32(const double* fields, unsigned flags, const double* g
         az_load_fast(fields, 1, 0, flags, inc, 0, k0);
         az_double_increments(k0);
         az_fast_window(fields, 1, 0, w_a, w_b, dt, k0);
+        const bool win_bad = !az_fast_window_ok<false>(k0, g, w_a, w_b);
         az_load_fast(fields, 1, 0, flags, inc, 1, k1);
         az_fast_window(fields, 1, 0, w_a, w_b, step, k1);
         FastK32 k32;
@@ -127,7 +170,8 @@ void emul_propagate_fast32(const double* fields, unsigned flags, const double* g
         az_seed_fast32(f0, k1, st);
         for (int i = w0; i < w1; ++i) {
             az_f2 r[3], v[3];
-            bad_out[i] = az_sgp4_fast_step_f32<true>(k32, g, ts0 + i * dt, st, r, v) ? 1 : 0;
+            az_sgp4_fast_step_f32<true>(k32, g, ts0 + i * dt, st, r, v);
+            bad_out[i] = win_bad ? 1 : 0;
             for (int j = 0; j < 3; ++j) {
                 out6[12*i + j] = r[j].x; out6[12*i + 3 + j] = v[j].x;
                 out6[12*i + 6 + j] = r[j].y; out6[12*i + 9 + j] = v[j].y;

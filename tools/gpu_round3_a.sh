@@ -1,13 +1,10 @@
 #!/bin/bash
-# round 3, GPU call A: the full -m gpu tier, smoke, and the default bench line (with its `secondary` block)
-mkdir -p gpurun_out/r3a
-timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/r3a/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r3a/pytest.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r3a/smoke.log 2>&1
-timeout 600 python bench.py > gpurun_out/r3a/bench.json 2> gpurun_out/r3a/bench.err
-tail -3 gpurun_out/r3a/pytest.log; tail -2 gpurun_out/r3a/smoke.log; python - <<'PY'
-import json
-j=json.loads([l for l in open("gpurun_out/r3a/bench.json") if l.startswith("{")][-1])
-print("headline ms/step", j["ms_per_step"], "value", j["value"], "frac", j["roofline"]["frac"], "power", j.get("power"))
-for e in j.get("secondary", []):
-    print(e.get("key"), e.get("ms_per_step"), e.get("roofline", {}).get("frac"), e.get("parity"), e.get("cold_grid_call_ms"), e.get("failed"))
-PY
+# GPU call: the full -m gpu tier, smoke, and the default bench line (with its `secondary` block) -> gpurun_out/$TAG
+T=${TAG:-r3a}
+mkdir -p gpurun_out/$T
+timeout 900 python -m pytest tests -m gpu -q $PYTEST_ARGS > gpurun_out/$T/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/$T/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$T/smoke.log 2>&1
+timeout 600 python bench.py $BENCH_ARGS > gpurun_out/$T/bench.json 2> gpurun_out/$T/bench.err
+grep -E "passed|failed" gpurun_out/$T/pytest.log | tail -2; tail -1 gpurun_out/$T/smoke.log
+python tools/show_bench.py gpurun_out/$T/bench.json
+exit 0

@@ -39,7 +39,7 @@ def run(extra):
             continue
         name = f[4:-3]
         env = dict(os.environ, ASTROZ_AMD_LIB=os.path.join(VAR, f))
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + extra
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary"] + extra
         r = subprocess.run(cmd, capture_output=True, text=True, env=env)
         try:
             j = json.loads(r.stdout.strip().splitlines()[-1])
