@@ -134,6 +134,9 @@ struct azh_constellation {
     hipStream_t s_main = nullptr, s_deep = nullptr, s_ecc = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     unsigned off_cat = 0; // d_list + off_cat: near-earth members in plain catalog order (k_tiles_fast: runs of consecutive rows)
+    unsigned off_deep_cat = 0; // d_list + off_deep_cat: deep-space members in plain catalog order (lane = time kernels)
+    unsigned off_rowmap = 0;   // d_list + off_rowmap: per catalog row, kind << 30 | slot (AZ_ROW_*: k_tiles_fast)
+    DevBuf<double> d_deep_tmp; // time-major output: the deep-space rows' compact satellite-major scratch (k_deep_transpose)
     bool tile_kernel = true; // time-major output on uniform grids through k_tiles_fast (azh_set_tile_kernel)
     unsigned off_circ = 0, n_circ = 0; // d_list + off_circ: near-earth members in catalog order, [n_circ of eccentricity class 0 | the rest]
     bool timed = false;
@@ -160,6 +163,7 @@ void destroy(azh_constellation *c)
     c->d_sin.release();
     c->d_cos.release();
     c->d_seeds.release();
+    c->d_deep_tmp.release();
     c->d_inc.release();
     for (auto &pl : c->plan) { pl.win.release(); pl.flag.release(); pl.redo.release(); }
     c->d_tgt.release();
@@ -300,6 +304,22 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
         c->off_cat = (unsigned)list.size();
         for (size_t s = 0; s < n; ++s)
             if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && !(c->h_flags[s] & AZ_FLAG_DEEP)) list.push_back((unsigned)s);
+        // ... and the deep-space members in plain catalog order: one wave per satellite needs no grouping by branch, and
+        // runs of consecutive rows leave the time-major transposer as single long stores
+        c->off_deep_cat = (unsigned)list.size();
+        for (size_t s = 0; s < n; ++s)
+            if (AZ_FLAG_ERR(c->h_flags[s]) == 0 && (c->h_flags[s] & AZ_FLAG_DEEP)) list.push_back((unsigned)s);
+        // ... and the row map of the time-major tile kernel: what every catalog row is and where its data comes from
+        c->off_rowmap = (unsigned)list.size();
+        {
+            unsigned near = 0, deepn = 0;
+            for (size_t s = 0; s < n; ++s) {
+                const unsigned f = c->h_flags[s];
+                if (AZ_FLAG_ERR(f) != 0) list.push_back((unsigned)AZ_ROW_ZERO << 30);
+                else if (f & AZ_FLAG_DEEP) list.push_back(((unsigned)AZ_ROW_COPY << 30) | deepn++);
+                else list.push_back(((unsigned)AZ_ROW_NEAR << 30) | near++);
+            }
+        }
         if (c->d_list.ensure(list.size()) != AZ_OK ||
             !hip_ok(hipMemcpy(c->d_list.p, list.data(), sizeof(unsigned) * list.size(), hipMemcpyHostToDevice), "H2D list")) {
             rc = AZ_ERR_HIP;
@@ -379,8 +399,8 @@ bool use_rows(const PropArgs &a, int layout, bool deep)
     // satellite-major near-earth rows (and the fused screen, which stores nothing): one wave per
     // satellite, lane = time
     // both populations have a lane = time kernel (k_rows, k_rows_deep).  Deep-space rows use theirs for the
-    // time-major layout too: the lane = satellite form needs 250+ VGPRs (1-2 waves/SIMD), which costs more
-    // than the scattered 24-byte stores of a few thousand rows.
+    // time-major layout too (the lane = satellite form needs 250+ VGPRs, 1-2 waves/SIMD): satellite-major into a
+    // compact scratch array, then k_deep_transpose (launch_all).
     if (deep && layout == AZ_LAYOUT_TIME_MAJOR && a.n_times >= 32) return true;
     return (layout == AZ_LAYOUT_SAT_MAJOR || a.screen_target) && a.n_times >= 32;
 }
@@ -389,7 +409,8 @@ bool use_rows(const PropArgs &a, int layout, bool deep)
 unsigned screen_parts(const PropArgs &a, bool deep)
 {
     if (use_rows(a, AZ_LAYOUT_SAT_MAJOR, deep)) {
-        const unsigned tile = rows_tile(a.n_list, a.n_times, a.tile_forced);
+        unsigned tile = rows_tile(a.n_list, a.n_times, a.tile_forced);
+        if (deep) tile = std::min(tile, 64u * (unsigned)AZ_DEEP_SEED_MAX); // as launch_propagate
         return (a.n_times + tile - 1) / tile;
     }
     return (a.n_times + a.tile - 1) / a.tile;
@@ -422,6 +443,10 @@ FastShape fast_shape_rows(const PropArgs &a, unsigned n_sgp4, unsigned n_circ)
     const unsigned n_ecc = n_sgp4 - n_circ;
     // eccentric members: few rows, finer time segments so that they still fill the chip when they run alone
     f.tile_e = std::min(rows_tile(std::max(n_ecc, 1u), a.n_times, 256), cap);
+    if (const char *ev = getenv("AZ_TILE_E")) { // tuning experiment
+        const unsigned v = (unsigned)atoi(ev);
+        if (v >= 64) f.tile_e = std::min(v / 64u * 64u, cap);
+    }
     f.tile_c = std::min(rows_tile(n_sgp4, a.n_times, a.tile_forced), cap);
     // packed fp32 kernel: a lane carries two grid points, a wave iteration 128 (windows shorter than that -- grid
     // steps beyond ~23 minutes -- keep the fp64 kernel with rounded stores)
@@ -430,10 +455,10 @@ FastShape fast_shape_rows(const PropArgs &a, unsigned n_sgp4, unsigned n_circ)
     f.kind = f.packed32 ? 1 : 0;
     return f;
 }
-FastShape fast_shape_tiles(const PropArgs &a, unsigned n_sgp4)
+FastShape fast_shape_tiles(const PropArgs &a, unsigned n_rows)
 {
     FastShape f;
-    unsigned tile = std::min(rows_tile(std::max((n_sgp4 + 15u) / 16u, 1u) * 16u, a.n_times, a.tile_forced), fast_window_cap(a.uniform_step));
+    unsigned tile = std::min(rows_tile(std::max((n_rows + 15u) / 16u, 1u) * 16u, a.n_times, a.tile_forced), fast_window_cap(a.uniform_step));
     if (a.mode == AZ_OUT_ECEF) tile = std::min(tile, (unsigned)AZ_TILE_SEG_MAX); // the Greenwich-angle table of a time segment is staged in LDS
     f.tile_c = f.tile_e = tile;
     f.kind = 2;
@@ -498,7 +523,7 @@ void launch_tiles(const PropArgs &a0, bool vel, hipStream_t st, const FastShape 
     PropArgs a = a0;
     a.tile = shape.tile_c;
     const bool ecef = a.mode == AZ_OUT_ECEF;
-    dim3 grid(((a.n_list + 15u) / 16u + 7u) / 8u * 8u, (a.n_times + a.tile - 1) / a.tile);
+    dim3 grid(((a.n_rows + 15u) / 16u + 7u) / 8u * 8u, (a.n_times + a.tile - 1) / a.tile); // tiles of 16 catalog rows
     if (ecef) {
         if (vel) hipLaunchKernelGGL((k_tiles_fast<true, true>), grid, dim3(1024), 0, st, a);
         else hipLaunchKernelGGL((k_tiles_fast<false, true>), grid, dim3(1024), 0, st, a);
@@ -524,7 +549,7 @@ void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStr
     if (use_rows(a, layout, deep)) {
         PropArgs b = a;
         b.tile = rows_tile(a.n_list, a.n_times, a.tile_forced);
-        b.tm_rows = (deep && layout == AZ_LAYOUT_TIME_MAJOR && !a.screen_target) ? 1 : 0;
+        if (deep) b.tile = std::min(b.tile, 64u * (unsigned)AZ_DEEP_SEED_MAX); // k_rows_deep stages a segment's chunk seeds in LDS
         dim3 grid((a.n_list + 7) / 8 * 8, (a.n_times + b.tile - 1) / b.tile);
         if (deep || a.screen_target || a.inc == nullptr) b.redo_items = nullptr; // k_rows_fast: near-earth rows on a uniform grid
         if (a.screen_target) {
@@ -608,7 +633,7 @@ int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, 
 int32_t prepare_deep(azh_constellation *c, PropArgs &d, hipStream_t st, bool rows)
 {
     const unsigned n_times = d.n_times;
-    d.list = c->d_list.p + c->n_sgp4;
+    d.list = c->d_list.p + (rows ? c->off_deep_cat : c->n_sgp4); // lane = time: catalog order; lane = satellite: grouped by branch
     d.n_list = c->n_sdp4;
     d.tile = auto_tile(c->n_sdp4, n_times, c->tile_sdp4, 8);
     d.tile_forced = c->tile_sdp4;
@@ -702,14 +727,44 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
 
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
     if (d_err) HIP_TRY(hipMemsetAsync(d_err + row_lo * (size_t)n_times, 0, (row_hi - row_lo) * (size_t)n_times, st));
+    // time-major output on a uniform grid: the near-earth members take the 16-satellite tile kernel
+    const bool tiles = c->n_sgp4 > 0 && c->tile_kernel && a.inc != nullptr && layout == AZ_LAYOUT_TIME_MAJOR && !f32 &&
+                       a.mode != AZ_OUT_GEODETIC && a.mask == nullptr && n_times >= 64 &&
+                       c->n < 5000000u; // (k_tiles_fast packs an output column, 3 n, into 24 bits)
     const bool fork = c->n_sdp4 > 0;
     if (fork) {
         // deep-space rows on their own stream, concurrent with the near-earth launch
         HIP_TRY(hipEventRecord(c->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(c->s_deep, c->ev_fork, 0));
         PropArgs d = a;
-        if (int32_t rc = prepare_deep(c, d, c->s_deep, use_rows(d, layout, true)); rc != AZ_OK) return rc;
-        launch_propagate(d, layout, d_vel != nullptr, true, c->s_deep);
+        const bool deep_rows = use_rows(d, layout, true);
+        if (int32_t rc = prepare_deep(c, d, c->s_deep, deep_rows); rc != AZ_OK) return rc;
+        if (deep_rows && layout == AZ_LAYOUT_TIME_MAJOR) {
+            // time-major: the rows go satellite-major into a compact scratch array (row = list slot), then one pure-memory
+            // kernel writes them out as time-major runs (k_deep_transpose)
+            const size_t per = (size_t)c->n_sdp4 * n_times * 3, words = f32 ? (per + 1) / 2 : per; // in doubles
+            if (c->d_deep_tmp.cap < words * (d_vel ? 2 : 1)) HIP_TRY(hipStreamSynchronize(c->s_deep));
+            if (c->d_deep_tmp.ensure(words * (d_vel ? 2 : 1)) != AZ_OK) return AZ_ERR_HIP;
+            PropArgs t = d;
+            t.pos = c->d_deep_tmp.p;
+            t.vel = d_vel ? c->d_deep_tmp.p + words : nullptr;
+            t.rows_compact = 1;
+            launch_propagate(t, AZ_LAYOUT_SAT_MAJOR, d_vel != nullptr, true, c->s_deep);
+            HIP_TRY(hipGetLastError());
+            a.tmp_pos = t.pos;
+            a.tmp_vel = t.vel;
+            dim3 tg((c->n_sdp4 + AZ_TR_ROWS - 1) / AZ_TR_ROWS, (n_times + 63) / 64);
+            if (tiles) { /* the tile kernel copies the scratch rows through its own tiles */ }
+            else if (f32)
+                hipLaunchKernelGGL((k_deep_transpose<float>), tg, dim3(192), 0, c->s_deep, reinterpret_cast<const float *>(t.pos),
+                                   reinterpret_cast<const float *>(t.vel), reinterpret_cast<float *>(d_pos), reinterpret_cast<float *>(d_vel),
+                                   d.list, c->n_sdp4, n_times, stride, d.mask, d.row_lo, d.row_hi);
+            else
+                hipLaunchKernelGGL((k_deep_transpose<double>), tg, dim3(192), 0, c->s_deep, t.pos, t.vel, d_pos, d_vel, d.list, c->n_sdp4,
+                                   n_times, stride, d.mask, d.row_lo, d.row_hi);
+        } else {
+            launch_propagate(d, layout, d_vel != nullptr, true, c->s_deep);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_join, c->s_deep));
     }
@@ -718,9 +773,10 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         a.n_list = c->n_sgp4;
         a.tile = auto_tile(c->n_sgp4, n_times, c->tile_sgp4, 8);
         a.tile_forced = c->tile_sgp4;
-        const bool tiles = c->tile_kernel && a.inc != nullptr && layout == AZ_LAYOUT_TIME_MAJOR && !f32 && a.mode != AZ_OUT_GEODETIC &&
-                           a.mask == nullptr && a.screen_target == nullptr && n_times >= 64 &&
-                           c->n < 5000000u; // (k_tiles_fast packs an output column, 3 n, into 24 bits)
+        // The tile kernel copies the deep-space rows out of the scratch array: they go FIRST and it follows them.  (Beside
+        // each other they would not overlap well anyway: a tile workgroup is 16 waves of 128 VGPRs and needs a whole CU's
+        // register files at once, so any small workgroup of another kernel resident on the CU keeps it out.)
+        if (tiles && fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
         if (tiles) a.list = c->d_list.p + c->off_cat; // plain catalog order; the redo items index this list
         FastShape shape;
         const bool fast = a.inc != nullptr && (tiles || use_rows(a, layout, false));
@@ -731,7 +787,9 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
             if (!tiles) a.list = c->d_list.p + c->off_circ; // [class 0 | other classes], catalog order inside each
             a.n_list = c->n_sgp4;
             a.n_circ = c->n_circ;
-            shape = tiles ? fast_shape_tiles(a, c->n_sgp4) : fast_shape_rows(a, c->n_sgp4, c->n_circ);
+            a.rowmap = c->d_list.p + c->off_rowmap;
+            a.n_rows = (unsigned)c->n;
+            shape = tiles ? fast_shape_tiles(a, (unsigned)c->n) : fast_shape_rows(a, c->n_sgp4, c->n_circ);
             if (int32_t rc = ensure_plan(c, a, shape, st); rc != AZ_OK) return rc;
         }
         if (a.n_list > 0 && tiles) launch_tiles(a, d_vel != nullptr, st, shape);
@@ -744,7 +802,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
                            c->have_mask ? c->d_mask.p : nullptr, layout, stride, f32, a.row_lo, a.row_hi);
         HIP_TRY(hipGetLastError());
     }
-    if (fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
+    if (fork && !tiles) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t1, st));
         c->timed = true;

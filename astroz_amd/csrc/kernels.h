@@ -68,7 +68,9 @@ struct PropArgs {
     const double *seeds;         // deep space: resonance state at each tile start, [tile][3][n_list]; may be null
     int mode;
     int f32; // outputs are float arrays (pos/vel point to float): fp64 arithmetic, results rounded once at the store
-    int tm_rows; // k_rows_deep only: write the time-major layout (scattered 24-byte pieces, see launch_propagate)
+    int tm_rows; // k_rows (redo pass behind the tile kernel): write this lane's 24 bytes of the time-major layout
+    int rows_compact; // k_rows_deep: the output row of a satellite is its LIST SLOT (a compact satellite-major scratch array
+                      // that k_deep_transpose turns into time-major runs), not its catalog index
     // fused single-target conjunction screen (sink instead of stores): the target's TEME track,
     // [n_times][3], NaN where the target itself failed; partial minima per (segment or tile, list slot)
     const double *screen_target;
@@ -91,12 +93,18 @@ struct PropArgs {
     unsigned *redo_items;
     // the window plan of the staged grid (k_plan_windows): per (time segment, list slot) the window constants of the fast
     // step and whether its validation bounds hold; rejected windows are items [0, *redo_static) of the redo list
+    // k_tiles_fast: tiles are 16 consecutive CATALOG rows; rowmap[s] = kind << 30 | slot (AZ_ROW_*), and the rows it does not
+    // compute itself arrive in a compact satellite-major scratch array (row = slot), see k_rows_deep / rows_compact
+    const unsigned *rowmap;
+    const double *tmp_pos, *tmp_vel;
+    unsigned n_rows;
     const double *plan_win;         // [n_seg][plan_stride][AZ_PLAN_NUM]
     const unsigned char *plan_flag; // [n_seg][plan_stride]: AZ_PLAN_OK | AZ_PLAN_TC
     unsigned plan_stride;
     const unsigned *redo_static;
     AzGrav g;
 };
+enum { AZ_ROW_NEAR = 0, AZ_ROW_COPY = 1, AZ_ROW_ZERO = 2 }; // rowmap kinds: slot = near-earth list slot | scratch row | -
 enum { AZ_PLAN_sOc, AZ_PLAN_cOc, AZ_PLAN_sdU, AZ_PLAN_cdU, AZ_PLAN_s1U, AZ_PLAN_c1U, AZ_PLAN_NUM };
 #define AZ_PLAN_OK 1u /* the fast step's validation bounds hold over this window (az_fast_window_ok) */
 #define AZ_PLAN_TC 2u /* the drag phase is expanded about the window centre (tc = tmid), else tc = 0 */
@@ -900,20 +908,25 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
     // XCD-aware tile assignment (workgroup b runs on XCD b % 8; gridDim.x is a multiple of 8): every XCD takes a contiguous
     // range of tiles, so the cache lines that two neighbouring tiles share at the ends of their 384-byte runs meet in ONE L2
     const unsigned tile_id = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const unsigned slot0 = tile_id * AZ_TILE_SATS, slot = slot0 + w;
-    if (slot0 >= p.n_list) return; // padding workgroup (uniform over the workgroup)
-    const unsigned n_valid = min((unsigned)AZ_TILE_SATS, p.n_list - slot0);
+    // A tile is 16 consecutive CATALOG rows, whatever they are: a near-earth member is computed here; a deep-space member was
+    // computed by k_rows_deep into the compact scratch array just before and is copied through (a coalesced 1.5-KB read per
+    // wave and iteration); a member whose initialisation failed is zeros.  So every tile is a run of consecutive rows and
+    // leaves as 384-byte runs even when the catalog mixes the populations in any order (round 2 tiled the near-earth LIST:
+    // with one deep-space member in ten scattered through the catalog four tiles in five fell back to 8-byte pieces).
+    const unsigned s_first = tile_id * AZ_TILE_SATS;
+    if (s_first >= p.n_rows) return; // padding workgroup (uniform over the workgroup)
+    const unsigned n_valid = min((unsigned)AZ_TILE_SATS, p.n_rows - s_first);
     const bool have = w < n_valid;
-    const unsigned s = p.list[have ? slot : slot0];
+    const unsigned s = s_first + (have ? w : 0u);
     const unsigned fl = p.flags[s];
-    const unsigned s_first = p.list[slot0];
-    // a full tile of consecutive catalog rows inside the row window leaves as 16-byte pieces (384-byte runs); any other
-    // tile -- deep-space or failed members between its rows, the end of the list, a row window cutting through it --
-    // as 8-byte pieces at per-satellite columns
-    const bool contig = n_valid == AZ_TILE_SATS && (p.list[slot0 + n_valid - 1] - s_first) == n_valid - 1 &&
-                        s_first >= p.row_lo && s_first + n_valid <= p.row_hi;
+    const unsigned rm = p.rowmap[s], kind = rm >> 30, slot = rm & 0x3fffffffu;
+    // a full tile inside the row window leaves as 16-byte pieces (384-byte runs); the last tile of the catalog and a tile a
+    // row window cuts through as 8-byte pieces at per-satellite columns
+    const bool contig = n_valid == AZ_TILE_SATS && s_first >= p.row_lo && s_first + n_valid <= p.row_hi;
     const unsigned t_lo = blockIdx.y * p.tile, t_hi = min(t_lo + p.tile, p.n_times);
-    bool dead = !(have && s >= p.row_lo && s < p.row_hi);
+    const bool in_window = have && s >= p.row_lo && s < p.row_hi;
+    bool dead = !(in_window && kind == AZ_ROW_NEAR);   // no arithmetic in this wave
+    const bool copy = in_window && kind == AZ_ROW_COPY, zero = in_window && kind == AZ_ROW_ZERO;
     if (ECEF) {
         for (unsigned j = threadIdx.x; j < t_hi - t_lo; j += 1024u) {
             gst[2 * j] = p.sin_g[t_lo + j];
@@ -963,7 +976,7 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
             } else {
                 const unsigned e = 1024u * m + tid, arr = e / 3072u, pe = e - arr * 3072u, row = pe / 48u, d = pe - row * 48u, j = d / 3u;
                 if (arr < NA && j < n_valid) {
-                    const unsigned sj = p.list[slot0 + j];
+                    const unsigned sj = s_first + j;
                     if (sj >= p.row_lo && sj < p.row_hi) {
                         lds = arr * (64u * AZ_TILE_PITCH) + row * AZ_TILE_PITCH + d;
                         rc = (row << 24) | (arr << 31) | (sj * 3u + (d - j * 3u));
@@ -975,6 +988,10 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
             f_rc[m] = rc;
         }
     }
+    // time rows that start on a 128-byte boundary (a padded out_stride_sats: 16 satellites = 384 bytes): every 384-byte run
+    // is three whole lines and leaves with the streaming hint (0.283 -> 0.270 ms); unaligned rows share their first and
+    // last line with the neighbouring tile's run, which only merge in L2 without it (0.293 against 0.355 ms with the hint)
+    const bool stream_out = ((p.stride_sats * 24u) & 127u) == 0 && ((reinterpret_cast<size_t>(p.pos) | (VEL ? reinterpret_cast<size_t>(p.vel) : 0)) & 127u) == 0;
     unsigned kiter = 0;
 #pragma unroll 1
     for (unsigned base = t_lo; base < t_hi; base += 64, ++kiter) {
@@ -1003,8 +1020,16 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
                 }
             }
         }
+        if (copy) {
+            const size_t at = ((size_t)slot * p.n_times + min(i, t_hi - 1)) * 3; // the frame is already the output's
+            r[0] = p.tmp_pos[at]; r[1] = p.tmp_pos[at + 1]; r[2] = p.tmp_pos[at + 2];
+            if (VEL) { v[0] = p.tmp_vel[at]; v[1] = p.tmp_vel[at + 1]; v[2] = p.tmp_vel[at + 2]; }
+        } else if (zero) {
+            r[0] = r[1] = r[2] = 0.0;
+            v[0] = v[1] = v[2] = 0.0;
+        }
         double *buf = tile + (kiter & 1u) * (NA * 64 * AZ_TILE_PITCH);
-        if (!dead) {
+        if (!dead || copy || zero) {
             double *q = buf + lane * AZ_TILE_PITCH + w * 3;
             q[0] = r[0]; q[1] = r[1]; q[2] = r[2];
             if (VEL) {
@@ -1021,7 +1046,8 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
             const unsigned row = (f_rc[m] >> 24) & 63u;
             if (lds == 0xffffu || base + row >= t_hi) continue;
             double *g = ((f_rc[m] >> 31) ? p.vel : p.pos) + gbase + (size_t)row * p.stride_sats * 3 + (f_rc[m] & 0xffffffu);
-            if (contig) *reinterpret_cast<az_d2s *>(g) = *reinterpret_cast<const az_d2s *>(buf + lds);
+            if (contig && stream_out) __builtin_nontemporal_store(*reinterpret_cast<const az_d2s *>(buf + lds), reinterpret_cast<az_d2s *>(g));
+            else if (contig) *reinterpret_cast<az_d2s *>(g) = *reinterpret_cast<const az_d2s *>(buf + lds);
             else g[0] = buf[lds];
         }
     }
@@ -1310,6 +1336,7 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
 #ifndef AZ_ROWSD_WAVES
 #define AZ_ROWSD_WAVES 3
 #endif
+#define AZ_DEEP_SEED_MAX 64 /* chunk seeds of one time segment staged in LDS: segments of at most 64 x 64 grid points */
 template <bool VEL, bool FRAME, int SINK>
 __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
 {
@@ -1322,57 +1349,78 @@ __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
     const unsigned s = p.list[row];
     const unsigned fl = p.flags[s];
     if (SINK != AZ_SINK_SCREEN && ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi)) return;
-    const unsigned t_lo = blockIdx.y * p.tile; // p.tile is a multiple of 64
+    const unsigned t_lo = blockIdx.y * p.tile; // p.tile is a multiple of 64 (and at most 64 * AZ_DEEP_SEED_MAX: host)
     const unsigned t_hi = min(t_lo + p.tile, p.n_times);
-    __shared__ double lds[TL + H_NUM + D_NUM];
+    __shared__ double lds[TL + H_NUM + D_NUM + 3 * AZ_DEEP_SEED_MAX];
+    double *seed_lds = lds + TL + H_NUM + D_NUM;
     int irez;
     {
         Sdp4Bcast e0{lds + TL, 0};
         az_load_sdp4(p.el, p.n_pad, s, fl, e0, ColdBroadcast{lds + TL + H_NUM});
         irez = e0.irez;
     }
+    // The loop below holds NO vector-memory load: vmcnt counts loads and stores in issue order, so a load's s_waitcnt also
+    // waits for every output store issued before it -- one load per iteration serialises the arithmetic against the write
+    // stream (round 2's loop fetched the chunk seeds and, on spills, scratch words every iteration).  The resonance
+    // states of all chunks of this segment are staged in LDS once; time is arithmetic on uniform grids and an LDS table
+    // otherwise.
+    const bool res = irez != 0; // wave-uniform
+    const unsigned n_chunks = (t_hi - t_lo + 63u) >> 6;
+    if (res && p.seeds) {
+        for (unsigned j = lane; j < 3u * n_chunks; j += 64u) {
+            const unsigned c = j / 3u, f = j - 3u * c;
+            seed_lds[j] = p.seeds[((size_t)((t_lo >> 6) + c) * 3 + f) * p.n_list + row];
+        }
+    }
     const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
+    const bool uniform = p.uniform_step != 0.0;
+    const double step = p.uniform_step, t_first = uniform ? p.times[0] + off : 0.0;
     const RotK rk = az_rotk();
-    out_t *prow = reinterpret_cast<out_t *>(p.pos) + (size_t)s * p.n_times * 3;
-    out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + (size_t)s * p.n_times * 3 : nullptr;
+    const size_t out_row = p.rows_compact ? row : s;
+    out_t *prow = reinterpret_cast<out_t *>(p.pos) + out_row * p.n_times * 3;
+    out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + out_row * p.n_times * 3 : nullptr;
     double best_d2 = __builtin_inf();
     unsigned best_t = 0xffffffffu;
     Sdp4Acc acc; // resonance accelerations of this lane's current integrator state (no state yet)
     acc.atime = __builtin_nan("");
     acc.xndt = acc.xnddt = acc.xldot = 0.0;
+    az_wave_lds_fence();
 #pragma unroll 1
     for (unsigned base = t_lo; base < t_hi; base += 64) {
         const unsigned i = base + lane;
         const bool live = i < t_hi;
-        const unsigned kk = (base - t_lo) & (TL - 1u);
-        if (kk == 0) {
-            az_wave_lds_fence();
+        double t;
+        if (uniform) {
+            t = fma((double)i, step, t_first);
+        } else {
+            const unsigned kk = (base - t_lo) & (TL - 1u);
+            if (kk == 0) {
+                az_wave_lds_fence();
 #pragma unroll
-            for (unsigned j = 0; j < TL; j += 64) lds[j + lane] = p.times[min(i + j, t_hi - 1)];
+                for (unsigned j = 0; j < TL; j += 64) lds[j + lane] = p.times[min(i + j, t_hi - 1)];
+                az_wave_lds_fence();
+            }
+            t = lds[kk + lane] + off;
         }
-        az_wave_lds_fence();
-        const double t = lds[kk + lane] + off;
-        // the constants are re-read from LDS where they are used: an opaque zero in the address keeps the
-        // compiler from hoisting 61 loop-invariant loads into 122 VGPRs
-        unsigned zero = 0;
-        asm volatile("" : "+s"(zero));
-        const Sdp4Bcast e{lds + TL + zero, irez};
-        const ColdBroadcast cold{lds + TL + H_NUM + zero};
+        // the constants are re-read from LDS where they are used: an address the compiler cannot see through keeps it
+        // from hoisting 61 loop-invariant loads into 122 VGPRs (a VGPR-held LDS address: reads are immediate offsets)
+        const double *lds_now = az_opaque_lds(lds + TL);
+        const Sdp4Bcast e{const_cast<double *>(lds_now), irez};
+        const ColdBroadcast cold{const_cast<double *>(lds_now) + H_NUM};
         Sdp4Carry cy;
-        if (p.seeds) {
-            const double *sd = p.seeds + (size_t)(base >> 6) * 3 * p.n_list + row; // wave-uniform address
+        if (res && p.seeds) {
+            const double *sd = lds_now + H_NUM + D_NUM + 3u * ((base - t_lo) >> 6); // wave-uniform address
             cy.atime = sd[0];
-            cy.xli = sd[p.n_list];
-            cy.xni = sd[2 * (size_t)p.n_list];
+            cy.xli = sd[1];
+            cy.xni = sd[2];
         } else {
             cy.atime = 0.0;
             cy.xli = e(H_xlamo);
             cy.xni = e(H_no_unkozai);
         }
         double r[3], v[3];
-        const bool res = irez != 0; // wave-uniform
         if (res) az_resonance_cached(e, cold, t, cy, acc);
-        int rc = az_sdp4_step<VEL>(e, cold, p.g, rk, t, cy, r, v, res ? &acc : nullptr);
+        int rc = az_sdp4_step_pre<VEL>(e, cold, p.g, rk, t, cy, r, v, acc);
         if (SINK == AZ_SINK_SCREEN) {
             const double *q = p.screen_target + (size_t)(live ? i : t_hi - 1) * 3;
             const double dx = q[0] - r[0], dy = q[1] - r[1], dz = q[2] - r[2];
@@ -1390,14 +1438,6 @@ __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
             if (p.err && live) p.err[(size_t)s * p.n_times + i] = (unsigned char)rc;
         }
         if (live) {
-            if (p.tm_rows) {
-                // time-major output from the lane = time kernel: each lane's 24 bytes land n_sats*24 bytes apart
-                // (plain stores: the rest of each cache line belongs to neighbouring satellites)
-                const size_t ob = ((size_t)i * p.stride_sats + s) * 3;
-                az_put3(reinterpret_cast<out_t *>(p.pos) + ob, r);
-                if (VEL) az_put3(reinterpret_cast<out_t *>(p.vel) + ob, v);
-                continue;
-            }
             az_put3_stream(prow + (size_t)i * 3, r);
             if (VEL) az_put3_stream(vrow + (size_t)i * 3, v);
         }
@@ -1407,6 +1447,56 @@ __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
         if (lane == 0) {
             p.part_d2[(size_t)blockIdx.y * p.n_list + row] = best_d2;
             p.part_t[(size_t)blockIdx.y * p.n_list + row] = best_t;
+        }
+    }
+}
+
+// Deep-space rows, TIME-major output: k_rows_deep writes its rows satellite-major into a compact scratch array (row =
+// list slot; full-line streaming stores, like the satellite-major layout) and this pure-memory kernel turns 32 list slots
+// x 64 time steps at a time into time-major rows through LDS.  When the 32 slots are consecutive catalog rows (catalogs
+// grouped by regime: the reference's own Constellation puts its deep-space members last, src/Constellation.zig L101-200)
+// every time step leaves as ONE 768-byte run; otherwise as per-satellite 24-byte pieces.  Round 2 stored those pieces
+// straight from the arithmetic kernel for every deep-space row: partial-line writes n_sats x 24 bytes apart, which also
+// halved the rate of the near-earth tile kernel running beside it (0.60 instead of 0.27 ms).
+#define AZ_TR_ROWS 32
+template <class T>
+__global__ void __launch_bounds__(192) k_deep_transpose(const T *tmp_pos, const T *tmp_vel, T *out_pos, T *out_vel, const unsigned *list,
+                                                        unsigned n_list, unsigned n_times, size_t stride_sats, const unsigned char *mask,
+                                                        unsigned row_lo, unsigned row_hi)
+{
+    constexpr unsigned PITCH = AZ_TR_ROWS * 3 + 1; // odd word pitch: conflict-free column writes
+    __shared__ T tile[64 * PITCH];
+    const unsigned slot0 = blockIdx.x * AZ_TR_ROWS, t0 = blockIdx.y * 64u;
+    const unsigned nr = min((unsigned)AZ_TR_ROWS, n_list - slot0), nt = min(64u, n_times - t0);
+    const unsigned s_first = list[slot0];
+    const bool run = list[slot0 + nr - 1] - s_first == nr - 1 && s_first >= row_lo && s_first + nr <= row_hi && mask == nullptr; // uniform
+    const int n_arr = tmp_vel ? 2 : 1;
+    // gather: thread = one of the 192 words of a slot's 64 x 3 block, the slots at a uniform stride -- 32 independent loads
+    // in flight per thread (a loop that stores each value to LDS as it arrives waits for memory 32 times over)
+    const unsigned col = threadIdx.x, tt_g = col / 3u, cp_g = col - tt_g * 3u;
+    const size_t row_words = (size_t)n_times * 3;
+    // scatter: thread = word j of the run of time step tt_s + 2 m
+    const unsigned tt_s = threadIdx.x / 96u, j_s = threadIdx.x - tt_s * 96u, rw_s = j_s / 3u, cp_s = j_s - rw_s * 3u;
+    const unsigned sj = list[min(slot0 + rw_s, n_list - 1)];
+    const bool keep = rw_s < nr && (run || (sj >= row_lo && sj < row_hi && (mask == nullptr || mask[sj] != 0)));
+    const size_t dcol = run ? (size_t)s_first * 3 + j_s : (size_t)sj * 3 + cp_s;
+    for (int arr = 0; arr < n_arr; ++arr) {
+        const T *src = (arr ? tmp_vel : tmp_pos) + ((size_t)slot0 * n_times + t0) * 3 + col;
+        T *dst = (arr ? out_vel : out_pos) + dcol;
+        T val[AZ_TR_ROWS];
+#pragma unroll
+        for (unsigned k = 0; k < AZ_TR_ROWS; ++k)
+            val[k] = (k < nr && tt_g < nt) ? __builtin_nontemporal_load(src + k * row_words) : (T)0;
+        if (arr) __syncthreads(); // the previous array has left the tile
+#pragma unroll
+        for (unsigned k = 0; k < AZ_TR_ROWS; ++k) tile[tt_g * PITCH + k * 3u + cp_g] = val[k];
+        __syncthreads();
+        if (keep) {
+#pragma unroll 8
+            for (unsigned m = 0; m < 32u; ++m) {
+                const unsigned tt = tt_s + 2u * m;
+                if (tt < nt) dst[(size_t)(t0 + tt) * stride_sats * 3] = tile[tt * PITCH + j_s];
+            }
         }
     }
 }

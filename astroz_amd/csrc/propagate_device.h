@@ -423,41 +423,67 @@ AZ_DEVICE void az_resonance_accel(const Lane &e, const Cold &cold, double xli, d
 {
     xldot = xni + e(H_xfact);
     double xndt_h = 0.0, xnddt_h = 0.0;
+    // Every phase is k xomi + m xli - G (half-day) or m (xli - fasx) (synchronous) with small integers k, m and model
+    // constants G: ONE sincos of xli (and one of xomi) and angle additions give all of them -- 2 sincos + ~90 FMA-class
+    // instructions for the ten half-day phases instead of ten sincos, 1 + ~25 instead of three for the synchronous ones.
+    // (sin,cos) of the constants are literals; sin(a - G) = sin a cos G - cos a sin G.
+    double sl, cl;
+    az_sincos(xli, sl, cl);
+    const double s2l = 2.0 * sl * cl, c2l = fma(-2.0 * sl, sl, 1.0);
     if (az_any(e.irez == 2)) {
         const double xomi = fma(e(H_argpdot), atime, e(H_argpo));
-        const double x2omi = xomi + xomi, x2li = xli + xli;
-        // ten phases, accumulated one at a time (short live ranges: the kernel is register-bound)
-        double sn, cs, acc_s = 0.0, acc_c = 0.0, acc_c2 = 0.0;
-        az_sincos(x2omi + xli - AZ_G22, sn, cs);
-        acc_s = DL(d2201) * sn; acc_c = DL(d2201) * cs;
-        az_sincos(xli - AZ_G22, sn, cs);
-        acc_s = fma(DL(d2211), sn, acc_s); acc_c = fma(DL(d2211), cs, acc_c);
-        az_sincos(xomi + xli - AZ_G32, sn, cs);
-        acc_s = fma(DL(d3210), sn, acc_s); acc_c = fma(DL(d3210), cs, acc_c);
-        az_sincos(-xomi + xli - AZ_G32, sn, cs);
-        acc_s = fma(DL(d3222), sn, acc_s); acc_c = fma(DL(d3222), cs, acc_c);
-        az_sincos(xomi + xli - AZ_G52, sn, cs);
-        acc_s = fma(DL(d5220), sn, acc_s); acc_c = fma(DL(d5220), cs, acc_c);
-        az_sincos(-xomi + xli - AZ_G52, sn, cs);
-        acc_s = fma(DL(d5232), sn, acc_s); acc_c = fma(DL(d5232), cs, acc_c);
-        az_sincos(x2omi + x2li - AZ_G44, sn, cs);
-        acc_s = fma(DL(d4410), sn, acc_s); acc_c2 = DL(d4410) * cs;
-        az_sincos(x2li - AZ_G44, sn, cs);
-        acc_s = fma(DL(d4422), sn, acc_s); acc_c2 = fma(DL(d4422), cs, acc_c2);
-        az_sincos(xomi + x2li - AZ_G54, sn, cs);
-        acc_s = fma(DL(d5421), sn, acc_s); acc_c2 = fma(DL(d5421), cs, acc_c2);
-        az_sincos(-xomi + x2li - AZ_G54, sn, cs);
-        acc_s = fma(DL(d5433), sn, acc_s); acc_c2 = fma(DL(d5433), cs, acc_c2);
+        double so, co;
+        az_sincos(xomi, so, co);
+        const double s2o = 2.0 * so * co, c2o = fma(-2.0 * so, so, 1.0);
+        double acc_s = 0.0, acc_c = 0.0, acc_c2 = 0.0;
+        // term(d, (sa, ca) = (sin,cos) of the phase without its constant, (sg, cg) = (sin,cos) G): d sin(a - G), d cos(a - G)
+#define AZ_RES_TERM(d, sa, ca, sg, cg, ACC_C)                        \
+    {                                                               \
+        const double sn = fma(sa, cg, -((ca) * (sg)));              \
+        const double cs = fma(ca, cg, (sa) * (sg));                 \
+        acc_s = fma(d, sn, acc_s);                                  \
+        ACC_C = fma(d, cs, ACC_C);                                  \
+    }
+        double sa, ca;
+        // sin/cos of the model constants (src/Sdp4.zig L15-52): G22 = 5.7686396, G32 = 0.95240898, G44 = 1.8014998,
+        // G52 = 1.0508330, G54 = 4.4108898
+        const double sG22 = -4.92139430489155261e-01, cG22 = 8.70516387529729374e-01;
+        const double sG32 = 8.14814406163892446e-01, cG32 = 5.79721901870011491e-01;
+        const double sG44 = 9.73505778018079915e-01, cG44 = -2.28662415288155479e-01;
+        const double sG52 = 8.67837401281277288e-01, cG52 = 4.96848311798841979e-01;
+        const double sG54 = -9.54892377615299992e-01, cG54 = -2.96952095753168943e-01;
+        az_angle_add(s2o, c2o, sl, cl, sa, ca);                       // 2 xomi + xli
+        AZ_RES_TERM(DL(d2201), sa, ca, sG22, cG22, acc_c)
+        AZ_RES_TERM(DL(d2211), sl, cl, sG22, cG22, acc_c)            //          xli
+        az_angle_add(so, co, sl, cl, sa, ca);                         //   xomi + xli
+        AZ_RES_TERM(DL(d3210), sa, ca, sG32, cG32, acc_c)
+        AZ_RES_TERM(DL(d5220), sa, ca, sG52, cG52, acc_c)
+        az_angle_add(-so, co, sl, cl, sa, ca);                        //  -xomi + xli
+        AZ_RES_TERM(DL(d3222), sa, ca, sG32, cG32, acc_c)
+        AZ_RES_TERM(DL(d5232), sa, ca, sG52, cG52, acc_c)
+        az_angle_add(s2o, c2o, s2l, c2l, sa, ca);                     // 2 xomi + 2 xli
+        AZ_RES_TERM(DL(d4410), sa, ca, sG44, cG44, acc_c2)
+        AZ_RES_TERM(DL(d4422), s2l, c2l, sG44, cG44, acc_c2)         //          2 xli
+        az_angle_add(so, co, s2l, c2l, sa, ca);                       //   xomi + 2 xli
+        AZ_RES_TERM(DL(d5421), sa, ca, sG54, cG54, acc_c2)
+        az_angle_add(-so, co, s2l, c2l, sa, ca);                      //  -xomi + 2 xli
+        AZ_RES_TERM(DL(d5433), sa, ca, sG54, cG54, acc_c2)
+#undef AZ_RES_TERM
         xndt_h = acc_s;
         xnddt_h = fma(2.0, acc_c2, acc_c) * xldot;
     }
     double xndt_g = 0.0, xnddt_g = 0.0;
     if (az_any(e.irez == 1)) {
-        // synchronous: phases xli - fasx2, 2(xli - fasx4), 3(xli - fasx6)
-        double s1, c1, s2, c2, s3, c3;
-        az_sincos(xli - AZ_FASX2, s1, c1);
-        az_sincos(2.0 * (xli - AZ_FASX4), s2, c2);
-        az_sincos(3.0 * (xli - AZ_FASX6), s3, c3);
+        // synchronous: phases xli - fasx2, 2 (xli - fasx4), 3 (xli - fasx6); fasx2 = 0.13130908, 2 fasx4 = 5.7686396,
+        // 3 fasx6 = 1.12344261
+        double s3l, c3l;
+        az_angle_add(s2l, c2l, sl, cl, s3l, c3l);
+        const double sF2 = 1.30932065016401006e-01, cF2 = 9.91391342684885934e-01;
+        const double sF4 = -4.92139430489155261e-01, cF4 = 8.70516387529729374e-01;
+        const double sF6 = 9.01594990166664223e-01, cF6 = 4.32581175857633338e-01;
+        const double s1 = fma(sl, cF2, -(cl * sF2)), c1 = fma(cl, cF2, sl * sF2);
+        const double s2 = fma(s2l, cF4, -(c2l * sF4)), c2 = fma(c2l, cF4, s2l * sF4);
+        const double s3 = fma(s3l, cF6, -(c3l * sF6)), c3 = fma(c3l, cF6, s3l * sF6);
         const double del1 = DL(del1), del2 = DL(del2), del3 = DL(del3);
         xndt_g = del1 * s1 + del2 * s2 + del3 * s3;
         xnddt_g = (del1 * c1 + 2.0 * del2 * c2 + 3.0 * del3 * c3) * xldot;
@@ -538,11 +564,12 @@ AZ_DEVICE void az_resonance_cached(const Lane &e, const Cold &cold, double t, Sd
 }
 
 // one deep-space propagation; returns 0 / 1 (eccentricity) / 6 (decayed) per the scalar
-// reference path (src/Sdp4.zig L914-921, L937-938, L967).  pre != nullptr: cy is already this lane's integrator state
-// for t and *pre the accelerations at it (az_resonance_cached).
-template <bool VEL, class Lane, class Cold>
-AZ_DEVICE int az_sdp4_step(const Lane &e, const Cold &cold, const AzGrav &g, const RotK &rk, double t,
-                           Sdp4Carry &cy, double r[3], double v[3], const Sdp4Acc *pre = nullptr)
+// reference path (src/Sdp4.zig L914-921, L937-938, L967).  PRE: cy is already this lane's integrator state for t and
+// `pre` the accelerations at it (az_resonance_cached); a template flag and a reference, not a nullable pointer: taking
+// the address of the caller's struct keeps it in scratch memory.
+template <bool VEL, bool PRE, class Lane, class Cold>
+AZ_DEVICE int az_sdp4_step_impl(const Lane &e, const Cold &cold, const AzGrav &g, const RotK &rk, double t,
+                                Sdp4Carry &cy, double r[3], double v[3], const Sdp4Acc &pre)
 {
     const double t2 = t * t;
     const double tempa = 1.0 - e(H_cc1) * t;
@@ -562,10 +589,10 @@ AZ_DEVICE int az_sdp4_step(const Lane &e, const Cold &cold, const AzGrav &g, con
     if (az_any(e.irez != 0)) {
         const bool res = e.irez != 0;
         double xndt, xnddt, xldot;
-        if (pre != nullptr) {
-            xndt = pre->xndt;
-            xnddt = pre->xnddt;
-            xldot = pre->xldot;
+        if (PRE) {
+            xndt = pre.xndt;
+            xnddt = pre.xnddt;
+            xldot = pre.xldot;
         } else {
             az_resonance_advance(e, cold, t, cy);
             az_resonance_accel(e, cold, cy.xli, cy.xni, cy.atime, xndt, xnddt, xldot);
@@ -636,22 +663,21 @@ AZ_DEVICE int az_sdp4_step(const Lane &e, const Cold &cold, const AzGrav &g, con
         const double sinip = sI, cosip = cI;
         const bool lyd = inclm < 0.2;
         if (az_any(lyd)) {
-            // Lyddane modification for near-equatorial orbits (own branch; the host groups such
-            // members so that most waves skip it)
+            // Lyddane modification for near-equatorial orbits (src/Sdp4.zig L731-757), in closed form.  The reference
+            // forms alfdp = sinip sin(node) + ph cos(node) + pinc cosip sin(node), betdp likewise with cos, takes
+            // node' = atan2(alfdp, betdp) on the branch nearest the old node xnoh = node mod 2 pi, and then
+            // argp' = xls + dls - mm' - cosip node'.  Rotating (betdp, alfdp) back by xnoh,
+            //      alfdp cos(xnoh) - betdp sin(xnoh) = ph,        betdp cos(xnoh) + alfdp sin(xnoh) = sinip + pinc cosip,
+            // so  node' = xnoh + delta,  delta = atan2(ph, sinip + pinc cosip)  (principal value = the nearest branch), and
+            //      argp' = argp + pgh - pinc xnoh sinip - cosip delta,          mm' = mm + pl
+            // -- no sincos of the node, one small polynomial atan2 instead of libm's.  (xnoh's VALUE in [0, 2 pi) enters
+            // the reference's dls term, hence the one explicit modulus.)
             if (lyd) {
-                double sinop, cosop;
-                az_sincos(nodem, sinop, cosop);
-                double alfdp = sinip * sinop, betdp = sinip * cosop;
-                alfdp += ph * cosop + pinc * cosip * sinop;
-                betdp += -ph * sinop + pinc * cosip * cosop;
-                nodem = az_mod2pi(nodem);
-                const double xls = mm + argpm + cosip * nodem;
-                const double dls = pl + pgh - pinc * nodem * sinip;
-                const double xnoh = nodem;
-                nodem = atan2(alfdp, betdp);
-                if (fabs(xnoh - nodem) > AZ_PI) nodem += (nodem < xnoh) ? AZ_TWOPI : -AZ_TWOPI;
+                const double xnoh = az_mod2pi(nodem);
+                const double delta = az_atan2(ph, fma(pinc, cosip, sinip));
+                argpm += pgh - pinc * xnoh * sinip - cosip * delta;
+                nodem += delta;
                 mm += pl;
-                argpm = xls + dls - mm - cosip * nodem;
             }
         }
         if (!lyd) {
@@ -694,6 +720,19 @@ AZ_DEVICE int az_sdp4_step(const Lane &e, const Cold &cold, const AzGrav &g, con
     const double mrt = az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, sO, cO, sI, cI, k, rk, r, v);
     if (rc == 0 && mrt < 1.0) rc = 6;
     return rc;
+}
+template <bool VEL, class Lane, class Cold>
+AZ_DEVICE int az_sdp4_step(const Lane &e, const Cold &cold, const AzGrav &g, const RotK &rk, double t,
+                           Sdp4Carry &cy, double r[3], double v[3])
+{
+    const Sdp4Acc none = {0.0, 0.0, 0.0, 0.0};
+    return az_sdp4_step_impl<VEL, false>(e, cold, g, rk, t, cy, r, v, none);
+}
+template <bool VEL, class Lane, class Cold>
+AZ_DEVICE int az_sdp4_step_pre(const Lane &e, const Cold &cold, const AzGrav &g, const RotK &rk, double t,
+                               Sdp4Carry &cy, double r[3], double v[3], const Sdp4Acc &acc)
+{
+    return az_sdp4_step_impl<VEL, true>(e, cold, g, rk, t, cy, r, v, acc);
 }
 #undef DL
 

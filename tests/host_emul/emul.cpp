@@ -199,7 +199,7 @@ void emul_propagate_deep_cached(const double* fields, unsigned flags, const doub
         const double before = acc.atime;
         if (e.irez != 0) az_resonance_cached(e, cold, ts[i], cy, acc);
         if (!(before == acc.atime)) ++evals;
-        int rc = az_sdp4_step<true>(e, cold, g, az_rotk(), ts[i], cy, r, v, e.irez != 0 ? &acc : nullptr);
+        int rc = az_sdp4_step_pre<true>(e, cold, g, az_rotk(), ts[i], cy, r, v, acc);
         if (rc) { r[0]=r[1]=r[2]=v[0]=v[1]=v[2]=0.0; }
         memcpy(out6 + 6*i, r, 24); memcpy(out6 + 6*i + 3, v, 24);
         rc_out[i] = rc;

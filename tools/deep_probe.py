@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from astroz_amd import _native, synth
 
+LAYOUT = _native.TIME_MAJOR if "time" in sys.argv[1:] else _native.SAT_MAJOR
+
 def run(name, el, n_times=1440, reps=10):
     pairs = synth.elements_to_pairs(el, 1)
     dev = _native.DeviceConstellation.from_tle_lines(pairs, _native.WGS72, 0)
@@ -13,11 +15,13 @@ def run(name, el, n_times=1440, reps=10):
     off = (synth.START_JD - dev.epochs) * 1440.0
     pos = torch.empty((n_times, dev.n, 3), dtype=torch.float64, device="cuda")
     vel = torch.empty_like(pos)
-    dev.propagate_device(times, off, pos.data_ptr(), vel.data_ptr())
+    dev.propagate_device(times, off, pos.data_ptr(), vel.data_ptr(), layout=LAYOUT)
     dev.synchronize()
     ms = []
+    for _ in range(5):
+        dev.propagate_device_cached(pos.data_ptr(), vel.data_ptr(), layout=LAYOUT)
     for _ in range(reps):
-        dev.propagate_device_cached(pos.data_ptr(), vel.data_ptr())
+        dev.propagate_device_cached(pos.data_ptr(), vel.data_ptr(), layout=LAYOUT)
         dev.synchronize()
         ms.append(dev.last_kernel_ms())
     print("%-10s n=%5d deep=%5d irez=%s  kernel %.3f ms  (%.2f G props/s)" % (
@@ -37,5 +41,6 @@ run("Molniya", pick((ecc > 0.59) & (mm > 1.99) & (mm < 2.02)))
 run("GTO", pick((ecc >= 0.3) & ~((mm > 1.99) & (mm < 2.02) & (ecc > 0.59))))
 run("other", pick((mm >= 3.0) & (ecc < 0.11)))
 run("mix", {k: v[:n] for k, v in base.items()})
+run("mix6064", {k: v[:6064] for k, v in base.items()})
 ne = synth.near_earth_elements(n, seed=4)
 run("near", ne)
