@@ -450,6 +450,10 @@ FastShape fast_shape_rows(const PropArgs &a, unsigned n_sgp4, unsigned n_circ)
     f.tile_c = std::min(rows_tile(n_sgp4, a.n_times, a.tile_forced), cap);
     // packed fp32 kernel: a lane carries two grid points, a wave iteration 128 (windows shorter than that -- grid
     // steps beyond ~23 minutes -- keep the fp64 kernel with rounded stores)
+    if (a.mode != AZ_OUT_TEME) { // ECEF / geodetic: a wave stages its segment's Greenwich-angle table in LDS (k_rows_fast)
+        f.tile_c = std::min(f.tile_c, (unsigned)AZ_FRAME_SEG);
+        f.tile_e = std::min(f.tile_e, (unsigned)AZ_FRAME_SEG);
+    }
     f.packed32 = a.f32 && a.mode == AZ_OUT_TEME && a.arith32 && cap >= 128u;
     if (f.packed32) f.tile_c = std::max(128u, f.tile_c / 128u * 128u);
     f.kind = f.packed32 ? 1 : 0;
@@ -459,18 +463,19 @@ FastShape fast_shape_tiles(const PropArgs &a, unsigned n_rows)
 {
     FastShape f;
     unsigned tile = std::min(rows_tile(std::max((n_rows + 15u) / 16u, 1u) * 16u, a.n_times, a.tile_forced), fast_window_cap(a.uniform_step));
-    if (a.mode == AZ_OUT_ECEF) tile = std::min(tile, (unsigned)AZ_TILE_SEG_MAX); // the Greenwich-angle table of a time segment is staged in LDS
+    if (a.mode != AZ_OUT_TEME) tile = std::min(tile, (unsigned)AZ_TILE_SEG_MAX); // the Greenwich-angle table of a time segment is staged in LDS
     f.tile_c = f.tile_e = tile;
     f.kind = 2;
     return f;
 }
 
-template <bool VEL, bool FRAME>
+template <bool VEL, int FRAME> // FRAME: 0 TEME, 1 ECEF, 2 geodetic (the generic kernels take frame / no frame and p.mode)
 void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const EccSide &side = EccSide(), const FastShape *shape = nullptr)
 {
+    constexpr bool FR = FRAME != 0;
     if (deep) {
-        if (a.f32) hipLaunchKernelGGL((k_rows_deep<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_rows_deep<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
+        if (a.f32) hipLaunchKernelGGL((k_rows_deep<VEL, FR, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_rows_deep<VEL, FR, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
     } else if (a.redo_items != nullptr && shape != nullptr) {
         // uniform grid: the branch-free kernels.  The near-circular bulk runs alone on the launch stream; beside it, on the
         // side stream, the eccentric members (few rows) and then the generic kernel over the redo list -- the windows the
@@ -483,7 +488,7 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const
         c.n_list = a.n_circ;
         e.tile = shape->tile_e;
         c.tile = shape->tile_c;
-        const bool packed32 = shape->packed32 && !FRAME;
+        const bool packed32 = shape->packed32 && !FR;
         dim3 egrid((e.n_list + 7) / 8 * 8, (a.n_times + e.tile - 1) / e.tile);
         dim3 cgrid((c.n_list + 7) / 8 * 8, (a.n_times + c.tile - 1) / c.tile);
         dim3 rgrid(256, 4);
@@ -499,8 +504,8 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const
             if (a.f32) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32, true>), egrid, dim3(64), 0, se, e);
             else hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F64, true>), egrid, dim3(64), 0, se, e);
         }
-        if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32, true>), rgrid, dim3(64), 0, se, a);
-        else hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64, true>), rgrid, dim3(64), 0, se, a);
+        if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FR, AZ_SINK_F32, true>), rgrid, dim3(64), 0, se, a);
+        else hipLaunchKernelGGL((k_rows<VEL, FR, AZ_SINK_F64, true>), rgrid, dim3(64), 0, se, a);
         if (c.n_list) {
             if (packed32) hipLaunchKernelGGL((k_rows_fast32<VEL>), cgrid, dim3(64), 0, st, c);
             else if (a.f32) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32, false>), cgrid, dim3(64), 0, st, c);
@@ -511,8 +516,8 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const
             (void)hipStreamWaitEvent(st, side.join, 0);
         }
     } else {
-        if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((k_rows<VEL, FRAME, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
+        if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FR, AZ_SINK_F32>), grid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_rows<VEL, FR, AZ_SINK_F64>), grid, dim3(64), 0, st, a);
     }
 }
 
@@ -522,14 +527,17 @@ void launch_tiles(const PropArgs &a0, bool vel, hipStream_t st, const FastShape 
 {
     PropArgs a = a0;
     a.tile = shape.tile_c;
-    const bool ecef = a.mode == AZ_OUT_ECEF;
+    const bool ecef = a.mode != AZ_OUT_TEME, geo = a.mode == AZ_OUT_GEODETIC;
     dim3 grid(((a.n_rows + 15u) / 16u + 7u) / 8u * 8u, (a.n_times + a.tile - 1) / a.tile); // tiles of 16 catalog rows
-    if (ecef) {
-        if (vel) hipLaunchKernelGGL((k_tiles_fast<true, true>), grid, dim3(1024), 0, st, a);
-        else hipLaunchKernelGGL((k_tiles_fast<false, true>), grid, dim3(1024), 0, st, a);
+    if (geo) {
+        if (vel) hipLaunchKernelGGL((k_tiles_fast<true, 2>), grid, dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((k_tiles_fast<false, 2>), grid, dim3(1024), 0, st, a);
+    } else if (ecef) {
+        if (vel) hipLaunchKernelGGL((k_tiles_fast<true, 1>), grid, dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((k_tiles_fast<false, 1>), grid, dim3(1024), 0, st, a);
     } else {
-        if (vel) hipLaunchKernelGGL((k_tiles_fast<true, false>), grid, dim3(1024), 0, st, a);
-        else hipLaunchKernelGGL((k_tiles_fast<false, false>), grid, dim3(1024), 0, st, a);
+        if (vel) hipLaunchKernelGGL((k_tiles_fast<true, 0>), grid, dim3(1024), 0, st, a);
+        else hipLaunchKernelGGL((k_tiles_fast<false, 0>), grid, dim3(1024), 0, st, a);
     }
     a.tm_rows = 1;
     dim3 rgrid(256, 4);
@@ -555,12 +563,15 @@ void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStr
         if (a.screen_target) {
             if (deep) hipLaunchKernelGGL((k_rows_deep<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);
             else hipLaunchKernelGGL((k_rows<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);
+        } else if (a.mode == AZ_OUT_GEODETIC) {
+            if (vel) launch_rows2<true, 2>(b, grid, deep, st, side, shape);
+            else launch_rows2<false, 2>(b, grid, deep, st, side, shape);
         } else if (frame) {
-            if (vel) launch_rows2<true, true>(b, grid, deep, st, side, shape);
-            else launch_rows2<false, true>(b, grid, deep, st, side, shape);
+            if (vel) launch_rows2<true, 1>(b, grid, deep, st, side, shape);
+            else launch_rows2<false, 1>(b, grid, deep, st, side, shape);
         } else {
-            if (vel) launch_rows2<true, false>(b, grid, deep, st, side, shape);
-            else launch_rows2<false, false>(b, grid, deep, st, side, shape);
+            if (vel) launch_rows2<true, 0>(b, grid, deep, st, side, shape);
+            else launch_rows2<false, 0>(b, grid, deep, st, side, shape);
         }
         return;
     }
@@ -729,7 +740,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     if (d_err) HIP_TRY(hipMemsetAsync(d_err + row_lo * (size_t)n_times, 0, (row_hi - row_lo) * (size_t)n_times, st));
     // time-major output on a uniform grid: the near-earth members take the 16-satellite tile kernel
     const bool tiles = c->n_sgp4 > 0 && c->tile_kernel && a.inc != nullptr && layout == AZ_LAYOUT_TIME_MAJOR && !f32 &&
-                       a.mode != AZ_OUT_GEODETIC && a.mask == nullptr && n_times >= 64 &&
+                       a.mask == nullptr && n_times >= 64 &&
                        c->n < 5000000u; // (k_tiles_fast packs an output column, 3 n, into 24 bits)
     const bool fork = c->n_sdp4 > 0;
     if (fork) {

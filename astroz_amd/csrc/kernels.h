@@ -798,8 +798,16 @@ __device__ __forceinline__ void az_rows_store(bool staged, bool full, bool live,
 // (near-circular Kepler form), ECC = true for the other classes (general form).  A wave whose validation vote
 // fails -- an angle outside its tier, a Newton iteration that needs more than five trips -- appends the rest of its
 // segment to the redo list and exits; the generic kernel runs that list afterwards.
-template <bool VEL, bool FRAME, int SINK, bool ECC>
-__global__ void __launch_bounds__(64, FRAME ? 2 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ_ROWSF_WAVES)) k_rows_fast(PropArgs p)
+// FRAME: 0 TEME, 1 ECEF, 2 geodetic (compile-time: the geodetic conversion's registers stay out of the ECEF kernel).  The
+// (sin,cos) of the Greenwich angle of this wave's whole segment (the host keeps FRAME segments at AZ_FRAME_SEG points)
+// are staged in LDS before the loop: no table load inside it (round 2's FRAME kernels loaded two doubles per iteration,
+// each load waiting for the stores in flight, and carried the run-time choice of ECEF / geodetic: 149-173 VGPRs + scratch).
+// The pair is NOT carried by a constant rotation although the angle is linear in time: the reference evaluates GMST from
+// jd = reference_jd + t / 1440 (src/Constellation.zig L573-581), whose rounding at 2.46e6 days moves every table entry by up
+// to 3e-9 rad -- the table, noise included, is what parity is measured against (a carried pair drifts 1e-8 rad = 85 mm).
+#define AZ_FRAME_SEG 256
+template <bool VEL, int FRAME, int SINK, bool ECC>
+__global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES : (FRAME == 1 ? 5 : AZ_ROWSF_WAVES))) k_rows_fast(PropArgs p)
 {
     typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
     const unsigned lane = threadIdx.x;
@@ -844,6 +852,16 @@ __global__ void __launch_bounds__(64, FRAME ? 2 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
         FastCarry fc;
         // seed one increment (64 grid steps) BEFORE this lane's first grid point
         az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, fc);
+        __shared__ double gst_lds[FRAME ? 2 * AZ_FRAME_SEG : 2];
+        if (FRAME) {
+#pragma unroll
+            for (unsigned j = lane; j < AZ_FRAME_SEG; j += 64) {
+                const unsigned jj = min(t_lo + j, p.n_times - 1);
+                gst_lds[2 * j] = p.sin_g[jj];
+                gst_lds[2 * j + 1] = p.cos_g[jj];
+            }
+            az_wave_lds_fence();
+        }
 #pragma unroll 1
         for (; window_ok && base < t_hi; base += 64) {
             const unsigned i = base + lane;
@@ -863,7 +881,13 @@ __global__ void __launch_bounds__(64, FRAME ? 2 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
             const bool bad = az_sgp4_fast_step<VEL, ECC>(k, p.g, rk, t, fc, r, v);
             if (az_any(bad && live)) break;
 #endif
-            if (FRAME) az_epilogue(r, v, p.mode, VEL, p.sin_g, p.cos_g, live ? i : t_hi - 1);
+            if (FRAME) {
+                const unsigned jj = (i - t_lo) & (AZ_FRAME_SEG - 1u);
+                const double sg = gst_lds[2 * jj], cg = gst_lds[2 * jj + 1];
+                az_to_ecef(r, sg, cg);
+                if (VEL) az_to_ecef(v, sg, cg);
+                if (FRAME == 2) az_ecef_to_geodetic(r);
+            }
 #if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only (every component stays live) */
             if (!(live && (r[0] + r[1] + r[2] + (VEL ? v[0] + v[1] + v[2] : 0.0)) == 1.2345e300)) continue;
 #endif
@@ -894,10 +918,11 @@ __global__ void __launch_bounds__(64, FRAME ? 2 : (ECC ? AZ_ROWSF_ECC_WAVES : AZ
 #define AZ_TILE_SATS 16
 #define AZ_TILE_SEG_MAX 1024 /* longest time segment of an ECEF launch (its Greenwich-angle table sits in LDS) */
 #define AZ_TILE_PITCH 49 /* doubles per staged time row: 48 + 1 (lane stride 98 dwords: ds_write_b64 conflict-free per half-wave) */
-template <bool VEL, bool ECEF = false>
+template <bool VEL, int FRAME = 0> // FRAME: 0 TEME, 1 ECEF, 2 geodetic positions (+ ECEF velocities)
 __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
 {
     constexpr unsigned NA = VEL ? 2u : 1u;
+    constexpr bool ECEF = FRAME != 0;
     __shared__ __attribute__((aligned(16))) double cold_all[AZ_TILE_SATS * (FC_NUM + RC_NUM)];
     __shared__ __attribute__((aligned(16))) double tile[2 * NA * 64 * AZ_TILE_PITCH];
     // ECEF output: (sin,cos) of the Greenwich angle of this segment's time steps, staged once (a load inside the loop would
@@ -1009,6 +1034,7 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
                 const double sg = gst[2 * jj], cg = gst[2 * jj + 1];
                 az_to_ecef(r, sg, cg);
                 if (VEL) az_to_ecef(v, sg, cg);
+                if (FRAME == 2) az_ecef_to_geodetic(r);
             }
             if (az_any(bad && live)) {
                 dead = true;

@@ -746,30 +746,35 @@ AZ_DEVICE void az_to_ecef(double p[3], double sg, double cg)
     p[1] = y;
 }
 
-// ECEF -> (lat rad, lon rad, alt km), WGS84; same fixed-point iteration as the reference (<= 10 trips)
+// ECEF -> (lat rad, lon rad, alt km), WGS84: the reference's fixed-point iteration lat <- atan2(z + e2 N(lat) sin lat, rho)
+// (src/WorldCoordinateSystem.zig L98-121: <= 10 trips, exit once the latitude moves by less than 1e-12), carried on the
+// (sin,cos) PAIR of the latitude -- (sin,cos) of atan2(Z, rho) is (Z, rho) / hypot(Z, rho): no atan2 and no sin inside the
+// loop -- for a fixed six trips (the map contracts by e2 = 0.0067 per trip: 3e-3 -> 3e-16, inside the reference's own exit
+// tolerance), then ONE polynomial atan2 each for the latitude and the longitude.  ~230 instructions and no branch instead
+// of libm's atan2 / sin / cos a dozen times over (~2,000).
 AZ_DEVICE void az_ecef_to_geodetic(double p[3])
 {
     const double f = 1.0 / 298.257223563;
     const double e2 = 2.0 * f - f * f;
     const double a = 6378.137;
     const double x = p[0], y = p[1], z = p[2];
-    const double lon = atan2(y, x);
-    const double rho = sqrt(x * x + y * y);
-    double lat = atan2(z, rho * (1.0 - e2));
-    bool done = false;
-#pragma unroll 1
-    for (int i = 0; i < 10; ++i) {
-        const double prev = lat;
-        const double sl = sin(lat);
-        const double N = a / sqrt(1.0 - e2 * sl * sl);
-        const double nl = atan2(z + e2 * N * sl, rho);
-        if (!done) lat = nl;
-        done = done || fabs(lat - prev) < 1e-12;
-        if (!az_any(!done)) break;
+    const double rho2 = fma(x, x, y * y);
+    const double rho = rho2 * az_rsqrt(fmax(rho2, 1.0e-300));
+    // lat0 = atan2(z, rho (1 - e2))
+    double Z = z, R = rho * (1.0 - e2);
+    double ih = az_rsqrt(fmax(fma(Z, Z, R * R), 1.0e-300));
+    double s = Z * ih, c;
+    double N = a;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        N = a * az_rsqrt(fma(-e2 * s, s, 1.0));
+        Z = fma(e2 * N, s, z);
+        ih = az_rsqrt(fmax(fma(Z, Z, rho2), 1.0e-300));
+        s = Z * ih;
     }
-    const double sl = sin(lat), cl = cos(lat);
-    const double N = a / sqrt(1.0 - e2 * sl * sl);
-    p[0] = lat;
-    p[1] = lon;
-    p[2] = rho / cl - N;
+    c = rho * ih;
+    N = a * az_rsqrt(fma(-e2 * s, s, 1.0));
+    p[0] = az_atan2(s, c);
+    p[1] = az_atan2(y, x);
+    p[2] = rho * az_rcp(fmax(c, 6.123233995736766e-17)) - N; // (cos(pi/2) in fp64, the reference's divisor on the axis)
 }

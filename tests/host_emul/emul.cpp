@@ -212,4 +212,5 @@ double emul_rcp(double x) { return az_rcp(x); }
 double emul_rsqrt(double x) { return az_rsqrt(x); }
 void emul_rotate(double* s, double* c, double d) { az_rotate(*s, *c, d, az_rotk()); }
 void emul_geodetic(double* p) { az_ecef_to_geodetic(p); }
+double emul_atan2(double y, double x) { return az_atan2(y, x); }
 }

@@ -456,3 +456,35 @@ def test_empty_and_malformed_inputs_are_rejected_before_any_device_work():
     with pytest.raises(_native.NativeError) as ei:
         _native.DeviceConstellation.from_tle_lines([("1 25544U", "2 25544")])
     assert ei.value.code == -1   # lines shorter than 69 columns (src/Tle.zig L50)
+
+
+def test_emulated_geodetic_and_atan2(emul, orc):
+    """devmath's polynomial atan2 against libm, and the pair-form ECEF -> geodetic conversion (six fixed trips of the
+    reference's fixed-point iteration, src/WorldCoordinateSystem.zig L98-121) against the oracle's restatement of it."""
+    emul.emul_atan2.restype = C.c_double
+    emul.emul_atan2.argtypes = [C.c_double, C.c_double]
+    rng = np.random.default_rng(12)
+    xs = rng.normal(size=(20000, 2)) * np.exp(rng.uniform(-20, 20, size=(20000, 1)))
+    worst = 0.0
+    for y, x in xs:
+        worst = max(worst, abs(emul.emul_atan2(y, x) - np.arctan2(y, x)))
+    for y, x in [(0.0, 1.0), (0.0, -1.0), (1.0, 0.0), (-1.0, 0.0), (1.0, 1.0), (-1.0, -1.0), (1e-300, -1.0), (0.0, 0.0)]:
+        worst = max(worst, abs(emul.emul_atan2(y, x) - np.arctan2(y, x)))
+    assert worst < 1e-15, worst
+    emul.emul_geodetic.argtypes = [C.c_void_p]
+    L = orc.lib()
+    L.orc_ecef_to_geodetic.argtypes = [C.c_void_p, C.c_void_p]
+    dl = da = 0.0
+    for _ in range(20000):
+        r = rng.uniform(6400.0, 45000.0)
+        v = rng.normal(size=3)
+        e = r * v / np.linalg.norm(v)
+        if rng.random() < 0.05:
+            e[:2] *= 1e-4          # near the axis
+        q = e.copy()
+        emul.emul_geodetic(q.ctypes.data)
+        ref = np.zeros(3)
+        L.orc_ecef_to_geodetic(e.ctypes.data, ref.ctypes.data)
+        dl = max(dl, abs(q[0] - ref[0]), abs((q[1] - ref[1] + np.pi) % (2 * np.pi) - np.pi))
+        da = max(da, abs(q[2] - ref[2]) / max(1.0, abs(ref[2]) / 1e4))
+    assert dl < 2e-13 and da < 1e-6, (dl, da)
