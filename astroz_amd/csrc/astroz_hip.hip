@@ -441,13 +441,11 @@ FastShape fast_shape_rows(const PropArgs &a, unsigned n_sgp4, unsigned n_circ)
     FastShape f;
     const unsigned cap = fast_window_cap(a.uniform_step);
     const unsigned n_ecc = n_sgp4 - n_circ;
-    // eccentric members: few rows, finer time segments so that they still fill the chip when they run alone
-    f.tile_e = std::min(rows_tile(std::max(n_ecc, 1u), a.n_times, 256), cap);
-    if (const char *ev = getenv("AZ_TILE_E")) { // tuning experiment
-        const unsigned v = (unsigned)atoi(ev);
-        if (v >= 64) f.tile_e = std::min(v / 64u * 64u, cap);
-    }
     f.tile_c = std::min(rows_tile(n_sgp4, a.n_times, a.tile_forced), cap);
+    // eccentric members: few rows.  Beside a bulk launch four times their size they take its segment length (their waves
+    // fill in wherever the bulk leaves room; fewer, longer segments = fewer seed sincos); on their own, finer time segments
+    // so that they still fill the chip
+    f.tile_e = n_circ >= 4u * n_ecc ? f.tile_c : std::min(rows_tile(std::max(n_ecc, 1u), a.n_times, 256), cap);
     // packed fp32 kernel: a lane carries two grid points, a wave iteration 128 (windows shorter than that -- grid
     // steps beyond ~23 minutes -- keep the fp64 kernel with rounded stores)
     if (a.mode != AZ_OUT_TEME) { // ECEF / geodetic: a wave stages its segment's Greenwich-angle table in LDS (k_rows_fast)

@@ -55,6 +55,9 @@ def parse_args():
                     help="fp32 OUTPUT arrays (BASELINE config 5); the arithmetic stays fp64")
     ap.add_argument("--layout", choices=["time", "sat"], default="sat",
                     help="physical output layout: sat = (n_sats, n_times, 3) [default], time = (n_times, n_sats, 3)")
+    ap.add_argument("--mode", choices=["teme", "ecef", "geodetic"], default="teme",
+                    help="output frame (SURVEY 8 f1): teme [default, BASELINE.json], ecef (the default of the reference's high-level "
+                         "propagate(), Constellation.zig L489-506), geodetic (lat rad, lon rad, alt km; velocities stay ECEF)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="N > 1: strong = one 13,478-satellite catalog sharded over the ranks (BASELINE config 4, default); "
                          "weak = every rank its own catalog, no gather")
@@ -412,7 +415,9 @@ def main():
     odt = torch.float32 if a.f32_out else torch.float64
     sharded = (world > 1 or a.force_sharded) and a.scaling == "strong"      # BASELINE config 4
     gather = sharded and not a.no_gather
-    if sharded and (a.layout != "sat" or a.f32_out):
+    mode = {"teme": 0, "ecef": 1, "geodetic": 2}[a.mode]
+    ref_jd = 0.0   # set with the workload (synth.START_JD) once the package is imported
+    if sharded and (a.layout != "sat" or a.f32_out or mode):
         raise SystemExit("bench.py: the sharded (config 4) path is satellite-major fp64; use --scaling weak for other variants")
 
     # ---- workload -------------------------------------------------------------------------
@@ -471,7 +476,9 @@ def main():
     torch.cuda.synchronize()
 
     # stage inputs (times, offsets) once; this call also runs the kernels (counts as warm-up)
-    dev.propagate_device(times, offsets, p_ptr, v_ptr, layout=layout, stride=stride, stream=sptr, f32=a.f32_out)
+    ref_jd = synth.START_JD
+    dev.propagate_device(times, offsets, p_ptr, v_ptr, mode=mode, reference_jd=ref_jd, layout=layout, stride=stride, stream=sptr,
+                         f32=a.f32_out)
     torch.cuda.synchronize()
     last_kernel_ms = dev.last_kernel_ms()   # the library's own hipEvent pair around that launch
     dev.set_timing(False)                    # the timed loop below is bracketed by events of its own
@@ -598,8 +605,11 @@ def main():
     valu_issue = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+        # (the fingerprint was written on the GPU box by tools/profile_run.py when the counters were collected; a file
+        # measured on other sources is not reported)
         if (pm.get("csrc_sha16") == csrc_fingerprint() and world == 1 and layout == _native.SAT_MAJOR and vel_on and
-                a.sats == 13478 and n_times == 1440 and not a.deep and not a.f32_out and not a.no_fast_path):
+                a.sats == 13478 and n_times == 1440 and not a.deep and not a.f32_out and not a.no_fast_path and mode == 0):
+            pm = pm.get("step", pm)     # tools/profile_run.py keeps the step totals under "step"
             traffic = pm["hbm_bytes_per_launch"]
             if pm.get("valu_wave_insts_per_launch"):
                 # VALU issue-slot utilisation of the step: one wave instruction occupies its SIMD's issue port for 4 cycles
@@ -633,8 +643,8 @@ def main():
         par = "independent catalogs x%d, no data-path collective" % world
     arith = "fp64 arithmetic" if not a.f32_out or not a.f32_arith or a.no_fast_path or layout != _native.SAT_MAJOR else \
         "fp32 arithmetic with fp64 phase and radius chains (near-circular members; fp64 for the rest)"
-    wl += ", %s, %s TEME %s, %s-major device-resident output" % (
-        arith, "fp32-stored" if a.f32_out else "fp64", "pos+vel" if vel_on else "pos only", a.layout)
+    wl += ", %s, %s %s %s, %s-major device-resident output" % (
+        arith, "fp32-stored" if a.f32_out else "fp64", a.mode.upper(), "pos+vel" if vel_on else "pos only", a.layout)
     if layout == _native.SAT_MAJOR:
         kname = ("k_rows_fast<%s> (branch-free uniform-grid step, one wave per satellite row, lane = time) + k_rows redo pass"
                  if not a.no_fast_path else "k_rows<%s> (one wave per satellite row, lane = time)") % ("pos+vel" if vel_on else "pos")
@@ -713,7 +723,7 @@ def main():
                 out["parity"]["max_abs_dv_kms"] = float(np.abs(full[1][idx].cpu().numpy() - v0).max())
         except Exception as exc:
             out["parity"] = {"failed": repr(exc)}
-    elif world == 1 and not a.no_cpu_baseline:
+    elif world == 1 and not a.no_cpu_baseline and mode == 0:
         try:
             cb, (n_s, p0, v0) = cpu_baseline(pairs, times, offsets, a.cpu_seconds, layout == _native.SAT_MAJOR)
             out["cpu_baseline"] = cb
@@ -724,8 +734,26 @@ def main():
         except Exception as exc:  # the baseline must never take the bench line down
             out["cpu_baseline"] = {"value": None, "unit": "propagations/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (exc,)}
+    if world == 1 and mode != 0 and not a.config5_share and "parity" not in out:
+        try:
+            from oracle import oracle
+            rows = _sample_rows(n_local, 16)
+            cat = oracle.Catalog.from_pairs([pairs[i] for i in rows], oracle.WGS72)
+            _, p0, v0 = cat.propagate(times, offsets[rows], mode=mode, reference_jd=ref_jd, layout=oracle.SAT_MAJOR, threads=usable_cpus())
+            idx = torch.as_tensor(rows, device=cuda)
+            gp = (pos[:, idx].permute(1, 0, 2) if layout == _native.TIME_MAJOR else pos[idx]).cpu().numpy().astype(np.float64)
+            d = gp - p0
+            if mode == 2:
+                d[..., 1] = (d[..., 1] + np.pi) % (2 * np.pi) - np.pi
+            out["parity"] = {"sample_sats": int(len(rows)), "max_abs_dpos": float(np.abs(d).max()),
+                             "units": "km" if mode == 1 else "rad, rad, km"}
+            if vel_on:
+                gv = (vel[:, idx].permute(1, 0, 2) if layout == _native.TIME_MAJOR else vel[idx]).cpu().numpy().astype(np.float64)
+                out["parity"]["max_abs_dv_kms"] = float(np.abs(gv - v0).max())
+        except Exception as exc:
+            out["parity"] = {"failed": repr(exc)}
     default_workload = (world == 1 and not sharded and not a.config5_share and a.sats == 13478 and n_times == 1440 and not a.deep and
-                        vel_on and not a.f32_out and a.layout == "sat" and not a.no_fast_path and not a.tile)
+                        vel_on and not a.f32_out and a.layout == "sat" and not a.no_fast_path and not a.tile and mode == 0)
     if default_workload and not a.no_secondary:
         try:
             out["secondary"] = run_secondary(torch, _native, synth, cuda, stream, dev, pairs,
