@@ -422,6 +422,7 @@ struct EccSide {
     hipEvent_t fork = nullptr, join = nullptr;
 };
 
+inline unsigned cgrid_y(unsigned n_times, unsigned tile) { return (n_times + tile - 1) / tile; }
 // launch shape of the fast kernels on a uniform grid: time-segment lengths of the near-circular and the eccentric launch,
 // which kernel family (= which window plan: 0 rows, 1 packed fp32 rows, 2 time-major tiles)
 struct FastShape {
@@ -489,7 +490,9 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const
         const bool packed32 = shape->packed32 && !FR;
         dim3 egrid((e.n_list + 7) / 8 * 8, (a.n_times + e.tile - 1) / e.tile);
         dim3 cgrid((c.n_list + 7) / 8 * 8, (a.n_times + c.tile - 1) / c.tile);
-        dim3 rgrid(256, 4);
+        // the generic pass: every workgroup takes items b, b + gridDim.x, ... and a quarter of each; enough workgroups that a
+        // large catalog's rejected windows (1 % of 125,000 x 14 segments in config 5's share) do not queue up behind 1,024 waves
+        dim3 rgrid(std::min(8192u, std::max(256u, (a.n_list * cgrid_y(a.n_times, shape->tile_c) + 63u) / 64u)), 4);
         // redo items carry (list slot, first, end): slots of the eccentric launch are offset into the common list
         e.redo_slot0 = a.n_circ;
         const bool beside = side.stream != nullptr && c.n_list;
@@ -645,7 +648,9 @@ int32_t prepare_deep(azh_constellation *c, PropArgs &d, hipStream_t st, bool row
     d.list = c->d_list.p + (rows ? c->off_deep_cat : c->n_sgp4); // lane = time: catalog order; lane = satellite: grouped by branch
     d.n_list = c->n_sdp4;
     d.tile = auto_tile(c->n_sdp4, n_times, c->tile_sdp4, 8);
-    d.tile_forced = c->tile_sdp4;
+    // beside a near-earth launch four times their size the deep-space rows take its segment length (fewer waves, fewer
+    // set-ups; the chip is full either way); on their own, the finer automatic segments
+    d.tile_forced = c->tile_sdp4 ? c->tile_sdp4 : (rows && c->n_sgp4 >= 4u * c->n_sdp4 ? rows_tile(c->n_sgp4, n_times, c->tile_sgp4) : 0u);
     // lane = time kernel: one state per 64-point chunk, taken at the chunk's grid point nearest to epoch
     const unsigned seed_tile = rows ? 64u : d.tile;
     const unsigned n_tiles = (n_times + seed_tile - 1) / seed_tile;
@@ -739,7 +744,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     // time-major output on a uniform grid: the near-earth members take the 16-satellite tile kernel
     const bool tiles = c->n_sgp4 > 0 && c->tile_kernel && a.inc != nullptr && layout == AZ_LAYOUT_TIME_MAJOR && !f32 &&
                        a.mask == nullptr && n_times >= 64 &&
-                       c->n < 5000000u; // (k_tiles_fast packs an output column, 3 n, into 24 bits)
+                       (size_t)stride * 64 * 24 < 0xf0000000ull; // (k_tiles_fast: 32-bit byte offsets inside a block of 64 time rows)
     const bool fork = c->n_sdp4 > 0;
     if (fork) {
         // deep-space rows on their own stream, concurrent with the near-earth launch

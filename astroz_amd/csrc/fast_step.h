@@ -172,13 +172,16 @@ AZ_DEVICE void az_rot_apply2(double &s, double &c, double p, double q)
 // where it likes: lane = satellite kernels, host emulation) or LDS words read by all lanes at once.  v_fma_f64
 // takes no 64-bit literal and one scalar operand, so a Horner chain's constants otherwise end up parked in VGPRs
 // for the whole loop -- 8 coefficients = 16 VGPRs, a sixth wave per SIMD in k_rows_fast.
-enum RotCoef { RC_n6, RC_p24, RC_p120, RC_n720, RC_n5040, RC_p40320, RC_p362880, RC_n3628800, RC_p8, RC_NUM };
+enum RotCoef { RC_n6, RC_p24, RC_p120, RC_n720, RC_n5040, RC_p40320, RC_p362880, RC_n3628800, RC_p8,
+               RC_n11f, RC_p12f, RC_p13f, RC_n14f, RC_n15f, RC_p16f, RC_NUM }; // ... -1/11!, 1/12!, 1/13!, -1/14!, -1/15!, 1/16!
 struct RotCoefLit {
     AZ_MEMBER double operator()(int k) const
     {
         return k == RC_n6 ? -1.0 / 6.0 : k == RC_p24 ? 1.0 / 24.0 : k == RC_p120 ? 1.0 / 120.0 : k == RC_n720 ? -1.0 / 720.0
              : k == RC_n5040 ? -1.0 / 5040.0 : k == RC_p40320 ? 1.0 / 40320.0 : k == RC_p362880 ? 1.0 / 362880.0
-             : k == RC_n3628800 ? -1.0 / 3628800.0 : 0.125;
+             : k == RC_n3628800 ? -1.0 / 3628800.0 : k == RC_p8 ? 0.125
+             : k == RC_n11f ? -1.0 / 39916800.0 : k == RC_p12f ? 1.0 / 479001600.0 : k == RC_p13f ? 1.0 / 6227020800.0
+             : k == RC_n14f ? -1.0 / 87178291200.0 : k == RC_n15f ? -1.0 / 1307674368000.0 : 1.0 / 20922789888000.0;
     }
 };
 struct RotCoefLds {
@@ -220,6 +223,28 @@ AZ_DEVICE void az_pq_16th(double d, const RC &k, double &p, double &q)
     const double d2 = d * d;
     q = d2 * fma(d2, fma(d2, fma(d2, k(RC_p40320), k(RC_n720)), k(RC_p24)), -0.5);
     p = d * fma(d2, fma(d2, fma(d2, k(RC_n5040), k(RC_p120)), k(RC_n6)), 1.0);
+}
+
+// (p,q) for |d| <= 1/2: sin to d^15, cos to d^16 (the polynomial of az_rotate_large, truncation 0.5^17/17! = 2e-20), the
+// coefficients through the accessor: fifteen 64-bit literals otherwise sit in VGPR pairs across the whole loop
+template <class RC>
+AZ_DEVICE void az_pq_large(double d, const RC &k, double &p, double &q)
+{
+    const double d2 = d * d;
+    q = fma(d2, k(RC_p16f), k(RC_n14f));
+    q = fma(d2, q, k(RC_p12f));
+    q = fma(d2, q, k(RC_n3628800));
+    q = fma(d2, q, k(RC_p40320));
+    q = fma(d2, q, k(RC_n720));
+    q = fma(d2, q, k(RC_p24));
+    q = d2 * fma(d2, q, -0.5);
+    p = fma(d2, k(RC_n15f), k(RC_p13f));
+    p = fma(d2, p, k(RC_n11f));
+    p = fma(d2, p, k(RC_p362880));
+    p = fma(d2, p, k(RC_n5040));
+    p = fma(d2, p, k(RC_p120));
+    p = fma(d2, p, k(RC_n6));
+    p = d * fma(d2, p, 1.0);
 }
 
 // (p,q) for |d| <= 1/8: sin to d^9, cos to d^10 (the polynomial of az_rotate_med).  Used for the rest of the
@@ -411,7 +436,8 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, doub
             eps += d;
             if (it == 0) {
                 bad |= !(fabs(d) <= 0.5);
-                az_rotate_large(s, c, d);
+                az_pq_large(d, rk, p, q);
+                az_rot_apply2(s, c, p, q);
             } else if (it == 1) {
                 bad |= !(fabs(d) <= AZ_ROT_MED);
                 az_pq_med(d, rk, p, q);

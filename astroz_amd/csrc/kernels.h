@@ -980,38 +980,18 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
         az_wave_lds_fence();
         az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, fc);
     }
-    // This thread's share of a tile flush, fixed for the whole kernel.  contig: pieces q = 1024 m + tid, m < 3, of the
-    // 3,072 sixteen-byte pieces (positions: 64 rows x 24, then velocities); otherwise doubles e = 1024 m + tid, m < 6, of
-    // the 6,144.  Per entry: the LDS word (16 bits, 0xffff = nothing to store) and (velocities << 31 | time row << 24 |
-    // output column); the host keeps 3 n below 2^24.
-    unsigned f_lds[3], f_rc[6];
-    {
-        const unsigned tid = threadIdx.x;
+    // This thread's share of a tile flush, fixed for the whole kernel: pieces q = 1024 m + tid, m < 3, of the 3,072
+    // sixteen-byte pieces of a full tile (positions: 64 time rows x 24 pieces, then velocities).  Per piece the LDS byte
+    // offset inside a tile buffer, the output pointer of time row 0 of the CURRENT iteration's block minus that block's
+    // offset (a uniform 64-bit add per iteration turns it into the address), and the time row (partial last iteration).
+    unsigned f_lds[3], f_out[3], f_row = 0; // (f_out: byte offset of the piece inside the iteration's block of 64 time rows;
+                                            // the host keeps 64 rows x stride x 24 bytes below 4 GB)
 #pragma unroll
-        for (unsigned m = 0; m < 6; ++m) {
-            unsigned lds = 0xffffu, rc = 0;
-            if (contig) {
-                if (m < 3) {
-                    const unsigned q = 1024u * m + tid, arr = q / 1536u, pq = q - arr * 1536u, row = pq / 24u, col = pq - row * 24u;
-                    if (arr < NA) {
-                        lds = arr * (64u * AZ_TILE_PITCH) + row * AZ_TILE_PITCH + col * 2u;
-                        rc = (row << 24) | (arr << 31) | (s_first * 3u + col * 2u);
-                    }
-                }
-            } else {
-                const unsigned e = 1024u * m + tid, arr = e / 3072u, pe = e - arr * 3072u, row = pe / 48u, d = pe - row * 48u, j = d / 3u;
-                if (arr < NA && j < n_valid) {
-                    const unsigned sj = s_first + j;
-                    if (sj >= p.row_lo && sj < p.row_hi) {
-                        lds = arr * (64u * AZ_TILE_PITCH) + row * AZ_TILE_PITCH + d;
-                        rc = (row << 24) | (arr << 31) | (sj * 3u + (d - j * 3u));
-                    }
-                }
-            }
-            if (m & 1u) f_lds[m >> 1] |= lds << 16;
-            else f_lds[m >> 1] = lds;
-            f_rc[m] = rc;
-        }
+    for (unsigned m = 0; m < 3; ++m) {
+        const unsigned q = 1024u * m + threadIdx.x, arr = q / 1536u, pq = q - arr * 1536u, row = pq / 24u, col = pq - row * 24u;
+        f_lds[m] = arr < NA ? (arr * (64u * AZ_TILE_PITCH) + row * AZ_TILE_PITCH + col * 2u) * 8u : 0xffffffffu;
+        f_out[m] = (unsigned)(((size_t)row * p.stride_sats + s_first) * 24u + col * 16u);
+        f_row |= (row | (arr << 7)) << (8u * m);
     }
     // time rows that start on a 128-byte boundary (a padded out_stride_sats: 16 satellites = 384 bytes): every 384-byte run
     // is three whole lines and leaves with the streaming hint (0.283 -> 0.270 ms); unaligned rows share their first and
@@ -1064,17 +1044,28 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
             }
         }
         __syncthreads();
-        const size_t gbase = (size_t)base * p.stride_sats * 3;
+        const size_t gbase = (size_t)base * p.stride_sats * 3; // uniform
+        const bool full = base + 64 <= t_hi;
+        if (contig) {
+            const char *bufc = reinterpret_cast<const char *>(buf);
+            char *pos_b = reinterpret_cast<char *>(p.pos + gbase), *vel_b = VEL ? reinterpret_cast<char *>(p.vel + gbase) : nullptr; // uniform
 #pragma unroll
-        for (unsigned m = 0; m < 6; ++m) {
-            if (contig && m >= 3) break;
-            const unsigned lds = (f_lds[m >> 1] >> ((m & 1u) * 16u)) & 0xffffu;
-            const unsigned row = (f_rc[m] >> 24) & 63u;
-            if (lds == 0xffffu || base + row >= t_hi) continue;
-            double *g = ((f_rc[m] >> 31) ? p.vel : p.pos) + gbase + (size_t)row * p.stride_sats * 3 + (f_rc[m] & 0xffffffu);
-            if (contig && stream_out) __builtin_nontemporal_store(*reinterpret_cast<const az_d2s *>(buf + lds), reinterpret_cast<az_d2s *>(g));
-            else if (contig) *reinterpret_cast<az_d2s *>(g) = *reinterpret_cast<const az_d2s *>(buf + lds);
-            else g[0] = buf[lds];
+            for (unsigned m = 0; m < 3; ++m) {
+                if (f_lds[m] == 0xffffffffu || (!full && base + ((f_row >> (8u * m)) & 63u) >= t_hi)) continue;
+                const az_d2s val = *reinterpret_cast<const az_d2s *>(bufc + f_lds[m]);
+                az_d2s *g = reinterpret_cast<az_d2s *>((((f_row >> (8u * m)) & 128u) ? vel_b : pos_b) + f_out[m]);
+                if (stream_out) __builtin_nontemporal_store(val, g);
+                else *g = val;
+            }
+        } else {
+            // the last tile of the catalog / a tile a row window cuts through: 8-byte pieces at per-satellite columns,
+            // addresses worked out on the spot (rare)
+            for (unsigned e = threadIdx.x; e < NA * 3072u; e += 1024u) {
+                const unsigned arr = e / 3072u, pe = e - arr * 3072u, row = pe / 48u, d = pe - row * 48u, j = d / 3u;
+                const unsigned sj = s_first + j;
+                if (j >= n_valid || sj < p.row_lo || sj >= p.row_hi || base + row >= t_hi) continue;
+                ((arr ? p.vel : p.pos) + gbase + ((size_t)row * p.stride_sats + s_first) * 3)[d] = buf[arr * (64u * AZ_TILE_PITCH) + row * AZ_TILE_PITCH + d];
+            }
         }
     }
 }
