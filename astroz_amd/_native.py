@@ -36,6 +36,7 @@ EXPORTS = [
     "azh_group_create_from_tle_text", "azh_group_create_from_omm_json", "azh_group_free", "azh_group_num_satellites",
     "azh_group_num_devices", "azh_group_padded_rows", "azh_group_get_epochs", "azh_group_propagate_host",
     "azh_group_propagate_allgather", "coords_eci_to_ecef", "coords_ecef_to_geodetic",
+    "orbital_hohmann", "orbital_velocity", "orbital_period", "orbital_escape_velocity",
 ]
 
 
@@ -197,6 +198,11 @@ def lib():
     L.azh_coarse_screen_host.restype = i32
     L.azh_screen_all_host.argtypes = [vp, vp, sz, vp, dbl, vp, vp, sz, C.POINTER(sz)]
     L.azh_screen_all_host.restype = i32
+    L.orbital_hohmann.argtypes = [dbl, dbl, dbl, vp]
+    L.orbital_hohmann.restype = i32
+    for f, n in (("orbital_velocity", 3), ("orbital_period", 2), ("orbital_escape_velocity", 2)):
+        getattr(L, f).argtypes = [dbl] * n
+        getattr(L, f).restype = dbl
     _lib = L
     return L
 

@@ -1884,22 +1884,60 @@ int32_t sgp4_propagate_batch(void *h, const double *times, double *results, uint
 // az_to_ecef, az_ecef_to_geodetic) -- no host-side floating point.  A round trip to the GPU per call (~25 us):
 // loops belong in azh_propagate_*'s output modes.  Without a device the outputs are NaN.
 namespace {
-int32_t coords_call(int op, const double in[4], double out[3])
+int32_t coords_call(int op, const double in[4], double *out, int n_out = 3)
 {
     static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
     static double *d_buf = nullptr;
     const double nan = std::nan("");
-    out[0] = out[1] = out[2] = nan;
+    for (int i = 0; i < n_out; ++i) out[i] = nan;
     if (!hip_ok(hipSetDevice(0), "hipSetDevice")) return AZ_ERR_HIP;
-    if (!d_buf && !hip_ok(hipMalloc((void **)&d_buf, sizeof(double) * 8), "hipMalloc")) return AZ_ERR_HIP;
+    if (!d_buf && !hip_ok(hipMalloc((void **)&d_buf, sizeof(double) * 12), "hipMalloc")) return AZ_ERR_HIP;
     HIP_TRY(hipMemcpy(d_buf, in, sizeof(double) * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_coords, dim3(1), dim3(64), 0, nullptr, op, d_buf, d_buf + 4);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, d_buf + 4, sizeof(double) * 3, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d_buf + 4, sizeof(double) * n_out, hipMemcpyDeviceToHost));
     return AZ_OK;
 }
 } // namespace
+
+// orbital_* (src/c_api/root.zig L60-71 over src/c_api/orbital_mechanics.zig): four closed-form scalars a link-time client of
+// libastroz_c.so resolves; evaluated on the device like coords_* (no host-side floating point: NaN / AZ_ERR_HIP without one)
+int32_t orbital_hohmann(double mu, double r1, double r2, azh_hohmann_result *out)
+{
+    if (!out) return AZ_ERR_NULL_POINTER;
+    if (r1 <= 0 || r2 <= 0 || std::fabs(r1 - r2) < 1000) return AZ_ERR_VALUE;
+    const double in[4] = {mu, r1, r2, 0};
+    double o[5];
+    const int32_t rc = coords_call(4, in, o, 5);
+    out->semi_major_axis = o[0]; out->delta_v1 = o[1]; out->delta_v2 = o[2]; out->total_delta_v = o[3];
+    out->transfer_time = o[4]; out->transfer_time_days = o[4] / 86400.0;
+    return rc;
+}
+double orbital_velocity(double mu, double radius, double sma)
+{
+    if (radius <= 0 || sma < 0) return -1.0;
+    const double in[4] = {mu, radius, sma, 0};
+    double o[3];
+    (void)coords_call(3, in, o);
+    return o[0];
+}
+double orbital_period(double mu, double sma)
+{
+    if (sma <= 0) return -1.0;
+    const double in[4] = {mu, 1.0, sma, 0};
+    double o[3];
+    (void)coords_call(3, in, o);
+    return o[1];
+}
+double orbital_escape_velocity(double mu, double radius)
+{
+    if (radius <= 0) return -1.0;
+    const double in[4] = {mu, radius, 0, 0};
+    double o[3];
+    (void)coords_call(3, in, o);
+    return o[2];
+}
 
 double coords_julian_to_gmst(double jd)
 {

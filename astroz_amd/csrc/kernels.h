@@ -1719,8 +1719,9 @@ __global__ void __launch_bounds__(256) k_prep_inc(const double *el, size_t n, si
     }
 }
 
-// scalar coordinate helpers of the c_api (coords_*, src/c_api/coordinates.zig): op 0 julianToGmst(in[0]),
-// op 1 eciToEcefGmst(in[0..3), gmst = in[3]), op 2 ecefToGeodeticDeg(in[0..3)) [lat deg, lon deg, alt km]
+// scalar helpers of the c_api (coords_*, src/c_api/coordinates.zig; orbital_*, src/c_api/orbital_mechanics.zig over
+// src/calculations.zig L83-125): op 0 julianToGmst(in[0]), op 1 eciToEcefGmst(in[0..3), gmst = in[3]), op 2
+// ecefToGeodeticDeg(in[0..3)) [lat deg, lon deg, alt km], op 3 velocity / period / escape velocity, op 4 Hohmann transfer
 __global__ void k_coords(int op, const double *in, double *out)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1736,10 +1737,22 @@ __global__ void k_coords(int op, const double *in, double *out)
         double r[3] = {in[0], in[1], in[2]};
         az_to_ecef(r, sin(in[3]), cos(in[3]));
         out[0] = r[0]; out[1] = r[1]; out[2] = r[2];
-    } else {
+    } else if (op == 2) {
         double r[3] = {in[0], in[1], in[2]};
         az_ecef_to_geodetic(r);
         out[0] = r[0] * (180.0 / AZ_PI); out[1] = r[1] * (180.0 / AZ_PI); out[2] = r[2];
+    } else if (op == 3) {
+        // orbital_velocity (vis-viva; sma = 0: circular), orbital_period, orbital_escape_velocity: in = mu, radius, sma
+        const double mu = in[0], r = in[1], a = in[2];
+        out[0] = sqrt(a != 0.0 ? mu * (2.0 / r - 1.0 / a) : mu / r);
+        out[1] = 2.0 * AZ_PI * sqrt(a * a * a / mu);
+        out[2] = sqrt(2.0 * mu / r);
+    } else {
+        // orbital_hohmann between circular orbits r1 -> r2: in = mu, r1, r2; out = sma, dv1, dv2, |dv1| + |dv2|, transfer time s
+        const double mu = in[0], r1 = in[1], r2 = in[2];
+        const double sma = 0.5 * (r1 + r2), v1c = sqrt(mu / r1), v2c = sqrt(mu / r2);
+        const double dv1 = v1c * sqrt(2.0 * r2 / (r1 + r2)) - v1c, dv2 = v2c - v2c * sqrt(2.0 * r1 / (r1 + r2));
+        out[0] = sma; out[1] = dv1; out[2] = dv2; out[3] = fabs(dv1) + fabs(dv2); out[4] = AZ_PI * sqrt(sma * sma * sma / mu);
     }
 }
 

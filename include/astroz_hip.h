@@ -83,11 +83,23 @@ int32_t sgp4_propagate_batch(void *handle, const double *times_min, double *resu
 /* root.zig L73-81 / src/c_api/coordinates.zig: the output-mode math of this path (WorldCoordinateSystem.zig
  * L87-154) as scalar calls.  gmst in radians; lla = (lat deg, lon deg, alt km), degrees like the reference's
  * ecefToGeodeticDeg.  Each call is one tiny launch on device 0 (the same device functions as the kernels'
- * ECEF / geodetic epilogue); without a device the outputs are NaN.  orbital_* (root.zig L60-71: Hohmann,
- * vis-viva helpers) are not on the propagation path and are not exported. */
+ * ECEF / geodetic epilogue); without a device the outputs are NaN. */
 double coords_julian_to_gmst(double jd);
 void coords_eci_to_ecef(const double eci[3], double gmst, double ecef[3]);
 void coords_ecef_to_geodetic(const double ecef[3], double lla[3]);
+
+/* root.zig L60-71 / src/c_api/orbital_mechanics.zig: four closed-form scalars (src/calculations.zig L83-125) that are not on
+ * the propagation path but belong to the reference's C surface, so that a client of libastroz_c.so links unchanged.  Same
+ * argument checks and return conventions: orbital_hohmann -> AZ_ERR_VALUE for r <= 0 or |r1 - r2| < 1000; the scalar
+ * functions return -1.0 for an invalid radius / semi-major axis; orbital_velocity(sma = 0) is the circular speed.
+ * Evaluated on device 0 like coords_* (NaN / AZ_ERR_HIP without one). */
+typedef struct azh_hohmann_result {
+    double semi_major_axis, delta_v1, delta_v2, total_delta_v, transfer_time, transfer_time_days;
+} azh_hohmann_result; /* = HohmannResult, orbital_mechanics.zig L9-16 */
+int32_t orbital_hohmann(double mu, double r1, double r2, azh_hohmann_result *out);
+double orbital_velocity(double mu, double radius, double sma);
+double orbital_period(double mu, double sma);
+double orbital_escape_velocity(double mu, double radius);
 
 /* =====================================================================================
  * (B) constellation boundary

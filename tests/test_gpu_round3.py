@@ -131,3 +131,27 @@ def test_bench_config4_reports_three_points(native):
     assert cfg["t_total_ms"] > 0 and cfg["t_kernel_ms"] > 0 and cfg["t_replicate_ms"] > 0
     assert cfg["gather"] is True and cfg["rccl_ranks"] == 1
     assert j["parity"]["max_abs_dr_km"] < 1e-6 and j["parity"]["max_abs_dv_kms"] < 1e-9, j["parity"]
+
+
+def test_orbital_exports(native):
+    """orbital_* of the reference's c_api (src/c_api/root.zig L60-71): closed forms (src/calculations.zig L83-125) evaluated
+    on the device, argument checks as in src/c_api/orbital_mechanics.zig."""
+    import ctypes as C
+    L = native.lib()
+    mu, r1, r2 = 398600.4418, 6778.0, 42164.0
+
+    class H(C.Structure):
+        _fields_ = [(n, C.c_double) for n in ("sma", "dv1", "dv2", "dvt", "t", "t_days")]
+    h = H()
+    assert L.orbital_hohmann(mu, r1, r2, C.byref(h)) == 0
+    sma = 0.5 * (r1 + r2)
+    v1, v2 = np.sqrt(mu / r1), np.sqrt(mu / r2)
+    dv1, dv2 = v1 * np.sqrt(2 * r2 / (r1 + r2)) - v1, v2 - v2 * np.sqrt(2 * r1 / (r1 + r2))
+    for got, want in ((h.sma, sma), (h.dv1, dv1), (h.dv2, dv2), (h.dvt, abs(dv1) + abs(dv2)), (h.t, np.pi * np.sqrt(sma ** 3 / mu)),
+                      (h.t_days, np.pi * np.sqrt(sma ** 3 / mu) / 86400.0)):
+        assert abs(got - want) <= 1e-12 * abs(want)
+    assert L.orbital_hohmann(mu, -1.0, r2, C.byref(h)) == -20 and L.orbital_hohmann(mu, r1, r1 + 10.0, C.byref(h)) == -20
+    assert abs(L.orbital_velocity(mu, r1, 0.0) - v1) < 1e-12 and abs(L.orbital_velocity(mu, r1, sma) - np.sqrt(mu * (2 / r1 - 1 / sma))) < 1e-12
+    assert abs(L.orbital_period(mu, r2) - 2 * np.pi * np.sqrt(r2 ** 3 / mu)) < 1e-8
+    assert abs(L.orbital_escape_velocity(mu, r1) - np.sqrt(2 * mu / r1)) < 1e-12
+    assert L.orbital_velocity(mu, -1.0, 0.0) == -1.0 and L.orbital_period(mu, 0.0) == -1.0 and L.orbital_escape_velocity(mu, 0.0) == -1.0

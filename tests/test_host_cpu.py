@@ -31,7 +31,7 @@ def native():
 def test_header_symbols_exported(native):
     hdr = open(os.path.join(ROOT, "include", "astroz_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b((?:azh|tle|sgp4|astroz|coords)_[a-z0-9_]+)\s*\(", hdr))
+    names = set(re.findall(r"\b((?:azh|tle|sgp4|astroz|coords|orbital)_[a-z0-9_]+)\s*\(", hdr))
     assert len(names) >= 30
     L = native.lib()
     missing = [n for n in sorted(names) if not hasattr(L, n)]
