@@ -642,15 +642,16 @@ int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, 
 // deep-space launch arguments: list slice, tile, and the resonance state at every tile start --
 // computed once per (time grid, offsets, tile) and kept in the handle, like the reference keeps its
 // carries (src/Constellation.zig L88, L294)
-int32_t prepare_deep(azh_constellation *c, PropArgs &d, hipStream_t st, bool rows)
+int32_t prepare_deep(azh_constellation *c, PropArgs &d, hipStream_t st, bool rows, bool beside_bulk = false)
 {
     const unsigned n_times = d.n_times;
     d.list = c->d_list.p + (rows ? c->off_deep_cat : c->n_sgp4); // lane = time: catalog order; lane = satellite: grouped by branch
     d.n_list = c->n_sdp4;
     d.tile = auto_tile(c->n_sdp4, n_times, c->tile_sdp4, 8);
-    // beside a near-earth launch four times their size the deep-space rows take its segment length (fewer waves, fewer
-    // set-ups; the chip is full either way); on their own, the finer automatic segments
-    d.tile_forced = c->tile_sdp4 ? c->tile_sdp4 : (rows && c->n_sgp4 >= 4u * c->n_sdp4 ? rows_tile(c->n_sgp4, n_times, c->tile_sgp4) : 0u);
+    // beside a near-earth row launch four times their size the deep-space rows take its segment length (fewer waves, fewer
+    // set-ups; the chip is full either way); on their own -- deep-space-only catalogs, or ahead of the time-major tile
+    // kernel -- the finer automatic segments (a single generation of long waves is latency-bound: 80 -> 140 us)
+    d.tile_forced = c->tile_sdp4 ? c->tile_sdp4 : (rows && beside_bulk && c->n_sgp4 >= 4u * c->n_sdp4 ? rows_tile(c->n_sgp4, n_times, c->tile_sgp4) : 0u);
     // lane = time kernel: one state per 64-point chunk, taken at the chunk's grid point nearest to epoch
     const unsigned seed_tile = rows ? 64u : d.tile;
     const unsigned n_tiles = (n_times + seed_tile - 1) / seed_tile;
@@ -752,7 +753,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         HIP_TRY(hipStreamWaitEvent(c->s_deep, c->ev_fork, 0));
         PropArgs d = a;
         const bool deep_rows = use_rows(d, layout, true);
-        if (int32_t rc = prepare_deep(c, d, c->s_deep, deep_rows); rc != AZ_OK) return rc;
+        if (int32_t rc = prepare_deep(c, d, c->s_deep, deep_rows, /*beside_bulk=*/!tiles && a.inc != nullptr); rc != AZ_OK) return rc;
         if (deep_rows && layout == AZ_LAYOUT_TIME_MAJOR) {
             // time-major: the rows go satellite-major into a compact scratch array (row = list slot), then one pure-memory
             // kernel writes them out as time-major runs (k_deep_transpose)
