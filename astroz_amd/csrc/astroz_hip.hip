@@ -1182,12 +1182,26 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
         a.screen_target = c->d_tgt.p;
         PropArgs near = a, deep = a;
         unsigned parts_near = 0, parts_deep = 0;
+        // near-earth members on a uniform grid: the branch-free fast kernels with the screen as their sink (no stores at all:
+        // the arithmetic-only rate), windows the plan rejects and Newton hand-overs through the generic pass like a propagation
+        const bool fast_screen = c->n_sgp4 > 0 && a.inc != nullptr && nt >= 32;
+        FastShape shape;
         if (c->n_sgp4 > 0) {
             near.list = c->d_list.p;
             near.n_list = c->n_sgp4;
             near.tile = auto_tile(c->n_sgp4, nt, c->tile_sgp4, 8);
             near.tile_forced = c->tile_sgp4;
             parts_near = screen_parts(near, false);
+            if (fast_screen) {
+                near.list = c->d_list.p + c->off_circ;
+                near.n_circ = c->n_circ;
+                shape = fast_shape_rows(near, c->n_sgp4, c->n_circ);
+                if ((rc = ensure_plan(c, near, shape, st)) != AZ_OK) return rc;
+                near.tile = shape.tile_c;
+                near.tile_e = shape.tile_e;
+                near.screen_nseg = cgrid_y(nt, std::min(shape.tile_c, shape.tile_e));
+                parts_near = 5u * near.screen_nseg; // the fast kernels' rows + four per segment for the generic pass
+            }
         }
         if (c->n_sdp4 > 0) {
             if ((rc = prepare_deep(c, deep, st, use_rows(deep, AZ_LAYOUT_SAT_MAJOR, true))) != AZ_OK) return rc;
@@ -1199,7 +1213,31 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
         if (c->n_sgp4 > 0) {
             near.part_d2 = c->d_part_d2.p;
             near.part_t = c->d_part_t.p;
-            launch_propagate(near, AZ_LAYOUT_SAT_MAJOR, false, false, st);
+            if (fast_screen) {
+                hipLaunchKernelGGL(k_screen_parts_clear, dim3((unsigned)((np_near + 255) / 256)), dim3(256), 0, st, np_near, near.part_d2, near.part_t);
+                PropArgs e = near, cc = near;
+                e.list = near.list + near.n_circ;
+                e.n_list = near.n_list - near.n_circ;
+                e.tile = shape.tile_e;
+                e.redo_slot0 = near.n_circ;
+                cc.n_list = near.n_circ;
+                // as in a propagation: the bulk alone on the launch stream, the eccentric members and the generic pass beside it
+                const bool beside = cc.n_list > 0;
+                hipStream_t se = beside ? c->s_ecc : st;
+                if (beside) {
+                    HIP_TRY(hipEventRecord(c->ev_fork2, st));
+                    HIP_TRY(hipStreamWaitEvent(se, c->ev_fork2, 0));
+                }
+                if (e.n_list) hipLaunchKernelGGL((k_rows_fast<false, 0, AZ_SINK_SCREEN, true>), dim3((e.n_list + 7) / 8 * 8, cgrid_y(nt, e.tile)), dim3(64), 0, se, e);
+                hipLaunchKernelGGL((k_rows<false, false, AZ_SINK_SCREEN, true>), dim3(256, 4), dim3(64), 0, se, near);
+                if (cc.n_list) hipLaunchKernelGGL((k_rows_fast<false, 0, AZ_SINK_SCREEN, false>), dim3((cc.n_list + 7) / 8 * 8, cgrid_y(nt, cc.tile)), dim3(64), 0, st, cc);
+                if (beside) {
+                    HIP_TRY(hipEventRecord(c->ev_join2, se));
+                    HIP_TRY(hipStreamWaitEvent(st, c->ev_join2, 0));
+                }
+            } else {
+                launch_propagate(near, AZ_LAYOUT_SAT_MAJOR, false, false, st);
+            }
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(k_screen_finalize, dim3((c->n_sgp4 + 255) / 256), dim3(256), 0, st, near.part_d2, near.part_t,
                                parts_near, near.list, c->n_sgp4, thr2, (unsigned)target, d_min_dist, d_min_t);

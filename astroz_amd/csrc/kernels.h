@@ -64,6 +64,8 @@ struct PropArgs {
     unsigned char *err;          // n_sats x n_times, may be null (pre-zeroed)
     size_t stride_sats;          // time-major row length
     unsigned tile;               // time steps per workgroup
+    unsigned tile_e, screen_nseg; // fused screen on the fast kernels: segment length of the eccentric form (tile: the
+                                  // near-circular one's), partial-minimum rows the fast kernels own
     unsigned tile_forced;        // user override (0 = automatic)
     const double *seeds;         // deep space: resonance state at each tile start, [tile][3][n_list]; may be null
     int mode;
@@ -816,19 +818,22 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
     if (row >= p.n_list) return;
     const unsigned s = p.list[row]; // wave-uniform
     const unsigned fl = p.flags[s];
-    if ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi) return;
+    if (SINK != AZ_SINK_SCREEN && ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi)) return;
     const unsigned t_lo = blockIdx.y * p.tile;
+    if (t_lo >= p.n_times) return; // (the screen launches both forms on one grid: the finer tiling decides its height)
     const unsigned t_hi = min(t_lo + p.tile, p.n_times);
     unsigned base = t_lo;
     bool window_ok;
+    double best_d2 = __builtin_inf(); // SINK_SCREEN: this lane's running minimum of |r - r_target|^2 and its grid point
+    unsigned best_t = 0xffffffffu;
     {
         __shared__ __attribute__((aligned(16))) double cold_lds[FC_NUM + RC_NUM];
         __shared__ __attribute__((aligned(16))) out_t rows_stage[AZ_ROWS_LDS_STORE ? 2 * 64 * 3 : 4];
         const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
         if (lane == 0) az_rotcoef_store([&](int k, double v) { cold_lds[FC_NUM + k] = v; });
-        out_t *prow = reinterpret_cast<out_t *>(p.pos) + (size_t)s * p.n_times * 3;
+        out_t *prow = SINK == AZ_SINK_SCREEN ? nullptr : reinterpret_cast<out_t *>(p.pos) + (size_t)s * p.n_times * 3;
         out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + (size_t)s * p.n_times * 3 : nullptr;
-        const bool staged = AZ_ROWS_LDS_STORE &&
+        const bool staged = AZ_ROWS_LDS_STORE && SINK != AZ_SINK_SCREEN &&
                             (((reinterpret_cast<size_t>(prow) | (VEL ? reinterpret_cast<size_t>(vrow) : 0)) & 15u) == 0);
         FastKBcast k;
         {
@@ -881,6 +886,19 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
             const bool bad = az_sgp4_fast_step<VEL, ECC>(k, p.g, rk, t, fc, r, v);
             if (az_any(bad && live)) break;
 #endif
+            if (SINK == AZ_SINK_SCREEN) {
+                // fused single-target screen (src/Constellation.zig L683-756): nothing is stored; distances are
+                // frame-independent, so the TEME vectors serve.  (The target track is read through scalar-friendly
+                // loads: the loop has no stores for them to wait on.)
+                const double *q = p.screen_target + (size_t)(live ? i : t_hi - 1) * 3;
+                const double dx = q[0] - r[0], dy = q[1] - r[1], dz = q[2] - r[2];
+                const double d2 = fma(dx, dx, fma(dy, dy, dz * dz));
+                if (live && d2 < best_d2) { // NaN (failed target step) never wins
+                    best_d2 = d2;
+                    best_t = i;
+                }
+                continue;
+            }
             if (FRAME) {
                 const unsigned jj = (i - t_lo) & (AZ_FRAME_SEG - 1u);
                 const double sg = gst_lds[2 * jj], cg = gst_lds[2 * jj + 1];
@@ -892,6 +910,15 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
             if (!(live && (r[0] + r[1] + r[2] + (VEL ? v[0] + v[1] + v[2] : 0.0)) == 1.2345e300)) continue;
 #endif
             az_rows_store<VEL>(staged, base + 64 <= t_hi, live, lane, rows_stage, prow, vrow, base, r, v);
+        }
+    }
+    if (SINK == AZ_SINK_SCREEN) {
+        // partial minimum of [t_lo, base) for (this form's segment, list slot); what a Newton hand-over leaves goes into the
+        // redo pass's own partial slots
+        az_wave_argmin(best_d2, best_t);
+        if (lane == 0) {
+            p.part_d2[(size_t)blockIdx.y * p.plan_stride + row + p.redo_slot0] = best_d2;
+            p.part_t[(size_t)blockIdx.y * p.plan_stride + row + p.redo_slot0] = best_t;
         }
     }
     if (ECC && base < t_hi && lane == 0) {
@@ -1333,8 +1360,13 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     if (SINK == AZ_SINK_SCREEN) {
         az_wave_argmin(best_d2, best_t);
         if (lane == 0) {
-            p.part_d2[(size_t)blockIdx.y * p.n_list + row] = best_d2;
-            p.part_t[(size_t)blockIdx.y * p.n_list + row] = best_t;
+            // whole-list form: one partial per (time segment, list slot).  Redo pass behind the fast screen kernels: four
+            // partials (blockIdx.y = quarter of the item) per (segment of the member's own form, list slot), stored behind
+            // the fast kernels' screen_nseg rows (p.tile / p.tile_e: the two forms' segment lengths)
+            size_t part = blockIdx.y;
+            if (redo) part = p.screen_nseg + 4u * (p.redo_items[3 * (size_t)item + 1] / (row < p.n_circ ? p.tile : p.tile_e)) + blockIdx.y;
+            p.part_d2[part * p.n_list + row] = best_d2;
+            p.part_t[part * p.n_list + row] = best_t;
         }
     }
     } // items
@@ -1533,14 +1565,25 @@ __global__ void k_screen_finalize(const double *part_d2, const unsigned *part_t,
     if (s != target) {
         for (unsigned k = 0; k < n_parts; ++k) {
             const double d = part_d2[(size_t)k * n_list + li];
-            if (d < best) {
+            const unsigned t = part_t[(size_t)k * n_list + li];
+            // smallest distance, earliest grid point among equals (the parts are not always in time order: the redo
+            // pass's partials follow the fast kernels'); a part that saw nothing carries +inf / 0xffffffff
+            if (d < best || (d == best && t < bt && d < threshold_sq)) {
                 best = d;
-                bt = part_t[(size_t)k * n_list + li];
+                bt = t;
             }
         }
     }
     out_d[s] = sqrt(best);
     out_t[s] = bt;
+}
+
+__global__ void k_screen_parts_clear(size_t n, double *part_d2, unsigned *part_t)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    part_d2[i] = __builtin_inf();
+    part_t[i] = 0xffffffffu;
 }
 
 __global__ void k_screen_fill(unsigned n, double threshold, double *out_d, unsigned *out_t)

@@ -326,6 +326,34 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
         case("config3_time_major", "config 3, TIME-major output, fp64 TEME pos+vel",
              "k_tiles_fast + deep-space rows + redo", dev3, pairs3, 1440, layout=TM, rows=48)
         dev3.close()
+    if "fused_screen" not in skip:
+        ent = {"key": "fused_screen", "kernel": "k_rows_fast<SINK = screen> (+ generic pass over rejected windows), k_screen_finalize",
+               "workload": "config 2 catalog, fused propagate + single-target conjunction screen (src/Constellation.zig L683-756): minimum "
+                           "distance and its grid point of every satellite against satellite 0 over 1,440 steps, nothing stored; one "
+                           "call = input staging + window plan + the kernels (azh_screen_target_host)"}
+        try:
+            times = np.arange(1440, dtype=np.float64)
+            offs = (synth.START_JD - dev2.epochs) * 1440.0
+            ks, ws = [], []
+            dev2.set_timing(True)          # (the library's own event pair around the screen's kernels)
+            for _ in range(8):
+                t0 = time.perf_counter()
+                d, ti = dev2.screen_target(times, 0, 500.0, offs)
+                ws.append((time.perf_counter() - t0) * 1e3)
+                ks.append(dev2.last_kernel_ms())
+            dev2.set_timing(False)
+            ms = sorted(ks)[len(ks) // 2]
+            ent.update({"ms_per_step": ms, "value": dev2.n * 1440 / (ms / 1e3), "unit": "propagations/s",
+                        "call_wall_ms_median": sorted(ws)[len(ws) // 2],
+                        "what": "ms_per_step: the library's HIP event pair around the screen's kernels; call_wall_ms: host wall clock of the "
+                                "whole call incl. staging and the D2H of the two result vectors"})
+            cat = oracle.Catalog.from_pairs(pairs2, oracle.WGS72)
+            d0, t0_ = cat.screen_target(times, 0, 500.0, offs)
+            ent["parity"] = {"rows": int(dev2.n), "max_abs_dmin_km": float(np.abs(d - d0).max()),
+                             "t_index_mismatches": int((ti != t0_).sum())}
+        except Exception as exc:
+            ent["failed"] = repr(exc)
+        res.append(ent)
     if "one_satellite" not in skip:
         ent = {"key": "one_satellite", "kernel": "k_one_satellite",
                "workload": "one satellite (ISS-like, near-earth) x 10,000,000 times through azh_propagate_one_device: device-resident "
