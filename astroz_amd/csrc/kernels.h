@@ -697,15 +697,31 @@ __device__ __forceinline__ const double *az_opaque_lds(const double *p)
     asm volatile("" : "+v"(q));
     return (const double *)q;
 }
+struct ColdBroadcast;
 // once-per-step constants of a lane = time kernel: one LDS word per constant, read by all 64 lanes
 // at once (broadcast ds_read_b64: no VALU slot, no SGPRs -- the 33 uniform doubles of a satellite do
 // not fit the SGPR file next to the kernel's pointers, and every SGPR spilled to a VGPR lane costs
 // a v_readlane per use)
 struct ColdBroadcast {
     double *p;
+    const double *m = nullptr; // polynomial coefficients (devmath.h AzMathConst) as LDS words; null: literals
     __device__ __forceinline__ double operator()(int k) const { return p[k]; }
     __device__ __forceinline__ void set(int k, double v) const { p[k] = v; }
+    __device__ __forceinline__ double mc(int k) const { return m[k]; }
+    // the same table behind an address the compiler cannot see through: one per call site of a polynomial, so that the
+    // coefficient reads of one call are not merged with the next call's (merged, they stay in registers across the step)
+    __device__ __forceinline__ ColdBroadcast fresh() const;
 };
+// ... the same with literal coefficients (set-up code, kernels without the table)
+struct ColdBroadcastLit {
+    double *p;
+    __device__ __forceinline__ double operator()(int k) const { return p[k]; }
+    __device__ __forceinline__ void set(int k, double v) const { p[k] = v; }
+    __device__ __forceinline__ double mc(int k) const { return az_mc_literal(k); }
+    __device__ __forceinline__ const ColdBroadcastLit &fresh() const { return *this; }
+};
+__device__ const double az_mc_table[MC_NUM] = AZ_MC_VALUES;
+__device__ __forceinline__ ColdBroadcast ColdBroadcast::fresh() const { return ColdBroadcast{p, az_opaque_lds(m)}; }
 #ifndef AZ_ROWSF_WAVES
 #define AZ_ROWSF_WAVES 6 /* k_rows_fast, near-circular Kepler form: 68 VGPRs (7 waves/SIMD fit) */
 #endif
@@ -1400,13 +1416,14 @@ __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
     if (SINK != AZ_SINK_SCREEN && ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi)) return;
     const unsigned t_lo = blockIdx.y * p.tile; // p.tile is a multiple of 64 (and at most 64 * AZ_DEEP_SEED_MAX: host)
     const unsigned t_hi = min(t_lo + p.tile, p.n_times);
-    __shared__ double lds[TL + H_NUM + D_NUM + 3 * AZ_DEEP_SEED_MAX];
+    __shared__ double lds[TL + H_NUM + D_NUM + 3 * AZ_DEEP_SEED_MAX + MC_NUM];
     double *seed_lds = lds + TL + H_NUM + D_NUM;
     int irez;
     {
         Sdp4Bcast e0{lds + TL, 0};
-        az_load_sdp4(p.el, p.n_pad, s, fl, e0, ColdBroadcast{lds + TL + H_NUM});
+        az_load_sdp4(p.el, p.n_pad, s, fl, e0, ColdBroadcastLit{lds + TL + H_NUM});
         irez = e0.irez;
+        if (lane < MC_NUM) lds[TL + H_NUM + D_NUM + 3 * AZ_DEEP_SEED_MAX + lane] = az_mc_table[lane];
     }
     // The loop below holds NO vector-memory load: vmcnt counts loads and stores in issue order, so a load's s_waitcnt also
     // waits for every output store issued before it -- one load per iteration serialises the arithmetic against the write
@@ -1455,7 +1472,7 @@ __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
         // from hoisting 61 loop-invariant loads into 122 VGPRs (a VGPR-held LDS address: reads are immediate offsets)
         const double *lds_now = az_opaque_lds(lds + TL);
         const Sdp4Bcast e{const_cast<double *>(lds_now), irez};
-        const ColdBroadcast cold{const_cast<double *>(lds_now) + H_NUM};
+        const ColdBroadcast cold{const_cast<double *>(lds_now) + H_NUM, lds_now + H_NUM + D_NUM + 3 * AZ_DEEP_SEED_MAX};
         Sdp4Carry cy;
         if (res && p.seeds) {
             const double *sd = lds_now + H_NUM + D_NUM + 3u * ((base - t_lo) >> 6); // wave-uniform address

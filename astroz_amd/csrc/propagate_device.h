@@ -72,12 +72,16 @@ struct ColdLds {
     double *p;
     AZ_MEMBER double operator()(int k) const { return p[k * AZ_COLD_STRIDE]; }
     AZ_MEMBER void set(int k, double v) const { p[k * AZ_COLD_STRIDE] = v; }
+    AZ_MEMBER double mc(int k) const { return az_mc_literal(k); } // polynomial coefficients: literals (devmath.h)
+    AZ_MEMBER const ColdLds &fresh() const { return *this; }
 };
 // ... or plain (wave-uniform) values when one wave works on a single satellite (lane = time kernels)
 struct ColdRegs {
     double c[C_NUM_MAX];
     AZ_MEMBER double operator()(int k) const { return c[k]; }
     AZ_MEMBER void set(int k, double v) { c[k] = v; }
+    AZ_MEMBER double mc(int k) const { return az_mc_literal(k); }
+    AZ_MEMBER const ColdRegs &fresh() const { return *this; }
 };
 
 template <class Cold>
@@ -114,10 +118,10 @@ struct J2Factors {
     double k_mrt, k_c2u, k_su, k_node, k_inc, x1mth2, k_rv;
 };
 
-template <bool VEL>
+template <bool VEL, class M = McLit>
 AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double axnl, double aynl,
                                   double su0, double cu0, double sO, double cO, double sI, double cI,
-                                  const J2Factors &k, const RotK &rk, double r[3], double v[3])
+                                  const J2Factors &k, const RotK &rk, double r[3], double v[3], const M &m = M())
 {
     // Newton on  E - aynl*cosE + axnl*sinE = u  with eps = E - u carried instead of E.
     // Exit test: the step after d would be ~ (el/2) d^2, so stop once el2 * d^4 < (2e-13)^2.
@@ -134,7 +138,7 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
         // first order (d1^2/2 < 2e-16).  37 instructions instead of two full trips (62).
         rden = az_rcp1(fma(-s, aynl, fma(-c, axnl, 1.0)));
         const double d0 = fma(axnl, s, -(aynl * c)) * rden;
-        az_rotate_le_tiny(s, c, d0, rk); // |d0| < 2^-10 for e < 1e-3, else the generic vote picks `small`
+        az_rotate_le_tiny_m(s, c, d0, rk, m); // |d0| < 2^-10 for e < 1e-3, else the generic vote picks `small`
         const double d1 = fma(axnl, s, fma(-aynl, c, -d0)) * rden;
         const double s1 = fma(c, d1, s);
         c = fma(-s, d1, c);
@@ -163,9 +167,9 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
             d = fmin(fmax(d, -0.95), 0.95);
             eps += d;
             if (it == 0)
-                az_rotate(s, c, d, rk);
+                az_rotate_m(s, c, d, rk, m);
             else
-                az_rotate_le_tiny(s, c, d, rk);
+                az_rotate_le_tiny_m(s, c, d, rk, m);
             const double d2 = d * d;
             if (!az_any(el2 * d2 * d2 >= 4.0e-26)) {
                 converged = true;
@@ -207,9 +211,9 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
         az_rotate_tiny(sn, cn, k.k_node * t2s, rk);
         az_rotate_tiny(si, ci, k.k_inc * temp2 * cos2u, rk);
     } else {
-        az_rotate(ssu, csu, k.k_su * t2s, rk);
-        az_rotate(sn, cn, k.k_node * t2s, rk);
-        az_rotate(si, ci, k.k_inc * temp2 * cos2u, rk);
+        az_rotate_m(ssu, csu, k.k_su * t2s, rk, m);
+        az_rotate_m(sn, cn, k.k_node * t2s, rk, m);
+        az_rotate_m(si, ci, k.k_inc * temp2 * cos2u, rk, m);
     }
 
     const double xmx = -sn * ci, xmy = cn * ci;
@@ -428,12 +432,12 @@ AZ_DEVICE void az_resonance_accel(const Lane &e, const Cold &cold, double xli, d
     // instructions for the ten half-day phases instead of ten sincos, 1 + ~25 instead of three for the synchronous ones.
     // (sin,cos) of the constants are literals; sin(a - G) = sin a cos G - cos a sin G.
     double sl, cl;
-    az_sincos(xli, sl, cl);
+    az_sincos_m(xli, sl, cl, cold.fresh());
     const double s2l = 2.0 * sl * cl, c2l = fma(-2.0 * sl, sl, 1.0);
     if (az_any(e.irez == 2)) {
         const double xomi = fma(e(H_argpdot), atime, e(H_argpo));
         double so, co;
-        az_sincos(xomi, so, co);
+        az_sincos_m(xomi, so, co, cold.fresh());
         const double s2o = 2.0 * so * co, c2o = fma(-2.0 * so, so, 1.0);
         double acc_s = 0.0, acc_c = 0.0, acc_c2 = 0.0;
         // term(d, (sa, ca) = (sin,cos) of the phase without its constant, (sg, cg) = (sin,cos) G): d sin(a - G), d cos(a - G)
@@ -610,10 +614,10 @@ AZ_DEVICE int az_sdp4_step_impl(const Lane &e, const Cold &cold, const AzGrav &g
         // binomial series to x^5 (next term 0.4 x^6 < 3e-17 for |x| <= 2e-3), cbrt only beyond that
         const double x = (nm - e(H_no_unkozai)) * az_rcp(e(H_no_unkozai));
         if (!az_any(fabs(x) > 2.0e-3)) {
-            double f = fma(x, -308.0 / 729.0, 110.0 / 243.0);
-            f = fma(x, f, -40.0 / 81.0);
-            f = fma(x, f, 5.0 / 9.0);
-            f = fma(x, f, -2.0 / 3.0);
+            double f = fma(x, cold.mc(MC_A23_0), cold.mc(MC_A23_1));
+            f = fma(x, f, cold.mc(MC_A23_2));
+            f = fma(x, f, cold.mc(MC_A23_3));
+            f = fma(x, f, cold.mc(MC_A23_4));
             a23 = e(H_a_base) * fma(x, f, 1.0);
         } else {
             const double q = g.xke / nm;
@@ -634,9 +638,9 @@ AZ_DEVICE int az_sdp4_step_impl(const Lane &e, const Cold &cold, const AzGrav &g
     {
         double zm = fma(AZ_ZNS, t, e(H_zmos));
         double szm, czm, sinzf, coszf;
-        az_sincos(zm, szm, czm);
+        az_sincos_m(zm, szm, czm, cold.fresh());
         sinzf = szm; coszf = czm;
-        az_rotate_med(sinzf, coszf, 2.0 * AZ_ZES * szm); // zf = zm + 2 zes sin zm  (|.| <= 0.0335)
+        az_rotate_med_m(sinzf, coszf, 2.0 * AZ_ZES * szm, cold.fresh()); // zf = zm + 2 zes sin zm  (|.| <= 0.0335)
         double f2 = fma(0.5 * sinzf, sinzf, -0.25), f3 = -0.5 * sinzf * coszf;
         const double ses = DL(se2) * f2 + DL(se3) * f3;
         const double sis = DL(si2) * f2 + DL(si3) * f3;
@@ -644,9 +648,9 @@ AZ_DEVICE int az_sdp4_step_impl(const Lane &e, const Cold &cold, const AzGrav &g
         const double sghs = DL(sgh2) * f2 + DL(sgh3) * f3 + DL(sgh4) * sinzf;
         const double shs = DL(sh2) * f2 + DL(sh3) * f3;
         zm = fma(AZ_ZNL, t, e(H_zmol));
-        az_sincos(zm, szm, czm);
+        az_sincos_m(zm, szm, czm, cold.fresh());
         sinzf = szm; coszf = czm;
-        az_rotate_med(sinzf, coszf, 2.0 * AZ_ZEL * szm); // |.| <= 0.1098
+        az_rotate_med_m(sinzf, coszf, 2.0 * AZ_ZEL * szm, cold.fresh()); // |.| <= 0.1098
         f2 = fma(0.5 * sinzf, sinzf, -0.25);
         f3 = -0.5 * sinzf * coszf;
         const double sel = DL(ee2) * f2 + DL(e3) * f3;
@@ -659,7 +663,7 @@ AZ_DEVICE int az_sdp4_step_impl(const Lane &e, const Cold &cold, const AzGrav &g
 
         inclm += pinc;
         em += pe;
-        az_sincos(inclm, sI, cI);
+        az_sincos_m(inclm, sI, cI, cold.fresh());
         const double sinip = sI, cosip = cI;
         const bool lyd = inclm < 0.2;
         if (az_any(lyd)) {
@@ -674,7 +678,7 @@ AZ_DEVICE int az_sdp4_step_impl(const Lane &e, const Cold &cold, const AzGrav &g
             // the reference's dls term, hence the one explicit modulus.)
             if (lyd) {
                 const double xnoh = az_mod2pi(nodem);
-                const double delta = az_atan2(ph, fma(pinc, cosip, sinip));
+                const double delta = az_atan2_m(ph, fma(pinc, cosip, sinip), cold.fresh());
                 argpm += pgh - pinc * xnoh * sinip - cosip * delta;
                 nodem += delta;
                 mm += pl;
@@ -711,13 +715,13 @@ AZ_DEVICE int az_sdp4_step_impl(const Lane &e, const Cold &cold, const AzGrav &g
     const double ra = az_rsqrt(am);
     const double temp = ra * ra * az_rcp(fma(-em, em, 1.0));
     double sw, cw, sO, cO, su0, cu0;
-    az_sincos(argpm, sw, cw);
-    az_sincos(nodem, sO, cO);
+    az_sincos_m(argpm, sw, cw, cold.fresh());
+    az_sincos_m(nodem, sO, cO, cold.fresh());
     const double axnl = em * cw;
     const double aynl = fma(em, sw, temp * aycof);
-    az_sincos(mm + argpm + temp * xlcof * axnl, su0, cu0);
+    az_sincos_m(mm + argpm + temp * xlcof * axnl, su0, cu0, cold.fresh());
 
-    const double mrt = az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, sO, cO, sI, cI, k, rk, r, v);
+    const double mrt = az_kepler_posvel<VEL>(g, am, ra, axnl, aynl, su0, cu0, sO, cO, sI, cI, k, rk, r, v, cold.fresh());
     if (rc == 0 && mrt < 1.0) rc = 6;
     return rc;
 }

@@ -216,7 +216,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
     sptr = stream.cuda_stream
     res = []
 
-    def timed(fn, warm, steps, pre_ms=120.0):
+    def timed(fn, warm, steps, pre_ms=200.0):
         # the device idles while the CPU baseline / the oracle of the previous entry run: bring the clocks back to their
         # loaded level first (the same back-to-back preconditioning as the headline's, shorter)
         fn()
@@ -238,7 +238,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / steps
 
-    def case(key, workload, kernel, dev, pairs, n_times, *, layout, vel=True, f32=False, mode=0, steps=20, warm=5,
+    def case(key, workload, kernel, dev, pairs, n_times, *, layout, vel=True, f32=False, mode=0, steps=50, warm=20,
              cold=False, rows=16, ref_jd=0.0, arith32=False):
         if key in skip:
             return
