@@ -675,8 +675,9 @@ int32_t ensure_plan(azh_constellation *c, PropArgs &a, const FastShape &shape, h
     const unsigned n_list = a.n_list;
     const unsigned n_seg = (a.n_times + std::min(shape.tile_c, shape.tile_e) - 1) / std::min(shape.tile_c, shape.tile_e);
     if (!pl.valid || pl.tile_c != shape.tile_c || pl.tile_e != shape.tile_e || pl.n_list != n_list) {
-        // every wave of the eccentric launch may file one dynamic item; static items: at most one per (slot, segment)
-        const size_t items = (size_t)n_list * n_seg + ((size_t)a.n_times + 63) / 64 * n_list;
+        // static items: at most one per (slot, segment); dynamic ones: only waves of eccentric members file them, at most one
+        // per 64-point iteration
+        const size_t items = (size_t)n_list * n_seg + ((size_t)a.n_times + 63) / 64 * (c->n_sgp4 - c->n_circ);
         if (pl.redo.cap < 4 + 3 * items || pl.win.cap < (size_t)n_list * n_seg * AZ_PLAN_NUM) HIP_TRY(hipStreamSynchronize(st)); // (launches in flight use the old buffers)
         if (pl.redo.ensure(4 + 3 * items) != AZ_OK || pl.win.ensure((size_t)n_list * n_seg * AZ_PLAN_NUM) != AZ_OK ||
             pl.flag.ensure((size_t)n_list * n_seg) != AZ_OK)
