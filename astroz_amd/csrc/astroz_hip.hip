@@ -114,6 +114,7 @@ struct azh_constellation {
         DevBuf<unsigned> redo;
     } plan[3];
     DevBuf<double> d_inc;       // uniform grids: per-satellite rotation increments (k_prep_inc), [2 * AZ_INC_NUM][n_pad]
+    DevBuf<double> d_fast_rec;  // ... and the record of folded constants of the lane = time fast kernels (k_prep_rec), [n_pad][FR_NUM]
     double uniform_step = 0.0;  // step of the staged grid if it is uniform, else 0
     DevBuf<double> d_tgt, d_part_d2, d_out_d; // fused screen: target track, partial minima, results
     DevBuf<unsigned> d_part_t, d_out_t;
@@ -165,6 +166,7 @@ void destroy(azh_constellation *c)
     c->d_seeds.release();
     c->d_deep_tmp.release();
     c->d_inc.release();
+    c->d_fast_rec.release();
     for (auto &pl : c->plan) { pl.win.release(); pl.flag.release(); pl.redo.release(); }
     c->d_tgt.release();
     c->d_part_d2.release();
@@ -633,6 +635,10 @@ int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, 
             hipLaunchKernelGGL(k_prep_inc, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, st, c->d_el, c->n, c->n_pad,
                                step, c->d_inc.p);
             HIP_TRY(hipGetLastError());
+            if (c->d_fast_rec.ensure((size_t)FR_NUM * c->n_pad) != AZ_OK) return AZ_ERR_HIP;
+            hipLaunchKernelGGL(k_prep_rec, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, st, c->d_el, c->d_flags, c->n, c->n_pad,
+                               c->d_inc.p, c->d_fast_rec.p);
+            HIP_TRY(hipGetLastError());
             c->uniform_step = step;
         }
     }
@@ -738,6 +744,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     a.g = c->g;
     a.uniform_step = c->fast_path ? c->uniform_step : 0.0;
     a.inc = (a.uniform_step != 0.0) ? c->d_inc.p : nullptr;
+    a.fast_rec = (a.uniform_step != 0.0) ? c->d_fast_rec.p : nullptr;
     a.row_lo = (unsigned)row_lo;
     a.row_hi = (unsigned)row_hi;
 
@@ -1178,6 +1185,7 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
         a.g = c->g;
         a.uniform_step = c->fast_path ? c->uniform_step : 0.0;
         a.inc = (a.uniform_step != 0.0) ? c->d_inc.p : nullptr;
+        a.fast_rec = (a.uniform_step != 0.0) ? c->d_fast_rec.p : nullptr;
         a.row_lo = 0;
         a.row_hi = 0xffffffffu;
         a.screen_target = c->d_tgt.p;

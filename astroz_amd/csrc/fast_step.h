@@ -142,6 +142,61 @@ AZ_DEVICE void az_fast_window(const double *__restrict__ el, size_t n_pad, size_
 #undef L
 }
 
+// ---- the per-satellite record of the lane = time kernels (one satellite per wave).  az_load_fast's folded products are the
+// same for every wave that ever works on the satellite, so k_prep_rec evaluates them ONCE per staged grid into an
+// array-of-structures record; a wave then reads its 33 constants with a handful of wide scalar loads (hot fields: straight
+// into SGPRs, no arithmetic on uniform values in the vector ALUs, no v_readfirstlane) and one per-lane vector load (lane j
+// fetches cold field j for the LDS table: no SGPR -> VGPR moves).  Layout: [FC_NUM cold fields in FastCold order |
+// AZ_FASTK_HOT_REC fields | the four angles of the seeds], padded to a 64-byte multiple.
+#define AZ_FASTK_HOT_REC(X)                                                                                  \
+    X(aycof) X(xlcof) X(xnodcf) X(sinio) X(cosio) X(k_mrt) X(k_c2u) X(k_su) X(k_node) X(k_inc) X(x1mth2) X(k_rv) \
+    X(sdA) X(cdA) X(sdW) X(cdW) X(nodedot)
+enum FastRec {
+    FR_COLD0 = 0,
+    FR_HOT0 = FC_NUM,
+#define X(n) FR_##n,
+    FR_first_hot_ = FR_HOT0 - 1,
+    AZ_FASTK_HOT_REC(X)
+#undef X
+    FR_mo, FR_mdot, FR_argpo, FR_argpdot,
+    FR_USED,
+    FR_NUM = (FR_USED + 7) & ~7
+};
+AZ_DEVICE void az_fast_rec_store(const double *__restrict__ el, size_t n_pad, size_t i, const FastK &k, double *__restrict__ rec)
+{
+#define X(n) rec[FC_##n] = k.n##_;
+    AZ_FASTK_COLD(X)
+#undef X
+#define X(n) rec[FR_##n] = k.n##_;
+    AZ_FASTK_HOT_REC(X)
+#undef X
+#define L(f) el[(size_t)F_##f * n_pad + i]
+    rec[FR_mo] = L(mo); rec[FR_mdot] = L(mdot); rec[FR_argpo] = L(argpo); rec[FR_argpdot] = L(argpdot);
+#undef L
+    for (int j = FR_USED; j < FR_NUM; ++j) rec[j] = 0.0;
+}
+// the wave-uniform part of a FastKBcast from the record (scalar loads)
+template <class K>
+AZ_DEVICE void az_fast_rec_hot(const double *__restrict__ rec, K &k)
+{
+#define X(n) k.n##_ = rec[FR_##n];
+    AZ_FASTK_HOT_REC(X)
+#undef X
+}
+// az_seed_fast from the record, the sincos coefficients through an accessor (an LDS table in the kernels); kappa = nl2
+template <class M>
+AZ_DEVICE void az_seed_fast_rec(const double *__restrict__ rec, double kappa, double t, double tc, FastCarry &st, const M &m)
+{
+    az_sincos_m(fma(rec[FR_mdot], t, rec[FR_mo]), st.sA, st.cA, m);
+    az_sincos_m(fma(rec[FR_argpdot], t, rec[FR_argpo]), st.sW, st.cW, m);
+    if (!az_any(tc != 0.0)) {
+        st.sU = fma(st.sA, st.cW, st.cA * st.sW);
+        st.cU = fma(st.cA, st.cW, -(st.sA * st.sW));
+    } else {
+        az_sincos_m(fma(rec[FR_mdot] + rec[FR_argpdot] + 2.0 * kappa * tc, t, rec[FR_mo] + rec[FR_argpo] - kappa * tc * tc), st.sU, st.cU, m);
+    }
+}
+
 // seed the carried pairs with full sincos at time t (the step BEFORE the first one to be produced: every
 // az_sgp4_fast_step call first advances the pairs by one increment); tc from az_fast_window
 AZ_DEVICE void az_seed_fast(const double *__restrict__ el, size_t n_pad, size_t i, double t, double tc, FastCarry &st)
@@ -174,14 +229,15 @@ AZ_DEVICE void az_rot_apply2(double &s, double &c, double p, double q)
 // for the whole loop -- 8 coefficients = 16 VGPRs, a sixth wave per SIMD in k_rows_fast.
 enum RotCoef { RC_n6, RC_p24, RC_p120, RC_n720, RC_n5040, RC_p40320, RC_p362880, RC_n3628800, RC_p8,
                RC_n11f, RC_p12f, RC_p13f, RC_n14f, RC_n15f, RC_p16f, RC_NUM }; // ... -1/11!, 1/12!, 1/13!, -1/14!, -1/15!, 1/16!
+#define AZ_RC_VALUES                                                                                                      \
+    {-1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, -1.0 / 720.0, -1.0 / 5040.0, 1.0 / 40320.0, 1.0 / 362880.0, -1.0 / 3628800.0, 0.125,     \
+     -1.0 / 39916800.0, 1.0 / 479001600.0, 1.0 / 6227020800.0, -1.0 / 87178291200.0, -1.0 / 1307674368000.0,                   \
+     1.0 / 20922789888000.0}
 struct RotCoefLit {
     AZ_MEMBER double operator()(int k) const
     {
-        return k == RC_n6 ? -1.0 / 6.0 : k == RC_p24 ? 1.0 / 24.0 : k == RC_p120 ? 1.0 / 120.0 : k == RC_n720 ? -1.0 / 720.0
-             : k == RC_n5040 ? -1.0 / 5040.0 : k == RC_p40320 ? 1.0 / 40320.0 : k == RC_p362880 ? 1.0 / 362880.0
-             : k == RC_n3628800 ? -1.0 / 3628800.0 : k == RC_p8 ? 0.125
-             : k == RC_n11f ? -1.0 / 39916800.0 : k == RC_p12f ? 1.0 / 479001600.0 : k == RC_p13f ? 1.0 / 6227020800.0
-             : k == RC_n14f ? -1.0 / 87178291200.0 : k == RC_n15f ? -1.0 / 1307674368000.0 : 1.0 / 20922789888000.0;
+        constexpr double v[RC_NUM] = AZ_RC_VALUES;
+        return v[k];
     }
 };
 struct RotCoefLds {

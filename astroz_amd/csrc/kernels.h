@@ -82,6 +82,7 @@ struct PropArgs {
     // rotation increments k_prep_inc prepared for it (fast_step.h); null = generic path only
     double uniform_step;
     const double *inc;
+    const double *fast_rec; // [n_pad][FR_NUM]: per-satellite record of the lane = time fast kernels (k_prep_rec, fast_step.h)
     // row window: only satellites with row_lo <= table index < row_hi are produced by this launch (chunked
     // launches whose results feed a collective while the next chunk is still being computed)
     unsigned row_lo, row_hi;
@@ -721,6 +722,23 @@ struct ColdBroadcastLit {
     __device__ __forceinline__ const ColdBroadcastLit &fresh() const { return *this; }
 };
 __device__ const double az_mc_table[MC_NUM] = AZ_MC_VALUES;
+__device__ const double az_rc_table[RC_NUM] = AZ_RC_VALUES;
+// sincos coefficients of a wave's seeds through its LDS table (the first AZ_SC_NUM entries of AzMathConst)
+#define AZ_SC_NUM (MC_C5 + 1)
+#define AZ_FAST_TABLE ((FC_NUM + RC_NUM + AZ_SC_NUM + 1) & ~1) /* doubles per wave, 16-byte multiple */
+struct McLds {
+    const double *p;
+    __device__ __forceinline__ double mc(int k) const { return p[k]; }
+};
+// One vector load fills a wave's constant table in LDS: lane j < FC_NUM fetches cold field j of the satellite's record, the
+// next RC_NUM lanes the rotation coefficients, the next AZ_SC_NUM the sincos coefficients (round 3 wrote the first two
+// groups from lane 0, two register moves and a share of an LDS write per constant: 100 VALU slots per segment).
+__device__ __forceinline__ void az_fill_fast_table(double *table, const double *__restrict__ rec, unsigned lane)
+{
+    const double *src = lane < FC_NUM ? rec + lane
+                        : lane < FC_NUM + RC_NUM ? az_rc_table + (lane - FC_NUM) : az_mc_table + (lane - (FC_NUM + RC_NUM));
+    if (lane < FC_NUM + RC_NUM + AZ_SC_NUM) table[lane] = *src;
+}
 __device__ __forceinline__ ColdBroadcast ColdBroadcast::fresh() const { return ColdBroadcast{p, az_opaque_lds(m)}; }
 #ifndef AZ_ROWSF_WAVES
 #define AZ_ROWSF_WAVES 6 /* k_rows_fast, near-circular Kepler form: 68 VGPRs (7 waves/SIMD fit) */
@@ -775,32 +793,68 @@ __device__ __forceinline__ void az_stage3(T *stage, unsigned lane, const double 
     stage[lane * 3 + 1] = (T)r[1];
     stage[lane * 3 + 2] = (T)r[2];
 }
-// 64 lanes x 3 components of type T staged at `stage` -> 16-byte pieces at `out` (16-byte aligned)
+// Flush of one staged iteration (64 lanes x 3 components of T, positions then velocities) as 16-byte pieces: 96 per array
+// in fp64, 48 in fp32.  fp64: all 64 lanes move pieces 0-63 of each array, lanes 0-31 pieces 64-95 -- unmasked stores and
+// ONE exec-masked block; fp32: lanes 0-47 move one piece per array.  The stores go through a buffer descriptor per row
+// (built once per segment from scalars): address = row base (descriptor) + the iteration's byte offset (one SGPR) + this
+// lane's piece offset (one VGPR shared by all stores, + an immediate) -- no vector ALU work at all.  (As independent
+// `if (lane < PIECES)` global stores per array the compiler kept a masked block per store -- it does not know lane < 64 --
+// and rebuilt an LDS address and a lane offset inside each, or hoisted a 64-bit address per array and re-derived it with
+// v_mad_u64_u32: 8-11 VALU and 20 scalar slots per iteration.)
+typedef unsigned az_u4 __attribute__((ext_vector_type(4)));
+struct AzRowSink {
+    __amdgpu_buffer_rsrc_t pos, vel;
+};
 template <class T>
-__device__ __forceinline__ void az_flush_stage(const T *stage, T *out, unsigned lane)
+__device__ __forceinline__ AzRowSink az_row_sink(T *prow, T *vrow, unsigned n_times)
 {
-    constexpr unsigned PIECES = 64 * 3 * sizeof(T) / 16; // 96 (fp64) / 48 (fp32)
-    const az_f4 *src = reinterpret_cast<const az_f4 *>(stage);
-    az_f4 *dst = reinterpret_cast<az_f4 *>(out);
-#if AZ_ROWS_NT
-    if (lane < PIECES) __builtin_nontemporal_store(src[lane], dst + lane);
-    if (PIECES > 64 && lane + 64 < PIECES) __builtin_nontemporal_store(src[lane + 64], dst + lane + 64);
-#else
-    if (lane < PIECES) dst[lane] = src[lane];
-    if (PIECES > 64 && lane + 64 < PIECES) dst[lane + 64] = src[lane + 64];
-#endif
+    // (flags 0x00020000: raw buffer, no swizzle, as in the guide's T8 recipe; num_records = the row's bytes)
+    const unsigned row_bytes = n_times * 3u * (unsigned)sizeof(T);
+    return AzRowSink{__builtin_amdgcn_make_buffer_rsrc(prow, 0, row_bytes, 0x00020000),
+                     __builtin_amdgcn_make_buffer_rsrc(vrow ? vrow : prow, 0, row_bytes, 0x00020000)};
+}
+#define AZ_AUX_NT 2 /* cache-policy bits of the buffer builtins on gfx94x/95x: 1 = sc0, 2 = nt, 16 = sc1 */
+template <bool VEL, class T>
+__device__ __forceinline__ void az_flush_stage(const T *stage, const AzRowSink &sink, unsigned base, unsigned lane)
+{
+    constexpr unsigned PIECES = 64 * 3 * sizeof(T) / 16; // 96 (fp64) / 48 (fp32); the velocity pieces follow at stage + 192
+    constexpr int aux = AZ_ROWS_NT ? AZ_AUX_NT : 0;
+    const az_u4 *src = reinterpret_cast<const az_u4 *>(stage) + lane;
+    const unsigned voff = lane * 16u, soff = base * 3u * (unsigned)sizeof(T);
+    if constexpr (PIECES >= 64) {
+        const az_u4 a = src[0];
+        __builtin_amdgcn_raw_buffer_store_b128(a, sink.pos, voff, soff, aux);
+        if (VEL) {
+            const az_u4 c = src[PIECES];
+            __builtin_amdgcn_raw_buffer_store_b128(c, sink.vel, voff, soff, aux);
+        }
+        if (lane < PIECES - 64) {
+            const az_u4 b = src[64];
+            __builtin_amdgcn_raw_buffer_store_b128(b, sink.pos, voff + 1024u, soff, aux);
+            if (VEL) {
+                const az_u4 d = src[PIECES + 64];
+                __builtin_amdgcn_raw_buffer_store_b128(d, sink.vel, voff + 1024u, soff, aux);
+            }
+        }
+    } else if (lane < PIECES) {
+        const az_u4 a = src[0];
+        __builtin_amdgcn_raw_buffer_store_b128(a, sink.pos, voff, soff, aux);
+        if (VEL) {
+            const az_u4 c = src[PIECES];
+            __builtin_amdgcn_raw_buffer_store_b128(c, sink.vel, voff, soff, aux);
+        }
+    }
 }
 // one wave's work on a row segment, shared by the two row kernels: where a finished iteration goes
 template <bool VEL, class out_t>
 __device__ __forceinline__ void az_rows_store(bool staged, bool full, bool live, unsigned lane, out_t *stage, out_t *prow,
-                                              out_t *vrow, unsigned base, const double r[3], const double v[3])
+                                              out_t *vrow, unsigned base, const double r[3], const double v[3], const AzRowSink &sink)
 {
     if (staged && full) {
         az_stage3(stage, lane, r);
         if (VEL) az_stage3(stage + 192, lane, v);
         az_wave_lds_fence();
-        az_flush_stage(stage, prow + (size_t)base * 3, lane);
-        if (VEL) az_flush_stage(stage + 192, vrow + (size_t)base * 3, lane);
+        az_flush_stage<VEL>(stage, sink, base, lane);
         az_wave_lds_fence();
     } else if (live) {
         // partial iteration / unaligned row: direct 24-byte (12-byte) pieces per lane
@@ -843,36 +897,31 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
     double best_d2 = __builtin_inf(); // SINK_SCREEN: this lane's running minimum of |r - r_target|^2 and its grid point
     unsigned best_t = 0xffffffffu;
     {
-        __shared__ __attribute__((aligned(16))) double cold_lds[FC_NUM + RC_NUM];
+        __shared__ __attribute__((aligned(16))) double cold_lds[AZ_FAST_TABLE];
         __shared__ __attribute__((aligned(16))) out_t rows_stage[AZ_ROWS_LDS_STORE ? 2 * 64 * 3 : 4];
         const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
-        if (lane == 0) az_rotcoef_store([&](int k, double v) { cold_lds[FC_NUM + k] = v; });
+        const double *__restrict__ rec = p.fast_rec + (size_t)s * FR_NUM;
+        az_fill_fast_table(cold_lds, rec, lane);
         out_t *prow = SINK == AZ_SINK_SCREEN ? nullptr : reinterpret_cast<out_t *>(p.pos) + (size_t)s * p.n_times * 3;
         out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + (size_t)s * p.n_times * 3 : nullptr;
         const bool staged = AZ_ROWS_LDS_STORE && SINK != AZ_SINK_SCREEN &&
                             (((reinterpret_cast<size_t>(prow) | (VEL ? reinterpret_cast<size_t>(vrow) : 0)) & 15u) == 0);
         FastKBcast k;
         {
-            FastK k0;
-            az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k0);
             const double w_a = fma((double)t_lo, p.uniform_step, p.times[0] + off), w_b = fma((double)(t_hi - 1), p.uniform_step, p.times[0] + off);
             // window constants and the verdict of the validation bounds: prepared once per staged grid (k_plan_windows); a
             // rejected window is already on the redo list
-            window_ok = az_plan_window(p, blockIdx.y, row + p.redo_slot0, w_a, w_b, k0);
+            window_ok = az_plan_window(p, blockIdx.y, row + p.redo_slot0, w_a, w_b, k);
             if (!window_ok) return;
-#define X(n) if (lane == 0) cold_lds[FC_##n] = k0.n##_;
-            AZ_FASTK_COLD(X)
-#undef X
-#define X(n) k.n##_ = az_uniform(k0.n##_);
-            AZ_FASTK_HOT(X)
-#undef X
+            az_fast_rec_hot(rec, k); // scalar loads: the hot constants arrive in SGPRs
             az_wave_lds_fence();
         }
         const double step = p.uniform_step;
         const double t_first = p.times[0] + off; // tsince of grid point 0; grid point i is t_first + i*step
         FastCarry fc;
         // seed one increment (64 grid steps) BEFORE this lane's first grid point
-        az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, fc);
+        az_seed_fast_rec(rec, rec[FC_nl2], fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, fc,
+                         McLds{cold_lds + FC_NUM + RC_NUM});
         __shared__ double gst_lds[FRAME ? 2 * AZ_FRAME_SEG : 2];
         if (FRAME) {
 #pragma unroll
@@ -883,6 +932,8 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
             }
             az_wave_lds_fence();
         }
+        AzRowSink sink{};
+        if constexpr (SINK != AZ_SINK_SCREEN) sink = az_row_sink(prow, vrow, p.n_times);
 #pragma unroll 1
         for (; window_ok && base < t_hi; base += 64) {
             const unsigned i = base + lane;
@@ -925,7 +976,7 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
 #if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only (every component stays live) */
             if (!(live && (r[0] + r[1] + r[2] + (VEL ? v[0] + v[1] + v[2] : 0.0)) == 1.2345e300)) continue;
 #endif
-            az_rows_store<VEL>(staged, base + 64 <= t_hi, live, lane, rows_stage, prow, vrow, base, r, v);
+            az_rows_store<VEL>(staged, base + 64 <= t_hi, live, lane, rows_stage, prow, vrow, base, r, v, sink);
         }
     }
     if (SINK == AZ_SINK_SCREEN) {
@@ -966,13 +1017,13 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
 {
     constexpr unsigned NA = VEL ? 2u : 1u;
     constexpr bool ECEF = FRAME != 0;
-    __shared__ __attribute__((aligned(16))) double cold_all[AZ_TILE_SATS * (FC_NUM + RC_NUM)];
+    __shared__ __attribute__((aligned(16))) double cold_all[AZ_TILE_SATS * AZ_FAST_TABLE];
     __shared__ __attribute__((aligned(16))) double tile[2 * NA * 64 * AZ_TILE_PITCH];
     // ECEF output: (sin,cos) of the Greenwich angle of this segment's time steps, staged once (a load inside the loop would
     // wait for the stores in flight); geodetic output stays with the lane = satellite kernel
     __shared__ double gst[ECEF ? 2 * AZ_TILE_SEG_MAX : 2];
-    const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    double *cold_lds = cold_all + w * (FC_NUM + RC_NUM);
+    const unsigned lane = threadIdx.x & 63u, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // (uniform, and known to be)
+    double *cold_lds = cold_all + w * AZ_FAST_TABLE;
     // XCD-aware tile assignment (workgroup b runs on XCD b % 8; gridDim.x is a multiple of 8): every XCD takes a contiguous
     // range of tiles, so the cache lines that two neighbouring tiles share at the ends of their 384-byte runs meet in ONE L2
     const unsigned tile_id = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -1008,20 +1059,14 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
     FastKBcast k;
     FastCarry fc;
     if (!dead) {
-        if (lane == 0) az_rotcoef_store([&](int j, double x) { cold_lds[FC_NUM + j] = x; });
-        FastK k0;
-        az_load_fast(p.el, p.n_pad, s, fl, p.inc, 0, k0);
+        const double *__restrict__ rec = p.fast_rec + (size_t)s * FR_NUM;
+        az_fill_fast_table(cold_lds, rec, lane);
         const double w_a = fma((double)t_lo, step, t_first), w_b = fma((double)(t_hi - 1), step, t_first);
         // (a window the plan rejected is a static item of the redo list: the generic kernel writes that satellite's pieces)
-        if (!az_plan_window(p, blockIdx.y, slot, w_a, w_b, k0)) dead = true;
-#define X(n) if (lane == 0) cold_lds[FC_##n] = k0.n##_;
-        AZ_FASTK_COLD(X)
-#undef X
-#define X(n) k.n##_ = az_uniform(k0.n##_);
-        AZ_FASTK_HOT(X)
-#undef X
+        if (!az_plan_window(p, blockIdx.y, slot, w_a, w_b, k)) dead = true;
+        az_fast_rec_hot(rec, k);
         az_wave_lds_fence();
-        az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, fc);
+        az_seed_fast_rec(rec, rec[FC_nl2], fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, fc, McLds{cold_lds + FC_NUM + RC_NUM});
     }
     // This thread's share of a tile flush, fixed for the whole kernel: pieces q = 1024 m + tid, m < 3, of the 3,072
     // sixteen-byte pieces of a full tile (positions: 64 time rows x 24 pieces, then velocities).  Per piece the LDS byte
@@ -1777,6 +1822,17 @@ __global__ void __launch_bounds__(256) k_prep_inc(const double *el, size_t n, si
             inc[(size_t)(AZ_INC_NUM * which + 2 * a + 1) * n_pad + s] = cs;
         }
     }
+}
+
+// ... and the record of folded constants the lane = time fast kernels read (fast_step.h, FastRec); after k_prep_inc on the
+// same stream.  One lane per satellite, once per staged grid.
+__global__ void __launch_bounds__(256) k_prep_rec(const double *el, const unsigned *flags, size_t n, size_t n_pad, const double *inc, double *rec)
+{
+    const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    FastK k;
+    az_load_fast(el, n_pad, s, flags[s], inc, 0, k);
+    az_fast_rec_store(el, n_pad, s, k, rec + s * FR_NUM);
 }
 
 // scalar helpers of the c_api (coords_*, src/c_api/coordinates.zig; orbital_*, src/c_api/orbital_mechanics.zig over
