@@ -32,7 +32,7 @@ EXPORTS = [
     "azh_last_kernel_ms", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
     "azh_screen_target_host", "azh_screen_target_device", "azh_coarse_screen_device", "azh_coarse_screen_host",
     "azh_screen_all_host", "azh_constellation_from_omm_json", "azh_propagate_one_device", "azh_selftest_math",
-    "azh_parse_tle_text", "azh_parse_omm_json", "coords_julian_to_gmst",
+    "azh_parse_tle_text", "azh_parse_omm_json", "azh_set_parse_threads", "coords_julian_to_gmst",
     "azh_group_create_from_tle_text", "azh_group_create_from_omm_json", "azh_group_free", "azh_group_num_satellites",
     "azh_group_num_devices", "azh_group_padded_rows", "azh_group_get_epochs", "azh_group_propagate_host",
     "azh_group_propagate_allgather", "coords_eci_to_ecef", "coords_ecef_to_geodetic",
@@ -114,6 +114,8 @@ def lib():
     for f in ("azh_parse_tle_text", "azh_parse_omm_json"):
         getattr(L, f).argtypes = [C.c_char_p, sz, vp, sz, C.POINTER(sz)]
         getattr(L, f).restype = i32
+    L.azh_set_parse_threads.argtypes = [i32]
+    L.azh_set_parse_threads.restype = None
     for f in ("azh_group_create_from_tle_text", "azh_group_create_from_omm_json"):
         getattr(L, f).argtypes = [C.c_char_p, sz, i32, vp, i32, i32, C.POINTER(vp)]
         getattr(L, f).restype = i32
@@ -502,19 +504,27 @@ def parse_tle_lines(line1, line2):
 
 def parse_element_text(text):
     """(n, 16) array of the numeric fields of every element set in multi-TLE text or OMM JSON (object or
-    array).  Host-side text handling only; raises ValueError on malformed OMM."""
+    array).  Host-side text handling only (several threads on catalog-scale TLE text, see set_parse_threads);
+    raises ValueError on malformed OMM."""
     b = text.encode() if isinstance(text, str) else bytes(text)
     fn = lib().azh_parse_omm_json if b.lstrip()[:1] in (b"{", b"[") else lib().azh_parse_tle_text
     k = C.c_size_t(0)
-    rc = fn(b, len(b), None, 0, C.byref(k))
+    cap = len(b) // 138 + 1  # a TLE record is at least two 69-character lines: one pass is enough for TLE text
+    out = np.zeros((cap, 16), dtype=np.float64)
+    rc = fn(b, len(b), out.ctypes.data, cap, C.byref(k))
     if rc != 0:
         raise ValueError("malformed element text (code %d)" % rc)
-    out = np.zeros((k.value, 16), dtype=np.float64)
-    if k.value:
+    if k.value > cap:  # (OMM records can be shorter than 138 bytes)
+        out = np.zeros((k.value, 16), dtype=np.float64)
         rc = fn(b, len(b), out.ctypes.data, k.value, C.byref(k))
         if rc != 0:
             raise ValueError("malformed element text (code %d)" % rc)
-    return out
+    return out[:k.value]
+
+
+def set_parse_threads(n):
+    """Host threads for catalog-scale TLE text (0 = automatic, 1 = serial); process-wide."""
+    lib().azh_set_parse_threads(int(n))
 
 
 def coarse_screen(positions, threshold, valid_mask=None, *, layout=SAT_MAJOR, max_results=10_000_000, device=0,

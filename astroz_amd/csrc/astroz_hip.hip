@@ -918,7 +918,10 @@ int32_t records_out(const std::vector<azh::TleRecord> &recs, double *out16, size
 {
     if (!n_found || (max_records && !out16)) return AZ_ERR_NULL_POINTER;
     *n_found = recs.size();
-    for (size_t i = 0; i < recs.size() && i < max_records; ++i) record_to_fields(recs[i], out16 + 16 * i);
+    const size_t n = std::min(recs.size(), max_records);
+    azh::parallel_ranges(n, azh::parse_threads_for(n * 140), [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; ++i) record_to_fields(recs[i], out16 + 16 * i);
+    });
     return AZ_OK;
 }
 } // namespace
@@ -942,6 +945,8 @@ int32_t azh_parse_tle_text(const char *text, size_t len, double *out16, size_t m
     azh::parse_all(std::string_view(text, len), recs);
     return records_out(recs, out16, max_records, n_found);
 }
+
+void azh_set_parse_threads(int32_t n) { azh::set_parse_threads(n > 0 ? (unsigned)n : 0u); }
 
 int32_t azh_parse_omm_json(const char *text, size_t len, double *out16, size_t max_records, size_t *n_found)
 {

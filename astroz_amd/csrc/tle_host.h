@@ -6,6 +6,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <string_view>
 #include <vector>
 
@@ -29,6 +30,11 @@ int parse_lines(std::string_view line1, std::string_view line2, TleRecord &out);
 int parse_first(std::string_view text, TleRecord &out);
 // every '1 ...' line followed by a '2 ...' line (MultiIterator); unparsable pairs are skipped
 void parse_all(std::string_view text, std::vector<TleRecord> &out);
+// threads parse_all may use on text beyond a few hundred KB (0 = automatic: the host's cores, at most 16; 1 = serial)
+void set_parse_threads(unsigned n);
+// threads worth using on `bytes` of text under that setting, and a helper: fn(begin, end) over [0, n) cut into `threads` ranges
+unsigned parse_threads_for(size_t bytes);
+void parallel_ranges(size_t n, unsigned threads, const std::function<void(size_t, size_t)> &fn);
 
 double year_doy_to_jd(int full_year, double doy);
 

@@ -19,6 +19,7 @@ t_allgather and t_total separately.  `--scaling weak` (every rank its own 13,478
 and `--no-gather` are explicit alternatives and say so in `config.workload`.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -376,6 +377,49 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
                              "max_abs_dr_km": float(np.abs(po[torch.as_tensor(pick, device=cuda)].cpu().numpy() - p0[0]).max()),
                              "max_abs_dv_kms": float(np.abs(ve[torch.as_tensor(pick, device=cuda)].cpu().numpy() - v0[0]).max())}
             del ts, po, ve
+        except Exception as exc:
+            ent["failed"] = repr(exc)
+        res.append(ent)
+    if "ingest" not in skip:
+        ent = {"key": "ingest", "kernel": "host text reader (azh::parse_all, threads) + k_init",
+               "workload": "SURVEY 8-f4: 13,478 TLEs of text -> device-resident constellation (azh_constellation_from_tle_text: parse, "
+                           "H2D, element initialisation kernel, classification), host wall clock; and the host reader alone on the "
+                           "same text repeated to 1,010,850 records (140 MB, config 5's catalog size)"}
+        try:
+            text = "\n".join(a + "\n" + b for a, b in pairs2).encode()
+            n2 = len(pairs2)
+            ws = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                d = _native.DeviceConstellation.from_tle_text(text, _native.WGS72, cuda.index or 0)
+                d.synchronize()
+                ws.append((time.perf_counter() - t0) * 1e3)
+                ok_n = d.n
+                d.close()
+            big = text + b"\n"
+            big = big * 75
+            cap = len(big) // 138 + 1
+            buf = np.empty((cap, 16))
+            k = ctypes.c_size_t(0)
+            L = _native.lib()
+            per = {}
+            for thr in (1, 0):
+                _native.set_parse_threads(thr)
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    L.azh_parse_tle_text(big, len(big), buf.ctypes.data, cap, ctypes.byref(k))
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                per["serial" if thr == 1 else "threads"] = {"ms": min(ts), "records": int(k.value), "records_per_s": k.value / (min(ts) / 1e3)}
+            _native.set_parse_threads(0)
+            t0 = time.perf_counter()
+            d = _native.DeviceConstellation.from_tle_text(big, _native.WGS72, cuda.index or 0)
+            d.synchronize()
+            per["text_to_device"] = {"ms": (time.perf_counter() - t0) * 1e3, "records": int(d.n)}
+            d.close()
+            ent.update({"ms_per_step": float(np.median(ws)), "value": n2 / (float(np.median(ws)) / 1e3), "unit": "TLEs/s (text -> initialised on device)",
+                        "n_sats": int(ok_n), "min_ms": float(min(ws)), "reader_1M": per, "host_cores": os.cpu_count()})
+            del big, buf
         except Exception as exc:
             ent["failed"] = repr(exc)
         res.append(ent)

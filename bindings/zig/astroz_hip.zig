@@ -106,6 +106,7 @@ pub extern "c" fn azh_screen_all_host(h: ?*Handle, times_min: [*]const f64, n_ti
 // text front ends (Tle.MultiIterator / parseOmm / parseOmmArray, src/Tle.zig L103-238)
 pub extern "c" fn azh_parse_tle_text(text: [*]const u8, len: usize, out16: [*]f64, max_records: usize, n_found: *usize) i32;
 pub extern "c" fn azh_parse_omm_json(text: [*]const u8, len: usize, out16: [*]f64, max_records: usize, n_found: *usize) i32;
+pub extern "c" fn azh_set_parse_threads(n: i32) void;
 pub extern "c" fn azh_constellation_from_omm_json(text: [*]const u8, len: usize, grav: i32, device: i32, out: *?*Handle) i32;
 pub extern "c" fn azh_constellation_subset(h: ?*const Handle, indices: [*]const u32, n: usize, device: i32, out: *?*Handle) i32;
 

@@ -119,6 +119,10 @@ int32_t azh_parse_tle_lines(const char *line1, const char *line2, double *out16)
  * no GPU needed.  *n_found = records in the text; at most max_records are written to out16 (16 doubles each). */
 int32_t azh_parse_tle_text(const char *text, size_t len, double *out16, size_t max_records, size_t *n_found);
 int32_t azh_parse_omm_json(const char *text, size_t len, double *out16, size_t max_records, size_t *n_found);
+/* Text ingest at catalog scale (the reference's from_tle_text, bindings/python/src/sgp4.zig L293-350, reads
+ * serially): text beyond a few hundred KB is cut at record boundaries and parsed by several host threads, results in
+ * file order.  n = threads to use (0 = automatic: the host's cores, at most 16; 1 = serial).  Process-wide. */
+void azh_set_parse_threads(int32_t n);
 
 /* number of visible HIP devices (0 when there is no GPU / no driver) */
 int azh_device_count(void);

@@ -146,6 +146,56 @@ def test_time_helpers(golden):
     assert jday(2024, 5, 6, 12, 0, 0.0) == (2460436.5, 0.5)
 
 
+def test_text_reader_threads_and_fast_fields(native):
+    """Catalog-scale text ingest: the threaded reader returns exactly the serial reader's records, in file
+    order, whatever the cut positions fall on (name lines, orphaned lines, CRLF, no final newline); and the fixed-point
+    fast path of the numeric columns is bit-identical to a correctly rounded decimal conversion (Python's float)."""
+    import random
+    from astroz_amd import synth
+    pairs = synth.elements_to_pairs(synth.near_earth_elements(3000, seed=3), 1)
+    rng = random.Random(7)
+    parts = []
+    for i, (a, b) in enumerate(pairs):
+        r = rng.random()
+        if r < 0.3:
+            parts.append("SAT-%d" % i)              # 3-line format
+        if r > 0.97:
+            parts.append(a)                          # orphaned line 1 before the real pair
+        parts.append(a)
+        if 0.5 < r < 0.52:
+            parts.append("x" * 72)                      # a 69+ character line that is neither: breaks that pair (Tle.zig L103-132)
+        parts.append(b)
+        if 0.6 < r < 0.63:
+            parts.append(b)                          # orphaned line 2
+    for eol, tail in (("\n", "\n"), ("\r\n", ""), ("\n", "")):
+        text = eol.join(parts) + tail
+        native.set_parse_threads(1)
+        ref = native.parse_element_text(text)
+        assert 2800 < len(ref) < 3000
+        for thr in (2, 3, 7, 16):
+            native.set_parse_threads(thr)
+            got = native.parse_element_text(text)
+            assert got.shape == ref.shape and np.array_equal(got, ref), (eol, thr)
+    native.set_parse_threads(0)
+    # numeric columns: random digits, compared with float() of the same characters
+    def rd(n):
+        return "".join(rng.choice("0123456789") for _ in range(n))
+    out = np.zeros(16)
+    L = native.lib()
+    for _ in range(3000):
+        sat, yy, day = rd(5), rd(2), rd(3) + "." + rd(8)
+        ndot = rng.choice("+- ") + "." + rd(8)
+        bm, be = rng.choice("+- ") + rd(5), rng.choice("+-") + rd(1)
+        l1 = ("1 %sU 98067A   %s%s %s  00000-0 %s%s 0 %s9" % (sat, yy, day, ndot, bm, be, rd(4)))[:69].ljust(69)
+        inc, raan, ecc, argp, ma, mm = rd(3) + "." + rd(4), rd(3) + "." + rd(4), rd(7), rd(3) + "." + rd(4), rd(3) + "." + rd(4), rd(2) + "." + rd(8)
+        l2 = "2 %s %s %s %s %s %s %s%s9" % (sat, inc, raan, ecc, argp, ma, mm, rd(5))
+        assert L.azh_parse_tle_lines(l1.encode(), l2.encode(), out.ctypes.data) == 0
+        exp = {0: float(sat), 1: float(yy), 2: float(day), 4: float(ndot), 5: (float(bm) * 1e-5) * 10.0 ** int(be), 6: float(inc), 7: float(raan),
+               8: float(ecc) / 1e7, 9: float(argp), 10: float(ma), 11: float(mm)}
+        for col, e in exp.items():
+            assert out[col] == e or (col == 5 and abs(out[col] - e) <= 2e-16 * abs(e)), (col, out[col], e, l1, l2)
+
+
 def test_text_front_ends(native, golden):
     """TLE text and OMM JSON front ends (host-side text handling of the library, no GPU): the reference's own
     parse tests (src/Tle.zig L306-392) as data."""

@@ -20,7 +20,7 @@ ASM = os.path.join(OUT, "astroz_hip-hip-amdgcn-amd-amdhsa-gfx950.s")
 
 def build(defs=()):
     os.makedirs(OUT, exist_ok=True)
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-save-temps",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-save-temps",
            "-I", os.path.join(ROOT, "include"), "-o", os.path.join(OUT, "lib.so"),
            os.path.join(ROOT, "astroz_amd", "csrc", "astroz_hip.hip"), os.path.join(ROOT, "astroz_amd", "csrc", "tle_host.cpp")]
     cmd += ["-D" + d for d in defs]

@@ -7,4 +7,4 @@ print("headline ms/step %.4f  value %.4g  frac %.3f  parity %s  power %s" % (j["
 if j.get("cpu_baseline"): print("cpu_baseline", j["cpu_baseline"].get("value"), j["cpu_baseline"].get("cores"))
 for e in j.get("secondary", []):
     print("%-28s ms %-8s frac %-6s %s %s %s" % (e.get("key"), "%.4f" % e["ms_per_step"] if "ms_per_step" in e else None,
-          "%.3f" % e["roofline"]["frac"] if "roofline" in e else None, e.get("parity"), e.get("cold_grid_call_ms", ""), e.get("failed", "")))
+          "%.3f" % e["roofline"]["frac"] if "roofline" in e else None, e.get("parity"), e.get("cold_grid_call_ms", e.get("reader_1M", "")), e.get("failed", "")))

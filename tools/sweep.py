@@ -17,7 +17,7 @@ def build(specs):
     for spec in specs:
         name, _, flags = spec.partition(":")
         out = os.path.join(VAR, "lib_%s.so" % name)
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + [f for f in flags.split(",") if f] + [
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread"] + [f for f in flags.split(",") if f] + [
             "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(ROOT, "include"), "-o", out,
             os.path.join(ROOT, "astroz_amd/csrc/astroz_hip.hip"), os.path.join(ROOT, "astroz_amd/csrc/tle_host.cpp")]
         procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
