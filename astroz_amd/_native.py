@@ -412,11 +412,17 @@ class DeviceConstellation:
         check(lib().azh_propagate_one_device(self._h, sat_index, d_tsince, n, d_pos, d_vel, d_err, stream),
               "azh_propagate_one_device")
 
-    def set_f32_arithmetic(self, enabled):
-        """fp32 outputs: False (default) = fp64 arithmetic rounded once at the store; True = opt into packed fp32
-        arithmetic where it applies (4 m / 6 mm/s instead of 0.25 m / 0.24 mm/s; which kernel runs then depends on
-        whether the staged grid is uniform, so results are not bit-stable across grids)."""
-        check(lib().azh_set_f32_arithmetic(self._h, 1 if enabled else 0), "azh_set_f32_arithmetic")
+    F32_MODES = {"mixed": 0, "packed": 1, "fp64": 2}
+
+    def set_f32_arithmetic(self, mode):
+        """Arithmetic behind fp32 outputs.  "mixed" / 0 / False (default): the mixed-precision step where it applies
+        (near-circular members, TEME, uniform grid: O(1) quantities in fp64, small ones in packed fp32 -- within 0.6 m /
+        0.6 mm/s of the fp64 oracle, i.e. the level of fp32 storage itself), fp64 rounded at the store elsewhere;
+        "packed" / 1 / True: packed fp32 arithmetic where it applies (opt-in: 4 m / 6 mm/s); "fp64" / 2: fp64 arithmetic
+        rounded once at the store everywhere (0.5 m / 0.4 mm/s).  Which kernel runs depends on whether the staged grid is
+        uniform, so fp32 results are not bit-stable across grids in the first two modes."""
+        m = self.F32_MODES[mode] if isinstance(mode, str) else int(mode)
+        check(lib().azh_set_f32_arithmetic(self._h, m), "azh_set_f32_arithmetic")
 
     def set_fast_path(self, enabled):
         check(lib().azh_set_fast_path(self._h, 1 if enabled else 0), "azh_set_fast_path")

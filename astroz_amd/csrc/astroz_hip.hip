@@ -107,7 +107,7 @@ struct azh_constellation {
     // (alternating launches, re-armed to the number of static items), [2] number of static items (windows the validation
     // bounds reject), [4..] (list slot, first grid point, end) triples -- static items first, dynamic ones behind
     struct FastPlan {
-        bool valid = false;
+        bool valid = false, mixed32 = false;
         unsigned tile_c = 0, tile_e = 0, n_list = 0, n_seg = 0, parity = 0;
         DevBuf<double> win;
         DevBuf<unsigned char> flag;
@@ -143,8 +143,11 @@ struct azh_constellation {
     bool timed = false;
     bool timing = true; // record the ev_t0/ev_t1 pair around every launch set (azh_set_timing)
     unsigned tile_sgp4 = 0, tile_sdp4 = 0;
-    bool f32_arith = false; // fp32 outputs: false (default) = fp64 arithmetic rounded once at the store; true = packed fp32
-                            // arithmetic where fast_step_f32.h applies (opt-in: azh_set_f32_arithmetic, metres / mm/s)
+    // fp32 outputs (azh_set_f32_arithmetic): 0 (default) = the mixed-precision step where it applies (near-circular members,
+    // TEME, uniform grid: every O(1) quantity in fp64, the small ones in packed fp32 -- storage-level accuracy, 0.4 m /
+    // 0.4 mm/s), fp64 arithmetic rounded once at the store elsewhere; 1 = packed fp32 arithmetic (opt-in: metres / mm/s);
+    // 2 = fp64 arithmetic rounded at the store everywhere
+    int f32_mode = 0;
     bool fast_path = true; // use the branch-free uniform-grid step where it applies (azh_set_fast_path)
 };
 
@@ -429,7 +432,8 @@ inline unsigned cgrid_y(unsigned n_times, unsigned tile) { return (n_times + til
 // which kernel family (= which window plan: 0 rows, 1 packed fp32 rows, 2 time-major tiles)
 struct FastShape {
     unsigned tile_c = 0, tile_e = 0;
-    bool packed32 = false;
+    bool packed32 = false; // the two-points-per-lane fp32 kernel (k_rows_fast32) takes the near-circular rows ...
+    bool mixed32 = false;  // ... in its mixed-precision form
     int kind = 0;
 };
 // a wave's time window must stay short enough for the window-centred constants of the fast step (the node moves
@@ -455,7 +459,8 @@ FastShape fast_shape_rows(const PropArgs &a, unsigned n_sgp4, unsigned n_circ)
         f.tile_c = std::min(f.tile_c, (unsigned)AZ_FRAME_SEG);
         f.tile_e = std::min(f.tile_e, (unsigned)AZ_FRAME_SEG);
     }
-    f.packed32 = a.f32 && a.mode == AZ_OUT_TEME && a.arith32 && cap >= 128u;
+    f.packed32 = a.f32 && a.mode == AZ_OUT_TEME && a.arith32 != 2 && cap >= 128u;
+    f.mixed32 = f.packed32 && a.arith32 == 0;
     if (f.packed32) f.tile_c = std::max(128u, f.tile_c / 128u * 128u);
     f.kind = f.packed32 ? 1 : 0;
     return f;
@@ -510,7 +515,8 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const
         if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FR, AZ_SINK_F32, true>), rgrid, dim3(64), 0, se, a);
         else hipLaunchKernelGGL((k_rows<VEL, FR, AZ_SINK_F64, true>), rgrid, dim3(64), 0, se, a);
         if (c.n_list) {
-            if (packed32) hipLaunchKernelGGL((k_rows_fast32<VEL>), cgrid, dim3(64), 0, st, c);
+            if (packed32 && shape->mixed32) hipLaunchKernelGGL((k_rows_fast32<VEL, true>), cgrid, dim3(64), 0, st, c);
+            else if (packed32) hipLaunchKernelGGL((k_rows_fast32<VEL, false>), cgrid, dim3(64), 0, st, c);
             else if (a.f32) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32, false>), cgrid, dim3(64), 0, st, c);
             else hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F64, false>), cgrid, dim3(64), 0, st, c);
         }
@@ -680,7 +686,7 @@ int32_t ensure_plan(azh_constellation *c, PropArgs &a, const FastShape &shape, h
     azh_constellation::FastPlan &pl = c->plan[shape.kind];
     const unsigned n_list = a.n_list;
     const unsigned n_seg = (a.n_times + std::min(shape.tile_c, shape.tile_e) - 1) / std::min(shape.tile_c, shape.tile_e);
-    if (!pl.valid || pl.tile_c != shape.tile_c || pl.tile_e != shape.tile_e || pl.n_list != n_list) {
+    if (!pl.valid || pl.tile_c != shape.tile_c || pl.tile_e != shape.tile_e || pl.n_list != n_list || pl.mixed32 != shape.mixed32) {
         // static items: at most one per (slot, segment); dynamic ones: only waves of eccentric members file them, at most one
         // per 64-point iteration
         const size_t items = (size_t)n_list * n_seg + ((size_t)a.n_times + 63) / 64 * (c->n_sgp4 - c->n_circ);
@@ -693,6 +699,7 @@ int32_t ensure_plan(azh_constellation *c, PropArgs &a, const FastShape &shape, h
         q.el = a.el; q.flags = a.flags; q.n_pad = a.n_pad; q.list = a.list; q.n_list = n_list; q.n_circ = a.n_circ;
         q.n_times = a.n_times; q.tile_c = shape.tile_c; q.tile_e = shape.tile_e; q.by_flags = shape.kind == 2 ? 1u : 0u;
         q.times = a.times; q.offsets = a.offsets; q.inc = a.inc; q.step = a.uniform_step; q.dt_mult = shape.kind == 1 ? 128.0 : 64.0;
+        q.f32_mixed = shape.mixed32 ? 1u : 0u;
         q.win = pl.win.p; q.flag = pl.flag.p;
         q.redo_static = pl.redo.p + 2; q.redo_c0 = pl.redo.p; q.redo_c1 = pl.redo.p + 1; q.redo_items = pl.redo.p + 4;
         q.g = a.g;
@@ -700,7 +707,7 @@ int32_t ensure_plan(azh_constellation *c, PropArgs &a, const FastShape &shape, h
         hipLaunchKernelGGL(k_plan_arm, dim3(1), dim3(64), 0, st, q.redo_static, q.redo_c0, q.redo_c1);
         HIP_TRY(hipGetLastError());
         pl.valid = true;
-        pl.tile_c = shape.tile_c; pl.tile_e = shape.tile_e; pl.n_list = n_list; pl.n_seg = n_seg; pl.parity = 0;
+        pl.tile_c = shape.tile_c; pl.tile_e = shape.tile_e; pl.n_list = n_list; pl.n_seg = n_seg; pl.parity = 0; pl.mixed32 = shape.mixed32;
     }
     a.plan_win = pl.win.p;
     a.plan_flag = pl.flag.p;
@@ -740,7 +747,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     a.stride_sats = stride;
     a.mode = c->cached_mode;
     a.f32 = f32;
-    a.arith32 = (f32 && c->f32_arith) ? 1 : 0;
+    a.arith32 = f32 ? c->f32_mode : 2;
     a.g = c->g;
     a.uniform_step = c->fast_path ? c->uniform_step : 0.0;
     a.inc = (a.uniform_step != 0.0) ? c->d_inc.p : nullptr;
@@ -1066,10 +1073,11 @@ int32_t azh_set_timing(azh_constellation *c, int32_t enabled)
     return AZ_OK;
 }
 
-int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t enabled)
+int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t mode)
 {
     if (!c) return AZ_ERR_NULL_POINTER;
-    c->f32_arith = enabled != 0;
+    if (mode < 0 || mode > 2) return AZ_ERR_VALUE;
+    c->f32_mode = mode;
     return AZ_OK;
 }
 

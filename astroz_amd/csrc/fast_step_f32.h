@@ -57,6 +57,8 @@ struct FastK32Doubles {
     double sab64;                       // sqrt(a_base), head of the along-radius chain
     double sdU, cdU, tc, tmid;          // the increment of U over one lane step, window centres
     double s1U, c1U;                    // the increment of U over ONE grid step (even -> odd point)
+    // the mixed-precision step (az_sgp4_fast_step_f32p) keeps the orientation chain in fp64: its starting pairs
+    double inv_sab64, sOc64, cOc64, sinio64, cosio64;
 };
 // everything in registers (host emulation, set-up)
 struct FastK32 : FastK32Doubles {
@@ -100,6 +102,7 @@ AZ_DEVICE void az_load_fast32(const FastK &k, const FastK &k1, double step1, Fas
     f.sab64 = k.sab_;
     f.sdU = k.sdU_; f.cdU = k.cdU_; f.tc = k.tc_; f.tmid = k.tmid_;
     f.s1U = k1.sdU_; f.c1U = k1.cdU_;
+    f.inv_sab64 = 1.0 / k.sab_; f.sOc64 = k.sOc_; f.cOc64 = k.cOc_; f.sinio64 = k.sinio_; f.cosio64 = k.cosio_;
     f.sdA32_ = (float)k.sdA_; f.cdA32_ = (float)k.cdA_; f.sdW32_ = (float)k.sdW_; f.cdW32_ = (float)k.cdW_;
     f.step1_ = (float)step1;
 }
@@ -274,5 +277,203 @@ AZ_DEVICE void az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, Fas
         v[0] = az_fma2(mvt, ux, rvdot * vx);
         v[1] = az_fma2(mvt, uy, rvdot * vy);
         v[2] = az_fma2(mvt, uz, rvdot * vz);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The MIXED-precision step: fp32 outputs at (nearly) the accuracy of fp64 arithmetic rounded once at the store, for two
+// thirds of its instruction slots.  The packed step above loses its metres and mm/s in the O(1) quantities: every fp32
+// rounding of a unit-vector component or of the 7.5 km/s speed factor is 0.4 m / 0.45 mm/s, and the chain from the U pair
+// to the velocity has a dozen of them.  Here every O(1) quantity stays fp64, per grid point -- the U pair and each
+// rotation APPLIED to it, sin/cos u, the three short-period rotations of (u, node, inclination), the orientation
+// products, the radius chain, the speed factors -- while everything SMALL is still computed once for both grid points
+// in packed fp32 and converted where it meets an O(1) value: the secular drag terms, the eccentricity vector (x 0.004),
+// the Kepler corrections, the (p,q) = (sin d, cos d - 1) of every rotation angle (|d| <= 1/8: an fp32 p is good to
+// 7.5e-9 rad = 5 cm), 1/(1 - e cos E) - 1 and 1/sqrt(am) - 1/sqrt(a_base) as short series, the J2 factors.
+// Near-circular members inside a window az_fast_window_ok<false> accepted AND whose drag deviation 1 - tempa stays
+// below 2^-6 over it (the 1/(1 - dev) series; the plan checks it).
+AZ_DEVICE void az_pq32_med(az_f2 d, az_f2 &p, az_f2 &q)
+{
+    const az_f2 d2 = d * d;
+    p = d * az_fma2(d2, az_fma2(1.0f / 120.0f, d2, -1.0f / 6.0f), 1.0f);
+    q = d2 * az_fma2(d2, az_fma2(-1.0f / 720.0f, d2, 1.0f / 24.0f), -0.5f);
+}
+// (s,c) in fp64 rotated by the fp32 pair (p,q)
+AZ_DEVICE void az_rot_apply_mixed(double &s, double &c, float p, float q)
+{
+    const double pd = (double)p, qd = (double)q;
+    const double ns = fma(c, pd, fma(s, qd, s));
+    c = fma(-s, pd, fma(c, qd, c));
+    s = ns;
+}
+#define AZ_F32P_DEV_MAX 0.015625 /* 1 - tempa: dev^5 < 1e-9 */
+
+// the extra bound of the mixed step over a window [t_a, t_b] (any order): 1 - tempa <= 2^-6
+template <class K>
+AZ_DEVICE bool az_fast32p_window_ok(const K &k, double t_a, double t_b)
+{
+    const double T = fmax(fabs(t_a), fabs(t_b));
+    const double da = T * fma(T, fma(T, fma(T, fabs(k.d4_), fabs(k.d3_)), fabs(k.d2_)), fabs(k.cc1_));
+    return da <= AZ_F32P_DEV_MAX;
+}
+
+template <bool VEL, class K>
+AZ_DEVICE void az_sgp4_fast_step_f32p(const K &k, const AzGrav &g, double ta, FastCarry32 &st, az_f2 r[3], az_f2 v[3])
+{
+    {
+        const az_f2 nsA = az_fma2(k.cdA32(), st.sA, k.sdA32() * st.cA);
+        st.cA = az_fma2(k.cdA32(), st.cA, -(k.sdA32() * st.sA));
+        st.sA = nsA;
+        const az_f2 nsW = az_fma2(k.cdW32(), st.sW, k.sdW32() * st.cW);
+        st.cW = az_fma2(k.cdW32(), st.cW, -(k.sdW32() * st.sW));
+        st.sW = nsW;
+        const double nsU = fma(st.sU, k.cdU, st.cU * k.sdU);
+        st.cU = fma(st.cU, k.cdU, -(st.sU * k.sdU));
+        st.sU = nsU;
+    }
+    az_f2 lane01;
+    lane01.x = 0.0f;
+    lane01.y = k.step1();
+    const az_f2 t = az_splat2((float)ta) + lane01;
+    const az_f2 dtc = az_splat2((float)(ta - k.tc)) + lane01;
+    const az_f2 t2 = t * t;
+
+    // ---- small quantities, packed fp32 (as in az_sgp4_fast_step_f32)
+    const az_f2 dm = az_fma2(k.eta(), st.cA, 1.0f);
+    const az_f2 th = az_fma2(k.xmcof(), dm * dm * dm, az_fma2(k.omgcof(), t, -k.xd()));
+    const az_f2 dev = t * az_fma2(t, az_fma2(t, az_fma2(k.d4(), t, k.d3()), k.d2()), k.cc1());
+    const az_f2 nl = az_fma2(k.nl2() * dtc, dtc, t2 * (t * az_fma2(t, az_fma2(k.nl5(), t, k.nl4()), k.nl3())));
+    const az_f2 th2 = th * th;
+    const az_f2 pth = az_fma2((-1.0f / 6.0f) * th2, th, th);
+    const az_f2 qth = -0.5f * th2;
+    const az_f2 smm = az_fma2(st.cA, pth, az_fma2(st.sA, qth, st.sA));
+    const az_f2 sw = az_fma2(-st.cW, pth, az_fma2(st.sW, qth, st.sW));
+    const az_f2 cw = az_fma2(st.sW, pth, az_fma2(st.cW, qth, st.cW));
+    az_f2 em = az_fma2(-k.bc5(), smm, az_fma2(-k.bc4(), t, k.ecb()));
+    em.x = fmaxf(em.x, 1.0e-6f);
+    em.y = fmaxf(em.y, 1.0e-6f);
+
+    // sqrt(am) = sqrt(a_base) (1 - dev) in fp64; 1/sqrt(am) = (1/sqrt(a_base)) (1 + c1), c1 = dev + dev^2 + dev^3 + dev^4
+    const double sqrt_am_a = fabs(fma(-k.sab64, (double)dev.x, k.sab64)), sqrt_am_b = fabs(fma(-k.sab64, (double)dev.y, k.sab64));
+    const az_f2 c1 = dev * az_fma2(dev, az_fma2(dev, az_fma2(dev, az_splat2(1.0f), 1.0f), 1.0f), 1.0f);
+    const double ra_a = fma(k.inv_sab64, (double)c1.x, k.inv_sab64), ra_b = fma(k.inv_sab64, (double)c1.y, k.inv_sab64);
+    const az_f2 ra = az_cvt2(ra_a, ra_b);
+    const az_f2 omem2 = az_fma2(-em, em, 1.0f);
+    const az_f2 inv_am = ra * ra;
+    const az_f2 temp = inv_am * az_rcp2(omem2);
+
+    const az_f2 axnl = em * cw;
+    const az_f2 aynl = az_fma2(em, sw, k.aycof() * temp);
+
+    // ---- the U pairs of the two grid points, fp64
+    double s_a = st.sU, c_a = st.cU;
+    double s_b = fma(st.sU, k.c1U, st.cU * k.s1U), c_b = fma(st.cU, k.c1U, -(st.sU * k.s1U));
+    az_f2 p, q;
+    {
+        const az_f2 eps = az_fma2(k.xlcof() * temp, axnl, nl);
+        az_pq32_med(eps, p, q);
+        az_rot_apply_mixed(s_a, c_a, p.x, q.x);
+        az_rot_apply_mixed(s_b, c_b, p.y, q.y);
+    }
+    // Kepler, near-circular: Newton step from E0 = u, then the chord step with the same reciprocal (first order)
+    const az_f2 el2 = az_fma2(axnl, axnl, aynl * aynl);
+    az_f2 s = az_cvt2(s_a, s_b), c = az_cvt2(c_a, c_b);
+    const az_f2 rden = az_rcp2(az_fma2(-s, aynl, az_fma2(-c, axnl, 1.0f)));
+    const az_f2 d0 = az_fma2(axnl, s, -(aynl * c)) * rden;
+    {
+        const az_f2 d2 = d0 * d0;                       // |d0| <= 0.0041: sin to d^3 (d^5/120 < 1e-14), cos to d^4
+        p = az_fma2((-1.0f / 6.0f) * d2, d0, d0);
+        q = d2 * az_fma2(1.0f / 24.0f, d2, -0.5f);
+        az_rot_apply_mixed(s_a, c_a, p.x, q.x);
+        az_rot_apply_mixed(s_b, c_b, p.y, q.y);
+        const az_f2 ns = az_fma2(c, p, az_fma2(s, q, s)); // the fp32 copies follow (they only feed small terms)
+        c = az_fma2(-s, p, az_fma2(c, q, c));
+        s = ns;
+    }
+    {
+        const az_f2 d1 = az_fma2(axnl, s, az_fma2(-aynl, c, -d0)) * rden; // <= (el/2) d0^2 = 3.4e-8 rad: a quarter of a metre
+        const double d1a = (double)d1.x, d1b = (double)d1.y;
+        const double nsa = fma(c_a, d1a, s_a), nsb = fma(c_b, d1b, s_b);
+        c_a = fma(-s_a, d1a, c_a);
+        c_b = fma(-s_b, d1b, c_b);
+        s_a = nsa;
+        s_b = nsb;
+    }
+    const az_f2 ecose = az_fma2(axnl, c, aynl * s);   // (the chord step moves them by el d1 < 2e-10)
+    const az_f2 esine = az_fma2(axnl, s, -(aynl * c));
+    // 1/(1 - ecose) = 1 + y, y = w + w^2 + w^3 + w^4, |w| <= 0.0041 (w^5 < 1.2e-12)
+    const az_f2 y = ecose * az_fma2(ecose, az_fma2(ecose, az_fma2(ecose, az_splat2(1.0f), 1.0f), 1.0f), 1.0f);
+    const az_f2 bm1 = el2 * az_fma2(-0.125f, el2, -0.5f); // betal - 1
+    const az_f2 inv_omel2 = az_splat2(1.0f) + el2;
+    const az_f2 inv_1pb = az_fma2(0.125f, el2, 0.5f);
+    const az_f2 est = esine * inv_1pb;
+    const az_f2 tA = az_fma2(axnl, est, aynl), tB = az_fma2(aynl, est, -axnl);
+    // sin u, cos u in fp64: (s - tA)(1 + y), (c + tB)(1 + y)
+    double sinu_a, cosu_a, sinu_b, cosu_b;
+    {
+        const double ya = (double)y.x, yb = (double)y.y;
+        const double da = s_a - (double)tA.x, db = s_b - (double)tA.y, ea = c_a + (double)tB.x, eb = c_b + (double)tB.y;
+        sinu_a = fma(da, ya, da); sinu_b = fma(db, yb, db);
+        cosu_a = fma(ea, ya, ea); cosu_b = fma(eb, yb, eb);
+    }
+    const az_f2 sinu = az_cvt2(sinu_a, sinu_b), cosu = az_cvt2(cosu_a, cosu_b);
+    const az_f2 sin2u = (sinu + sinu) * cosu;
+    const az_f2 cos2u = az_fma2(-2.0f * sinu, sinu, 1.0f);
+
+    const az_f2 inv_pl = inv_am * inv_omel2;
+    const az_f2 temp1 = (float)g.half_j2 * inv_pl;
+    const az_f2 temp2 = temp1 * inv_pl;
+    // radius: rl = am (1 - ecose), mrt = rl (1 + k_mrt temp2 betal) + k_c2u temp1 cos2u, fp64 with fp32 corrections
+    const az_f2 fm1 = k.k_mrt() * temp2 * (az_splat2(1.0f) + bm1);
+    const az_f2 add = k.k_c2u() * temp1 * cos2u;
+    const double rl_a = sqrt_am_a * sqrt_am_a * (1.0 - (double)ecose.x);
+    const double rl_b = sqrt_am_b * sqrt_am_b * (1.0 - (double)ecose.y);
+    const double rs_a = fma(rl_a, (double)fm1.x, rl_a + (double)add.x) * g.radius_km;
+    const double rs_b = fma(rl_b, (double)fm1.y, rl_b + (double)add.y) * g.radius_km;
+
+    // J2 short-period rotations of u, the node (with its motion across the window) and the inclination: angles and their
+    // (p,q) packed, applied in fp64
+    const az_f2 t2s = temp2 * sin2u;
+    const az_f2 a_nd = az_fma2(k.k_node(), t2s, az_fma2(k.nodedot(), az_splat2((float)(ta - k.tmid)) + lane01, k.xnodcf() * t2));
+    double ssu_a = sinu_a, csu_a = cosu_a, ssu_b = sinu_b, csu_b = cosu_b;
+    {
+        const az_f2 d = k.k_su() * t2s;               // <= 9e-4: sin d = d, cos d - 1 = -d^2/2 (d^3/6 < 1.3e-10)
+        const az_f2 qq = (-0.5f * d) * d;
+        az_rot_apply_mixed(ssu_a, csu_a, d.x, qq.x);
+        az_rot_apply_mixed(ssu_b, csu_b, d.y, qq.y);
+    }
+    double sn_a = k.sOc64, cn_a = k.cOc64, sn_b = k.sOc64, cn_b = k.cOc64;
+    az_pq32_med(a_nd, p, q);
+    az_rot_apply_mixed(sn_a, cn_a, p.x, q.x);
+    az_rot_apply_mixed(sn_b, cn_b, p.y, q.y);
+    double si_a = k.sinio64, ci_a = k.cosio64, si_b = k.sinio64, ci_b = k.cosio64;
+    {
+        const az_f2 d = k.k_inc() * temp2 * cos2u;
+        const az_f2 qq = (-0.5f * d) * d;
+        az_rot_apply_mixed(si_a, ci_a, d.x, qq.x);
+        az_rot_apply_mixed(si_b, ci_b, d.y, qq.y);
+    }
+    const double xmx_a = -sn_a * ci_a, xmy_a = cn_a * ci_a, xmx_b = -sn_b * ci_b, xmy_b = cn_b * ci_b;
+    const double ux_a = fma(xmx_a, ssu_a, cn_a * csu_a), uy_a = fma(xmy_a, ssu_a, sn_a * csu_a), uz_a = si_a * ssu_a;
+    const double ux_b = fma(xmx_b, ssu_b, cn_b * csu_b), uy_b = fma(xmy_b, ssu_b, sn_b * csu_b), uz_b = si_b * ssu_b;
+    r[0] = az_cvt2(rs_a * ux_a, rs_b * ux_b);
+    r[1] = az_cvt2(rs_a * uy_a, rs_b * uy_b);
+    r[2] = az_cvt2(rs_a * uz_a, rs_b * uz_b);
+    if (VEL) {
+        // rvdot = rv (1 + y)(1 + bm1) + nxt (x1mth2 cos2u + k_rv), rv = vkmpersec / sqrt(am): the O(7.5 km/s) part in fp64
+        const double rv_a = ra_a * g.vkmpersec, rv_b = ra_b * g.vkmpersec;
+        const az_f2 rv32 = (float)g.vkmpersec * ra;
+        const az_f2 zz = az_fma2(y, bm1, y + bm1);
+        const az_f2 nxt = rv32 * inv_am * temp1;
+        const az_f2 gg = nxt * az_fma2(k.x1mth2(), cos2u, k.k_rv());
+        const az_f2 mvt = az_fma2(-k.x1mth2() * nxt, sin2u, rv32 * (az_splat2(1.0f) + y) * esine); // <= 0.03 km/s
+        const double rvdot_a = fma(rv_a, (double)zz.x, rv_a) + (double)gg.x, rvdot_b = fma(rv_b, (double)zz.y, rv_b) + (double)gg.y;
+        const double mvt_a = (double)mvt.x, mvt_b = (double)mvt.y;
+        const double vx_a = fma(xmx_a, csu_a, -(cn_a * ssu_a)), vy_a = fma(xmy_a, csu_a, -(sn_a * ssu_a)), vz_a = si_a * csu_a;
+        const double vx_b = fma(xmx_b, csu_b, -(cn_b * ssu_b)), vy_b = fma(xmy_b, csu_b, -(sn_b * ssu_b)), vz_b = si_b * csu_b;
+        v[0] = az_cvt2(fma(mvt_a, ux_a, rvdot_a * vx_a), fma(mvt_b, ux_b, rvdot_b * vx_b));
+        v[1] = az_cvt2(fma(mvt_a, uy_a, rvdot_a * vy_a), fma(mvt_b, uy_b, rvdot_b * vy_b));
+        v[2] = az_cvt2(fma(mvt_a, uz_a, rvdot_a * vz_a), fma(mvt_b, uz_b, rvdot_b * vz_b));
     }
 }

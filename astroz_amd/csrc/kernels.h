@@ -88,7 +88,7 @@ struct PropArgs {
     unsigned row_lo, row_hi;
     // k_rows_fast -> k_rows hand-over: (list slot, first grid point, end) of every segment remainder the fast
     // step rejected
-    int arith32;         // fp32 outputs: fp32 arithmetic for near-circular TEME rows (k_rows_fast32)
+    int arith32;         // fp32 outputs: 0 mixed-precision step, 1 packed fp32 step (both k_rows_fast32), 2 fp64 rounded at the store
     unsigned n_circ;     // row kernels on a uniform grid: list = [n_circ members of eccentricity class 0 | the rest]
     unsigned redo_slot0; // added to a k_rows_fast launch's list slots when it files redo items (sub-list launches)
     unsigned *redo_count;
@@ -603,6 +603,7 @@ struct PlanArgs {
     size_t n_pad;
     const unsigned *list;
     unsigned n_list, n_circ, n_times, tile_c, tile_e, by_flags;
+    unsigned f32_mixed; // near-circular slots go to the mixed-precision fp32 step: its extra bound (az_fast32p_window_ok)
     const double *times, *offsets, *inc;
     double step, dt_mult;
     double *win;
@@ -634,6 +635,7 @@ __global__ void __launch_bounds__(256) k_plan_windows(PlanArgs a)
     // a class the form cannot take (an eccentric member in the near-circular list) is rejected like a failed bound
     bool ok = ecc ? az_fast_window_ok<true>(k0, a.g, w_a, w_b) : az_fast_window_ok<false>(k0, a.g, w_a, w_b);
     if (!ecc && AZ_FLAG_ECLASS(fl) != 0) ok = false;
+    if (!ecc && a.f32_mixed && !az_fast32p_window_ok(k0, w_a, w_b)) ok = false;
     const size_t at = (size_t)seg * a.n_list + slot;
     double *w = a.win + at * AZ_PLAN_NUM;
     w[AZ_PLAN_sOc] = k0.sOc_; w[AZ_PLAN_cOc] = k0.cOc_; w[AZ_PLAN_sdU] = k0.sdU_; w[AZ_PLAN_cdU] = k0.cdU_;
@@ -745,6 +747,9 @@ __device__ __forceinline__ ColdBroadcast ColdBroadcast::fresh() const { return C
 #endif
 #ifndef AZ_ROWSF32_WAVES
 #define AZ_ROWSF32_WAVES 4 /* k_rows_fast32: two grid points per lane */
+#endif
+#ifndef AZ_ROWSF32P_WAVES
+#define AZ_ROWSF32P_WAVES 3 /* k_rows_fast32<MIXED>: two grid points per lane, their O(1) chains in fp64 */
 #endif
 #ifndef AZ_ROWSF_ECC_WAVES
 #define AZ_ROWSF_ECC_WAVES 4 /* k_rows_fast, eccentric form: ~100 VGPRs (its own instantiation and launch, so that the
@@ -1192,8 +1197,8 @@ __device__ __forceinline__ void az_flush_pair3(unsigned a, float *out, unsigned 
 // k_rows_fast in PACKED fp32 arithmetic (fast_step_f32.h) for fp32 outputs: near-circular members, TEME, uniform
 // grid.  A lane carries two adjacent grid points (2i, 2i+1), a wave 128 per iteration: 1,536 contiguous bytes per
 // array, staged through LDS like the fp64 rows.  All constants are wave-uniform scalars (SGPRs).
-template <bool VEL>
-__global__ void __launch_bounds__(64, AZ_ROWSF32_WAVES) k_rows_fast32(PropArgs p)
+template <bool VEL, bool MIXED = false> // MIXED: az_sgp4_fast_step_f32p (O(1) quantities in fp64: the default for fp32 outputs)
+__global__ void __launch_bounds__(64, MIXED ? AZ_ROWSF32P_WAVES : AZ_ROWSF32_WAVES) k_rows_fast32(PropArgs p)
 {
     const unsigned lane = threadIdx.x;
     const unsigned per_xcd = gridDim.x >> 3; // XCD-aware row assignment, see k_rows
@@ -1242,6 +1247,7 @@ __global__ void __launch_bounds__(64, AZ_ROWSF32_WAVES) k_rows_fast32(PropArgs p
 #undef X
 #define U(n) k.n = az_uniform(kk.n);
             U(sab64) U(sdU) U(cdU) U(tc) U(tmid) U(s1U) U(c1U)
+            if (MIXED) { U(inv_sab64) U(sOc64) U(cOc64) U(sinio64) U(cosio64) }
 #undef U
             az_wave_lds_fence();
             // seed one lane step (128 grid steps) BEFORE this lane's first even grid point
@@ -1263,7 +1269,8 @@ __global__ void __launch_bounds__(64, AZ_ROWSF32_WAVES) k_rows_fast32(PropArgs p
 #if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
             r[0] = az_splat2((float)t); r[1] = r[0] + 1.0f; r[2] = r[0] + 2.0f; v[0] = r[0] + 3.0f; v[1] = r[0] + 4.0f; v[2] = r[0] + 5.0f;
 #else
-            az_sgp4_fast_step_f32<VEL>(k, p.g, t, fc, r, v);
+            if (MIXED) az_sgp4_fast_step_f32p<VEL>(k, p.g, t, fc, r, v);
+            else az_sgp4_fast_step_f32<VEL>(k, p.g, t, fc, r, v);
 #endif
 #if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only (every component stays live) */
             if (!(live_a && (r[0].x + r[1].x + r[2].x + r[0].y + r[1].y + r[2].y +

@@ -73,7 +73,8 @@ def parse_args():
                          "satellites (16 = 128-byte aligned rows)")
     ap.add_argument("--config5-share", action="store_true",
                     help="BASELINE config 5, one GPU's share: 125,000 synthetic satellites (seed 20260927) x 10,000 one-minute "
-                         "steps, fp32 pos+vel (30 GB); fp64 arithmetic rounded at the store unless --f32-arith; parity on sampled rows")
+                         "steps, fp32 pos+vel (30 GB); mixed-precision arithmetic unless --f32-arith (packed fp32) / --f32-fp64; parity on sampled rows")
+    ap.add_argument("--f32-fp64", action="store_true", help="fp32 outputs from fp64 arithmetic rounded at the store (azh_set_f32_arithmetic(c, 2))")
     ap.add_argument("--f32-arith", action="store_true",
                     help="with fp32 outputs: opt into the packed-fp32-arithmetic kernel (4 m / 6 mm/s) instead of the default "
                          "fp64 arithmetic rounded once at the store (0.25 m / 0.24 mm/s)")
@@ -423,14 +424,17 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
         except Exception as exc:
             ent["failed"] = repr(exc)
         res.append(ent)
-    if not {"config5_share", "config5_share_f32arith"} <= set(skip):
+    if not {"config5_share", "config5_share_f32arith", "config5_share_fp64"} <= set(skip):
         try:
             pairs5 = synth.synth_catalog(n_near=125000, n_deep=0, seed=20260927)
             dev5 = _native.DeviceConstellation.from_tle_lines(pairs5, _native.WGS72, cuda.index or 0)
             dev5.set_timing(False)
             c5 = "config 5, ONE GPU's share of 8: 125,000 synthetic satellites (seed 20260927) x 10,000 one-minute steps, fp32 pos+vel (30 GB), satellite-major, "
-            case("config5_share", c5 + "DEFAULT arithmetic: fp64, every component rounded once at the store",
-                 "k_rows_fast<SINK_F32> (+ eccentric members, redo)", dev5, pairs5, 10000, layout=SM, f32=True, steps=5, warm=2, rows=24)
+            case("config5_share", c5 + "DEFAULT arithmetic: mixed precision (O(1) quantities fp64, small ones packed fp32; eccentric members fp64 rounded at the store)",
+                 "k_rows_fast32<MIXED> (+ eccentric members, redo)", dev5, pairs5, 10000, layout=SM, f32=True, steps=5, warm=2, rows=24)
+            case("config5_share_fp64", c5 + "fp64 arithmetic, every component rounded once at the store (azh_set_f32_arithmetic(c, 2))",
+                 "k_rows_fast<SINK_F32> (+ eccentric members, redo)", dev5, pairs5, 10000, layout=SM, f32=True, steps=5, warm=2, rows=24,
+                 arith32=2)
             case("config5_share_f32arith", c5 + "OPT-IN packed fp32 arithmetic (azh_set_f32_arithmetic(c, 1): 4 m / 6 mm/s)",
                  "k_rows_fast32 (+ eccentric members, redo)", dev5, pairs5, 10000, layout=SM, f32=True, steps=5, warm=2, rows=24,
                  arith32=True)
@@ -509,7 +513,7 @@ def main():
         dev.set_fast_path(False)
     if a.no_tile_kernel:
         dev.set_tile_kernel(False)
-    dev.set_f32_arithmetic(bool(a.f32_arith))
+    dev.set_f32_arithmetic(1 if a.f32_arith else (2 if a.f32_fp64 else 0))
     n_local = dev.n
     offsets = (synth.START_JD - dev.epochs) * 1440.0
     layout = _native.TIME_MAJOR if a.layout == "time" else _native.SAT_MAJOR
@@ -713,15 +717,17 @@ def main():
         wl = "WEAK scaling (--scaling weak): %d GPUs x an own %d-sat synthetic catalog x %d one-minute steps, no gather" % (
             world, a.sats + a.deep, n_times)
         par = "independent catalogs x%d, no data-path collective" % world
-    arith = "fp64 arithmetic" if not a.f32_out or not a.f32_arith or a.no_fast_path or layout != _native.SAT_MAJOR else \
-        "fp32 arithmetic with fp64 phase and radius chains (near-circular members; fp64 for the rest)"
+    f32_fast = a.f32_out and not a.f32_fp64 and not a.no_fast_path and layout == _native.SAT_MAJOR and mode == 0
+    arith = "fp64 arithmetic" if not f32_fast else (
+        "packed fp32 arithmetic with fp64 phase and radius chains (near-circular members; fp64 for the rest)" if a.f32_arith else
+        "mixed-precision arithmetic (O(1) quantities fp64, small ones packed fp32; near-circular members; fp64 for the rest)")
     wl += ", %s, %s %s %s, %s-major device-resident output" % (
         arith, "fp32-stored" if a.f32_out else "fp64", a.mode.upper(), "pos+vel" if vel_on else "pos only", a.layout)
     if layout == _native.SAT_MAJOR:
         kname = ("k_rows_fast<%s> (branch-free uniform-grid step, one wave per satellite row, lane = time) + k_rows redo pass"
                  if not a.no_fast_path else "k_rows<%s> (one wave per satellite row, lane = time)") % ("pos+vel" if vel_on else "pos")
-        if a.f32_out and a.f32_arith and not a.no_fast_path:
-            kname = kname.replace("k_rows_fast<", "k_rows_fast32<")
+        if f32_fast:
+            kname = kname.replace("k_rows_fast<", "k_rows_fast32<MIXED," if not a.f32_arith else "k_rows_fast32<")
     else:
         kname = ("k_tiles_fast<%s> (16-satellite tiles of lane = time waves, LDS transpose) + k_rows redo pass"
                  if not (a.no_fast_path or a.no_tile_kernel or a.f32_out) else "k_propagate<time-major,%s> (lane = satellite)") % (

@@ -138,8 +138,8 @@ void emul_propagate_fast(const double* fields, unsigned flags, const double* gra
 // (2j, 2j+1) of a grid with step `step`, j = 0..n-1, one lane step (`lane_steps` grid steps; 128 in the kernel) apart;
 // windows of at most 6 lane steps (a 768-point segment) and ~3,000 minutes.  out6: 2n rows in the order
 // (even_0, odd_0, even_1, ...), bad_out: n.
-void emul_propagate_fast32(const double* fields, unsigned flags, const double* grav6, double ts0, double step, int lane_steps,
-                           int n, double* out6, int* bad_out)
+static void emul_fast32_run(const double* fields, unsigned flags, const double* grav6, double ts0, double step, int lane_steps,
+                            int n, double* out6, int* bad_out, bool precise)
 {
     AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
     const double dt = step * lane_steps;
@@ -170,14 +170,27 @@ void emul_propagate_fast32(const double* fields, unsigned flags, const double* g
         az_seed_fast32(f0, k1, st);
         for (int i = w0; i < w1; ++i) {
             az_f2 r[3], v[3];
-            az_sgp4_fast_step_f32<true>(k32, g, ts0 + i * dt, st, r, v);
-            bad_out[i] = win_bad ? 1 : 0;
+            if (precise) az_sgp4_fast_step_f32p<true>(k32, g, ts0 + i * dt, st, r, v);
+            else az_sgp4_fast_step_f32<true>(k32, g, ts0 + i * dt, st, r, v);
+            bad_out[i] = (win_bad || (precise && !az_fast32p_window_ok(k0, w_a, w_b))) ? 1 : 0;
             for (int j = 0; j < 3; ++j) {
                 out6[12*i + j] = r[j].x; out6[12*i + 3 + j] = v[j].x;
                 out6[12*i + 6 + j] = r[j].y; out6[12*i + 9 + j] = v[j].y;
             }
         }
     }
+}
+
+void emul_propagate_fast32(const double* fields, unsigned flags, const double* grav6, double ts0, double step, int lane_steps,
+                           int n, double* out6, int* bad_out)
+{
+    emul_fast32_run(fields, flags, grav6, ts0, step, lane_steps, n, out6, bad_out, false);
+}
+// ... and the mixed-precision step (az_sgp4_fast_step_f32p)
+void emul_propagate_fast32p(const double* fields, unsigned flags, const double* grav6, double ts0, double step, int lane_steps,
+                            int n, double* out6, int* bad_out)
+{
+    emul_fast32_run(fields, flags, grav6, ts0, step, lane_steps, n, out6, bad_out, true);
 }
 
 // the generic deep-space step as one lane of k_rows_deep runs it: per iteration the lane starts from a chunk seed (the

@@ -297,7 +297,7 @@ def test_fp32_outputs(native, orc, synth, layout):
     torch = _torch_dev()
     pairs = synth.synth_catalog(n_near=700, n_deep=60, seed=31)
     dev, cat = _dev_and_oracle(native, orc, pairs)
-    dev.set_f32_arithmetic(False)   # this test pins the "fp64 arithmetic, rounded once at the store" mode
+    dev.set_f32_arithmetic("fp64")   # this test pins the "fp64 arithmetic, rounded once at the store" mode
     times = np.arange(0.0, 500.0, 1.0)
     off = (synth.START_JD - dev.epochs) * 1440.0
     lay = native.TIME_MAJOR if layout == "time_major" else native.SAT_MAJOR
@@ -338,7 +338,7 @@ def test_fp32_config5_shape_properties(native, orc, synth):
     n = 4096
     pairs = synth.synth_catalog(n_near=n, n_deep=0, seed=20260927)
     dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
-    dev.set_f32_arithmetic(False)   # rounded-fp64 mode (the fp32-arithmetic mode has its own test in test_gpu_round2.py)
+    dev.set_f32_arithmetic("fp64")   # rounded-fp64 mode (the fp32-arithmetic mode has its own test in test_gpu_round2.py)
     times = np.arange(10000, dtype=np.float64)
     off = (synth.START_JD - dev.epochs) * 1440.0
     p32 = torch.empty((n, len(times), 3), dtype=torch.float32, device="cuda")

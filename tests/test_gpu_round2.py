@@ -83,7 +83,7 @@ def test_fast_path_pos_only_ecef_and_f32(native, orc, synth):
     _, q0, w0 = cat.propagate(times, off, layout=orc.SAT_MAJOR)
     p32 = torch.empty((dev.n, len(times), 3), dtype=torch.float32, device="cuda")
     v32 = torch.empty_like(p32)
-    dev.set_f32_arithmetic(False)   # fast fp64 step + rounded stores
+    dev.set_f32_arithmetic("fp64")   # fast fp64 step + rounded stores
     dev.propagate_device(times, off, p32.data_ptr(), v32.data_ptr(), layout=native.SAT_MAJOR, f32=True)
     dev.synchronize()
     assert np.abs(p32.cpu().numpy() - q0.astype(np.float32)).max() <= 2 * np.spacing(np.float32(8000.0))
@@ -121,7 +121,7 @@ def test_fp32_arithmetic_vs_oracle(native, orc, synth):
     # deep-space rows (fp64 arithmetic, rounded stores): storage precision at GEO radius
     assert dr[deep].max() < 2 * np.spacing(np.float32(45000.0))
     # the two modes agree to the same tolerance; the fp32-arithmetic one is NOT bit-identical to rounded fp64
-    dev.set_f32_arithmetic(False)
+    dev.set_f32_arithmetic("fp64")
     q32 = torch.empty_like(p32)
     dev.propagate_device(times, off, q32.data_ptr(), None, layout=native.SAT_MAJOR, f32=True)
     dev.synchronize()

@@ -19,6 +19,11 @@ F32_ROUNDED_TOL_V = 4.8e-7 * 1.01   # km/s: half an ulp of 8 km/s
 # opt-in packed-fp32 arithmetic (azh_set_f32_arithmetic(c, 1)): documented tolerance
 F32_ARITH_TOL_R = 4.0e-3
 F32_ARITH_TOL_V = 6.0e-6
+# the DEFAULT for fp32 outputs, the mixed-precision step (fast_step_f32.h, az_sgp4_fast_step_f32p): per component within 0.6 m
+# / 0.6 mm/s of the fp64 oracle -- storage-level (the half-ulp above is 0.49 m / 0.48 mm/s) and inside the reference's own
+# SIMD-vs-scalar velocity bar of 1e-6 km/s (src/Sgp4Batch.zig L186-187)
+F32_MIXED_TOL_R = 6.0e-4
+F32_MIXED_TOL_V = 6.0e-7
 
 
 @pytest.fixture(scope="module")
@@ -51,7 +56,7 @@ def _chunk_stats(t, rows_per_chunk=5000):
     return fin, rmin, rmax, chk
 
 
-@pytest.mark.parametrize("arith32", [False, True])
+@pytest.mark.parametrize("arith32", ["mixed", "packed", "fp64"])
 def test_config5_share_full_size(native, orc, synth, arith32):
     """BASELINE config 5, ONE GPU's share at full size: 125,000 synthetic satellites (seed 20260927) x 10,000 one-minute
     steps, fp32 pos+vel (2 x 15 GB) through azh_propagate_device_f32.  >= 64 rows spread over the catalog against the
@@ -80,7 +85,8 @@ def test_config5_share_full_size(native, orc, synth, arith32):
     idx = torch.as_tensor(rows, device="cuda")
     dp = np.abs(p32[idx].cpu().numpy().astype(np.float64) - p0).max()
     dv = np.abs(v32[idx].cpu().numpy().astype(np.float64) - v0).max()
-    tol_r, tol_v = (F32_ARITH_TOL_R, F32_ARITH_TOL_V) if arith32 else (F32_ROUNDED_TOL_R, F32_ROUNDED_TOL_V)
+    tol_r, tol_v = {"mixed": (F32_MIXED_TOL_R, F32_MIXED_TOL_V), "packed": (F32_ARITH_TOL_R, F32_ARITH_TOL_V),
+                    "fp64": (F32_ROUNDED_TOL_R, F32_ROUNDED_TOL_V)}[arith32]
     assert dp < tol_r and dv < tol_v, (dp, dv)
     # bit-identical repeat (cached inputs)
     dev.propagate_device_cached(p32.data_ptr(), v32.data_ptr(), layout=native.SAT_MAJOR, f32=True)
@@ -101,7 +107,7 @@ def test_bench_secondary_block(native):
     """The default bench invocation appends `secondary`: every non-headline configuration with its own timing, roofline
     fraction and oracle parity (the 30-GB config-5 share is skipped here: test_config5_share_full_size covers it)."""
     j = _bench_line(["--steps", "5", "--warmup", "2", "--precondition-ms", "0", "--no-cpu-baseline",
-                     "--secondary-skip", "config5_share,config5_share_f32arith"])
+                     "--secondary-skip", "config5_share,config5_share_f32arith,config5_share_fp64"])
     assert j["metric"].startswith("propagations/sec, 13,478 sats") and j["value"] > 0
     sec = {e["key"]: e for e in j["secondary"]}
     want = {"config2_pos_only", "config2_time_major", "config2_ecef_time_major", "config2_ecef_sat_major",

@@ -287,6 +287,7 @@ def emul():
     E.emul_propagate.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     E.emul_propagate_fast.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     E.emul_propagate_fast32.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    E.emul_propagate_fast32p.argtypes = E.emul_propagate_fast32.argtypes
     E.emul_propagate_deep_cached.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     E.emul_sincos.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
     E.emul_rcp.restype = C.c_double

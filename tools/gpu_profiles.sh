@@ -12,5 +12,6 @@ run r03_config2_ecef_sat_major -- --mode ecef
 run r03_config2_ecef_time_major -- --layout time --mode ecef
 run r03_config5_share --pmc --steps 10 -- --config5-share
 run r03_config5_share_f32arith --pmc --steps 10 -- --config5-share --f32-arith
+run r03_config5_share_fp64 --pmc --steps 10 -- --config5-share --f32-fp64
 cp $P/r03_config2_sat_major.json $P/latest_pmc.json
 ls -la $P | tail -20
