@@ -46,7 +46,7 @@ AZ_DEVICE az_f2 az_cvt2(double a, double b) { az_f2 r; r.x = (float)a; r.y = (fl
 #define AZ_F32_ONCE(X) \
     X(cc1) X(d2) X(d3) X(d4) X(nl2) X(nl3) X(nl4) X(nl5) X(eta) X(omgcof) X(xmcof) X(xd) X(bc4) X(bc5) X(ecb) X(aycof) \
     X(xlcof) X(xnodcf) X(k_mrt) X(k_c2u) X(k_su) X(k_node) X(k_inc) X(k_rv) X(nodedot) X(sinio) X(cosio) X(sOc) X(cOc)
-#define AZ_F32_MANY(X) X(x1mth2) X(sdA32) X(cdA32) X(sdW32) X(cdW32) X(step1)
+#define AZ_F32_MANY(X) X(x1mth2) X(sdA32) X(cdA32) X(sdW32) X(cdW32) X(step1) X(inv_sab32) X(abase32) X(rv0_32)
 enum Fast32Once {
 #define X(n) F32_##n,
     AZ_F32_ONCE(X)
@@ -58,7 +58,7 @@ struct FastK32Doubles {
     double sdU, cdU, tc, tmid;          // the increment of U over one lane step, window centres
     double s1U, c1U;                    // the increment of U over ONE grid step (even -> odd point)
     // the mixed-precision step (az_sgp4_fast_step_f32p) keeps the orientation chain in fp64: its starting pairs
-    double inv_sab64, sOc64, cOc64, sinio64, cosio64;
+    double abase_km64, rv0_64, sOc64, cOc64, sinio64, cosio64; // a_base radius_km, vkmpersec / sqrt(a_base), starting pairs
 };
 // everything in registers (host emulation, set-up)
 struct FastK32 : FastK32Doubles {
@@ -93,7 +93,7 @@ struct FastCarry32 {
 
 // k: constants with the increments of one LANE step (two grid points x 64 lanes = 128 grid steps);
 // k1: the same satellite's constants with the increments of ONE grid step; step1: the grid step in minutes
-AZ_DEVICE void az_load_fast32(const FastK &k, const FastK &k1, double step1, FastK32 &f)
+AZ_DEVICE void az_load_fast32(const FastK &k, const FastK &k1, double step1, const AzGrav &g, FastK32 &f)
 {
 #define X(n) f.n##_ = (float)k.n##_;
     AZ_F32_ONCE(X)
@@ -102,7 +102,12 @@ AZ_DEVICE void az_load_fast32(const FastK &k, const FastK &k1, double step1, Fas
     f.sab64 = k.sab_;
     f.sdU = k.sdU_; f.cdU = k.cdU_; f.tc = k.tc_; f.tmid = k.tmid_;
     f.s1U = k1.sdU_; f.c1U = k1.cdU_;
-    f.inv_sab64 = 1.0 / k.sab_; f.sOc64 = k.sOc_; f.cOc64 = k.cOc_; f.sinio64 = k.sinio_; f.cosio64 = k.cosio_;
+    {
+        const double inv_sab = 1.0 / k.sab_, abase = k.sab_ * k.sab_;
+        f.abase_km64 = abase * g.radius_km; f.rv0_64 = g.vkmpersec * inv_sab;
+        f.inv_sab32_ = (float)inv_sab; f.abase32_ = (float)abase; f.rv0_32_ = (float)f.rv0_64;
+    }
+    f.sOc64 = k.sOc_; f.cOc64 = k.cOc_; f.sinio64 = k.sinio_; f.cosio64 = k.cosio_;
     f.sdA32_ = (float)k.sdA_; f.cdA32_ = (float)k.cdA_; f.sdW32_ = (float)k.sdW_; f.cdW32_ = (float)k.cdW_;
     f.step1_ = (float)step1;
 }
@@ -354,11 +359,12 @@ AZ_DEVICE void az_sgp4_fast_step_f32p(const K &k, const AzGrav &g, double ta, Fa
     em.x = fmaxf(em.x, 1.0e-6f);
     em.y = fmaxf(em.y, 1.0e-6f);
 
-    // sqrt(am) = sqrt(a_base) (1 - dev) in fp64; 1/sqrt(am) = (1/sqrt(a_base)) (1 + c1), c1 = dev + dev^2 + dev^3 + dev^4
-    const double sqrt_am_a = fabs(fma(-k.sab64, (double)dev.x, k.sab64)), sqrt_am_b = fabs(fma(-k.sab64, (double)dev.y, k.sab64));
+    // am = a_base (1 - dev)^2; 1/sqrt(am) = (1/sqrt(a_base)) (1 + c1), c1 = dev + dev^2 + dev^3 + dev^4.  Both enter the
+    // results as a per-satellite fp64 constant plus a SMALL fp32 correction (below): a_base, vkmpersec / sqrt(a_base)
     const az_f2 c1 = dev * az_fma2(dev, az_fma2(dev, az_fma2(dev, az_splat2(1.0f), 1.0f), 1.0f), 1.0f);
-    const double ra_a = fma(k.inv_sab64, (double)c1.x, k.inv_sab64), ra_b = fma(k.inv_sab64, (double)c1.y, k.inv_sab64);
-    const az_f2 ra = az_cvt2(ra_a, ra_b);
+    const az_f2 ra = az_fma2(k.inv_sab32(), c1, k.inv_sab32());
+    const az_f2 omd = az_splat2(1.0f) - dev;
+    const az_f2 am = (k.abase32() * omd) * omd;
     const az_f2 omem2 = az_fma2(-em, em, 1.0f);
     const az_f2 inv_am = ra * ra;
     const az_f2 temp = inv_am * az_rcp2(omem2);
@@ -366,41 +372,25 @@ AZ_DEVICE void az_sgp4_fast_step_f32p(const K &k, const AzGrav &g, double ta, Fa
     const az_f2 axnl = em * cw;
     const az_f2 aynl = az_fma2(em, sw, k.aycof() * temp);
 
-    // ---- the U pairs of the two grid points, fp64
-    double s_a = st.sU, c_a = st.cU;
-    double s_b = fma(st.sU, k.c1U, st.cU * k.s1U), c_b = fma(st.cU, k.c1U, -(st.sU * k.s1U));
-    az_f2 p, q;
-    {
-        const az_f2 eps = az_fma2(k.xlcof() * temp, axnl, nl);
-        az_pq32_med(eps, p, q);
-        az_rot_apply_mixed(s_a, c_a, p.x, q.x);
-        az_rot_apply_mixed(s_b, c_b, p.y, q.y);
-    }
+    // ---- the U pairs of the two grid points, fp64; fp32 copies carry the chain U -> E -> u for the SMALL terms, and the
+    // angles of that chain are summed: ONE rotation takes each fp64 pair from U to u + (short-period correction)
+    const double sU_a = st.sU, cU_a = st.cU;
+    const double sU_b = fma(st.sU, k.c1U, st.cU * k.s1U), cU_b = fma(st.cU, k.c1U, -(st.sU * k.s1U));
+    az_f2 s = az_cvt2(sU_a, sU_b), c = az_cvt2(cU_a, cU_b);
+    const az_f2 eps = az_fma2(k.xlcof() * temp, axnl, nl);
+    az_rot32_med(s, c, eps);
     // Kepler, near-circular: Newton step from E0 = u, then the chord step with the same reciprocal (first order)
     const az_f2 el2 = az_fma2(axnl, axnl, aynl * aynl);
-    az_f2 s = az_cvt2(s_a, s_b), c = az_cvt2(c_a, c_b);
     const az_f2 rden = az_rcp2(az_fma2(-s, aynl, az_fma2(-c, axnl, 1.0f)));
     const az_f2 d0 = az_fma2(axnl, s, -(aynl * c)) * rden;
+    az_rot32_small(s, c, d0);
+    const az_f2 d1 = az_fma2(axnl, s, az_fma2(-aynl, c, -d0)) * rden; // <= (el/2) d0^2 = 3.4e-8 rad: a quarter of a metre
     {
-        const az_f2 d2 = d0 * d0;                       // |d0| <= 0.0041: sin to d^3 (d^5/120 < 1e-14), cos to d^4
-        p = az_fma2((-1.0f / 6.0f) * d2, d0, d0);
-        q = d2 * az_fma2(1.0f / 24.0f, d2, -0.5f);
-        az_rot_apply_mixed(s_a, c_a, p.x, q.x);
-        az_rot_apply_mixed(s_b, c_b, p.y, q.y);
-        const az_f2 ns = az_fma2(c, p, az_fma2(s, q, s)); // the fp32 copies follow (they only feed small terms)
-        c = az_fma2(-s, p, az_fma2(c, q, c));
+        const az_f2 ns = az_fma2(c, d1, s);
+        c = az_fma2(-s, d1, c);
         s = ns;
     }
-    {
-        const az_f2 d1 = az_fma2(axnl, s, az_fma2(-aynl, c, -d0)) * rden; // <= (el/2) d0^2 = 3.4e-8 rad: a quarter of a metre
-        const double d1a = (double)d1.x, d1b = (double)d1.y;
-        const double nsa = fma(c_a, d1a, s_a), nsb = fma(c_b, d1b, s_b);
-        c_a = fma(-s_a, d1a, c_a);
-        c_b = fma(-s_b, d1b, c_b);
-        s_a = nsa;
-        s_b = nsb;
-    }
-    const az_f2 ecose = az_fma2(axnl, c, aynl * s);   // (the chord step moves them by el d1 < 2e-10)
+    const az_f2 ecose = az_fma2(axnl, c, aynl * s);
     const az_f2 esine = az_fma2(axnl, s, -(aynl * c));
     // 1/(1 - ecose) = 1 + y, y = w + w^2 + w^3 + w^4, |w| <= 0.0041 (w^5 < 1.2e-12)
     const az_f2 y = ecose * az_fma2(ecose, az_fma2(ecose, az_fma2(ecose, az_splat2(1.0f), 1.0f), 1.0f), 1.0f);
@@ -409,47 +399,54 @@ AZ_DEVICE void az_sgp4_fast_step_f32p(const K &k, const AzGrav &g, double ta, Fa
     const az_f2 inv_1pb = az_fma2(0.125f, el2, 0.5f);
     const az_f2 est = esine * inv_1pb;
     const az_f2 tA = az_fma2(axnl, est, aynl), tB = az_fma2(aynl, est, -axnl);
-    // sin u, cos u in fp64: (s - tA)(1 + y), (c + tB)(1 + y)
-    double sinu_a, cosu_a, sinu_b, cosu_b;
+    // (sin u, cos u) = (s - tA, c + tB) / (1 - ecose) is (s, c) rotated by u - E: sin(u - E) = -(tA c + tB s)(1 + y)
+    // (a few 1e-3: the fp32 value is good to 5e-10 rad); the fp32 copies feed sin 2u / cos 2u, which only scale J2 terms
+    const az_f2 p2 = -(az_fma2(tA, c, tB * s)) * (az_splat2(1.0f) + y);
+    const az_f2 d_ue = az_fma2((1.0f / 6.0f) * p2 * p2, p2, p2);     // asin(p2), |p2| <= 0.0082
     {
-        const double ya = (double)y.x, yb = (double)y.y;
-        const double da = s_a - (double)tA.x, db = s_b - (double)tA.y, ea = c_a + (double)tB.x, eb = c_b + (double)tB.y;
-        sinu_a = fma(da, ya, da); sinu_b = fma(db, yb, db);
-        cosu_a = fma(ea, ya, ea); cosu_b = fma(eb, yb, eb);
+        const az_f2 ds = s - tA, dc = c + tB;
+        s = az_fma2(ds, y, ds);
+        c = az_fma2(dc, y, dc);
     }
-    const az_f2 sinu = az_cvt2(sinu_a, sinu_b), cosu = az_cvt2(cosu_a, cosu_b);
-    const az_f2 sin2u = (sinu + sinu) * cosu;
-    const az_f2 cos2u = az_fma2(-2.0f * sinu, sinu, 1.0f);
+    const az_f2 sin2u = (s + s) * c;
+    const az_f2 cos2u = az_fma2(-2.0f * s, s, 1.0f);
 
     const az_f2 inv_pl = inv_am * inv_omel2;
     const az_f2 temp1 = (float)g.half_j2 * inv_pl;
     const az_f2 temp2 = temp1 * inv_pl;
-    // radius: rl = am (1 - ecose), mrt = rl (1 + k_mrt temp2 betal) + k_c2u temp1 cos2u, fp64 with fp32 corrections
-    const az_f2 fm1 = k.k_mrt() * temp2 * (az_splat2(1.0f) + bm1);
-    const az_f2 add = k.k_c2u() * temp1 * cos2u;
-    const double rl_a = sqrt_am_a * sqrt_am_a * (1.0 - (double)ecose.x);
-    const double rl_b = sqrt_am_b * sqrt_am_b * (1.0 - (double)ecose.y);
-    const double rs_a = fma(rl_a, (double)fm1.x, rl_a + (double)add.x) * g.radius_km;
-    const double rs_b = fma(rl_b, (double)fm1.y, rl_b + (double)add.y) * g.radius_km;
-
-    // J2 short-period rotations of u, the node (with its motion across the window) and the inclination: angles and their
-    // (p,q) packed, applied in fp64
     const az_f2 t2s = temp2 * sin2u;
-    const az_f2 a_nd = az_fma2(k.k_node(), t2s, az_fma2(k.nodedot(), az_splat2((float)(ta - k.tmid)) + lane01, k.xnodcf() * t2));
-    double ssu_a = sinu_a, csu_a = cosu_a, ssu_b = sinu_b, csu_b = cosu_b;
+    // radius = a_base + [am - a_base] - am ecose + rl k_mrt temp2 betal + k_c2u temp1 cos2u (earth radii): the fp64 constant
+    // plus corrections of at most 3e-2, summed in fp32
+    az_f2 rcorr;
     {
-        const az_f2 d = k.k_su() * t2s;               // <= 9e-4: sin d = d, cos d - 1 = -d^2/2 (d^3/6 < 1.3e-10)
-        const az_f2 qq = (-0.5f * d) * d;
-        az_rot_apply_mixed(ssu_a, csu_a, d.x, qq.x);
-        az_rot_apply_mixed(ssu_b, csu_b, d.y, qq.y);
+        const az_f2 rl = az_fma2(-am, ecose, am);
+        const az_f2 fm1 = k.k_mrt() * temp2 * (az_splat2(1.0f) + bm1);
+        rcorr = az_fma2(rl, fm1, (k.k_c2u() * temp1) * cos2u);
+        rcorr = az_fma2(-am, ecose, rcorr);
+        rcorr = az_fma2(k.abase32() * dev, dev - az_splat2(2.0f), rcorr);
+        rcorr = rcorr * (float)g.radius_km;
     }
+    const double rs_a = k.abase_km64 + (double)rcorr.x, rs_b = k.abase_km64 + (double)rcorr.y;
+
+    // total rotation of the U pair: drag / long-period term, the two Kepler corrections, u - E, the J2 correction of u
+    az_f2 p, q;
+    {
+        const az_f2 theta = eps + ((d0 + d1) + (d_ue + k.k_su() * t2s));
+        az_pq32_med(theta, p, q);
+    }
+    double ssu_a = sU_a, csu_a = cU_a, ssu_b = sU_b, csu_b = cU_b;
+    az_rot_apply_mixed(ssu_a, csu_a, p.x, q.x);
+    az_rot_apply_mixed(ssu_b, csu_b, p.y, q.y);
+
+    // node (with its motion across the window) and inclination: per-window / per-satellite fp64 pairs rotated by small angles
+    const az_f2 a_nd = az_fma2(k.k_node(), t2s, az_fma2(k.nodedot(), az_splat2((float)(ta - k.tmid)) + lane01, k.xnodcf() * t2));
     double sn_a = k.sOc64, cn_a = k.cOc64, sn_b = k.sOc64, cn_b = k.cOc64;
     az_pq32_med(a_nd, p, q);
     az_rot_apply_mixed(sn_a, cn_a, p.x, q.x);
     az_rot_apply_mixed(sn_b, cn_b, p.y, q.y);
     double si_a = k.sinio64, ci_a = k.cosio64, si_b = k.sinio64, ci_b = k.cosio64;
     {
-        const az_f2 d = k.k_inc() * temp2 * cos2u;
+        const az_f2 d = k.k_inc() * temp2 * cos2u;     // <= 9e-4: sin d = d, cos d - 1 = -d^2/2 (d^3/6 < 1.3e-10)
         const az_f2 qq = (-0.5f * d) * d;
         az_rot_apply_mixed(si_a, ci_a, d.x, qq.x);
         az_rot_apply_mixed(si_b, ci_b, d.y, qq.y);
@@ -461,14 +458,15 @@ AZ_DEVICE void az_sgp4_fast_step_f32p(const K &k, const AzGrav &g, double ta, Fa
     r[1] = az_cvt2(rs_a * uy_a, rs_b * uy_b);
     r[2] = az_cvt2(rs_a * uz_a, rs_b * uz_b);
     if (VEL) {
-        // rvdot = rv (1 + y)(1 + bm1) + nxt (x1mth2 cos2u + k_rv), rv = vkmpersec / sqrt(am): the O(7.5 km/s) part in fp64
-        const double rv_a = ra_a * g.vkmpersec, rv_b = ra_b * g.vkmpersec;
-        const az_f2 rv32 = (float)g.vkmpersec * ra;
+        // rvdot = rv (1 + y)(1 + bm1) + nxt (x1mth2 cos2u + k_rv), rv = (vkmpersec / sqrt(a_base)) (1 + c1): the fp64 constant
+        // plus corrections of a few per cent, summed in fp32
+        const az_f2 rv32 = az_fma2(k.rv0_32(), c1, k.rv0_32());
         const az_f2 zz = az_fma2(y, bm1, y + bm1);
         const az_f2 nxt = rv32 * inv_am * temp1;
-        const az_f2 gg = nxt * az_fma2(k.x1mth2(), cos2u, k.k_rv());
+        az_f2 vcorr = az_fma2(rv32, zz, nxt * az_fma2(k.x1mth2(), cos2u, k.k_rv()));
+        vcorr = az_fma2(k.rv0_32(), c1, vcorr);
         const az_f2 mvt = az_fma2(-k.x1mth2() * nxt, sin2u, rv32 * (az_splat2(1.0f) + y) * esine); // <= 0.03 km/s
-        const double rvdot_a = fma(rv_a, (double)zz.x, rv_a) + (double)gg.x, rvdot_b = fma(rv_b, (double)zz.y, rv_b) + (double)gg.y;
+        const double rvdot_a = k.rv0_64 + (double)vcorr.x, rvdot_b = k.rv0_64 + (double)vcorr.y;
         const double mvt_a = (double)mvt.x, mvt_b = (double)mvt.y;
         const double vx_a = fma(xmx_a, csu_a, -(cn_a * ssu_a)), vy_a = fma(xmy_a, csu_a, -(sn_a * ssu_a)), vz_a = si_a * csu_a;
         const double vx_b = fma(xmx_b, csu_b, -(cn_b * ssu_b)), vy_b = fma(xmy_b, csu_b, -(sn_b * ssu_b)), vz_b = si_b * csu_b;

@@ -1238,7 +1238,7 @@ __global__ void __launch_bounds__(64, MIXED ? AZ_ROWSF32P_WAVES : AZ_ROWSF32_WAV
                 k1.tc_ = k0.tc_; k1.tmid_ = k0.tmid_; k1.sOc_ = k0.sOc_; k1.cOc_ = k0.cOc_;
             }
             FastK32 kk;
-            az_load_fast32(k0, k1, step, kk);
+            az_load_fast32(k0, k1, step, p.g, kk);
 #define X(n) if (lane == 0) once_lds[F32_##n] = kk.n##_;
             AZ_F32_ONCE(X)
 #undef X
@@ -1247,7 +1247,7 @@ __global__ void __launch_bounds__(64, MIXED ? AZ_ROWSF32P_WAVES : AZ_ROWSF32_WAV
 #undef X
 #define U(n) k.n = az_uniform(kk.n);
             U(sab64) U(sdU) U(cdU) U(tc) U(tmid) U(s1U) U(c1U)
-            if (MIXED) { U(inv_sab64) U(sOc64) U(cOc64) U(sinio64) U(cosio64) }
+            if (MIXED) { U(abase_km64) U(rv0_64) U(sOc64) U(cOc64) U(sinio64) U(cosio64) }
 #undef U
             az_wave_lds_fence();
             // seed one lane step (128 grid steps) BEFORE this lane's first even grid point

@@ -163,7 +163,7 @@ static void emul_fast32_run(const double* fields, unsigned flags, const double* 
         az_load_fast(fields, 1, 0, flags, inc, 1, k1);
         az_fast_window(fields, 1, 0, w_a, w_b, step, k1);
         FastK32 k32;
-        az_load_fast32(k0, k1, step, k32);
+        az_load_fast32(k0, k1, step, g, k32);
         FastCarry f0;
         az_seed_fast(fields, 1, 0, ts0 + (w0 - 1) * dt, k0.tc_, f0);
         FastCarry32 st;
