@@ -818,7 +818,9 @@ __device__ __forceinline__ AzRowSink az_row_sink(T *prow, T *vrow, unsigned n_ti
     return AzRowSink{__builtin_amdgcn_make_buffer_rsrc(prow, 0, row_bytes, 0x00020000),
                      __builtin_amdgcn_make_buffer_rsrc(vrow ? vrow : prow, 0, row_bytes, 0x00020000)};
 }
+#ifndef AZ_AUX_NT
 #define AZ_AUX_NT 2 /* cache-policy bits of the buffer builtins on gfx94x/95x: 1 = sc0, 2 = nt, 16 = sc1 */
+#endif
 template <bool VEL, class T>
 __device__ __forceinline__ void az_flush_stage(const T *stage, const AzRowSink &sink, unsigned base, unsigned lane)
 {

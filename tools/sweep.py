@@ -43,7 +43,9 @@ def run(extra):
         r = subprocess.run(cmd, capture_output=True, text=True, env=env)
         try:
             j = json.loads(r.stdout.strip().splitlines()[-1])
-            print("%-14s %7.2f Gprops/s  launch %.4f ms" % (name, j["value"] / 1e9, j["roofline"]["avg_launch_ms"]), flush=True)
+            pw = j.get("power") or {}
+            print("%-14s %7.2f Gprops/s  launch %.4f ms   %s W  %s MHz" % (name, j["value"] / 1e9, j["roofline"]["avg_launch_ms"],
+                  pw.get("socket_w_median"), pw.get("sclk_mhz_median")), flush=True)
         except Exception:
             print(name, "FAILED", r.stderr[-300:], flush=True)
 
