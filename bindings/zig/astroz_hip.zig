@@ -113,7 +113,7 @@ pub extern "c" fn azh_constellation_subset(h: ?*const Handle, indices: [*]const 
 // row windows (chunked multi-GPU pipelines), arithmetic / path switches, device-pointer one-satellite call
 pub extern "c" fn azh_propagate_device_window(h: ?*Handle, row_lo: usize, row_hi: usize, d_pos: [*]f64, d_vel: ?[*]f64, layout: i32,
     out_stride_sats: usize, d_err: ?[*]u8, stream: ?*anyopaque) i32;
-pub extern "c" fn azh_set_f32_arithmetic(h: ?*Handle, enabled: i32) i32;
+pub extern "c" fn azh_set_f32_arithmetic(h: ?*Handle, mode: i32) i32; // 0 mixed precision (default), 1 packed fp32, 2 fp64 rounded at the store
 pub extern "c" fn azh_set_fast_path(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_set_tile_kernel(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_propagate_one_device(h: ?*Handle, sat_index: usize, d_tsince_min: [*]const f64, n: usize, d_pos: [*]f64,

@@ -210,15 +210,19 @@ int32_t azh_propagate_device_window(azh_constellation *c, size_t row_lo, size_t 
                                     int32_t layout, size_t out_stride_sats, uint8_t *d_err, void *stream);
 /* fp32 OUTPUT variants (BASELINE config 5: 1M satellites x 10,000 steps would be 480 GB in fp64); d_pos/d_vel
  * are float arrays of the same shapes.  No reference counterpart (astroz is fp64 only).  Arithmetic:
- *   default                      fp64 arithmetic throughout, every component rounded ONCE when it is stored: the result is
- *                                float32(fp64 result), half an fp32 ulp from the fp64 path (0.25 m, 0.24 mm/s in LEO);
- *   azh_set_f32_arithmetic(c,1)  opt-in: packed fp32 arithmetic with fp64 phase and radius chains
- *                                (astroz_amd/csrc/fast_step_f32.h) for near-circular members on uniform grids,
- *                                satellite-major TEME -- 1.6x the rate of the default, positions within 4 m and velocities
- *                                within 6 mm/s of the fp64 result (measured 2.4 m / 4.0 mm/s over 10,000-minute spans; the
- *                                reference's own SIMD-vs-scalar bar is 1 mm/s, which fp32 ARITHMETIC cannot meet: one fp32
- *                                rounding of a 7.5 km/s component is already 0.24 mm/s).  Everything else as the default. */
-int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t enabled);
+ *   mode 0 (default)  mixed precision for near-circular members on uniform grids, satellite-major TEME
+ *                     (astroz_amd/csrc/fast_step_f32.h, az_sgp4_fast_step_f32p): every O(1) quantity -- the along-track
+ *                     phase pair and the rotation applied to it, node and inclination pairs, orientation, radius, speed --
+ *                     in fp64 per grid point, everything small in packed fp32 for two grid points at once.  Within 0.6 m /
+ *                     0.6 mm/s per component of the fp64 result (measured 0.35 m / 0.39 mm/s over 10,000-minute spans):
+ *                     the level of fp32 storage itself (half an ulp is 0.25 m / 0.24 mm/s per component in LEO) and inside
+ *                     the reference's own SIMD-vs-scalar bar of 1 mm/s (src/Sgp4Batch.zig L186-187).  Everything else
+ *                     (eccentric and deep-space members, ECEF / geodetic, irregular grids) as mode 2.
+ *   mode 1            opt-in: packed fp32 arithmetic with fp64 phase and radius chains for the same members -- 1.15x the
+ *                     rate of mode 0, positions within 4 m and velocities within 6 mm/s (measured 2.4 m / 4.0 mm/s).
+ *   mode 2            fp64 arithmetic throughout, every component rounded ONCE when it is stored: float32(fp64 result).
+ * Returns AZ_ERR_VALUE for any other mode. */
+int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t mode);
 int32_t azh_propagate_device_f32(azh_constellation *c, const double *times_min, size_t n_times,
                                  const double *epoch_offsets_min, float *d_pos, float *d_vel, int32_t output_mode,
                                  double reference_jd, const uint8_t *sat_mask, int32_t layout,
