@@ -212,20 +212,25 @@ class SatrecArray:
 
     def sgp4_device(self, jd, fr, *, velocities=True, stream=None):
         """Same computation, results left resident in HBM: returns torch tensors on the GPU
-        (e (n_sats,n_times) uint8, r_tm, v_tm (n_times, n_sats, 3) float64).  Asynchronous with
+        (e (n_sats,n_times) uint8, r_tm, v_tm (n_times, n_sats, 3) float64: views of arrays whose time rows are padded to
+        16 satellites).  Asynchronous with
         respect to the host; ordered on the constellation's stream (or `stream`)."""
         import torch
 
         times, offsets = self._grid(jd, fr)
         n_times, n_sats = len(times), self._num_sats
         dev = torch.device("cuda", self._device)  # the device the element table lives on
-        r_tm = torch.empty((n_times, n_sats, 3), dtype=torch.float64, device=dev)
-        v_tm = torch.empty((n_times, n_sats, 3), dtype=torch.float64, device=dev) if velocities else None
+        # time rows padded to a multiple of 16 satellites (384 bytes = three whole 128-byte lines): every run of the
+        # time-major tile kernel then starts on a line boundary and leaves as streaming stores (DESIGN.md 4, k_tiles_fast:
+        # 0.27 instead of 0.29 ms for config 2); the caller sees (n_times, n_sats, 3) views of the padded arrays
+        stride = (n_sats + 15) // 16 * 16
+        r_tm = torch.empty((n_times, stride, 3), dtype=torch.float64, device=dev)
+        v_tm = torch.empty((n_times, stride, 3), dtype=torch.float64, device=dev) if velocities else None
         e = torch.empty((n_sats, n_times), dtype=torch.uint8, device=dev)
         torch.cuda.current_stream(dev).synchronize()  # allocations visible before a foreign stream writes
         self._dev.propagate_device(times, offsets, r_tm.data_ptr(), None if v_tm is None else v_tm.data_ptr(),
-                                   layout=_native.TIME_MAJOR, d_err=e.data_ptr(), stream=stream)
-        return e, r_tm, v_tm
+                                   layout=_native.TIME_MAJOR, stride=stride, d_err=e.data_ptr(), stream=stream)
+        return e, r_tm[:, :n_sats], (None if v_tm is None else v_tm[:, :n_sats])
 
     def synchronize(self):
         self._dev.synchronize()

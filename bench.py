@@ -241,7 +241,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
         return e0.elapsed_time(e1) / steps
 
     def case(key, workload, kernel, dev, pairs, n_times, *, layout, vel=True, f32=False, mode=0, steps=50, warm=20,
-             cold=False, rows=16, ref_jd=0.0, arith32=False):
+             cold=False, rows=16, ref_jd=0.0, arith32=False, stride_align=0):
         if key in skip:
             return
         ent = {"key": key, "workload": workload, "kernel": kernel}
@@ -250,14 +250,15 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             dev.set_f32_arithmetic(arith32)
             times = np.arange(n_times, dtype=np.float64)
             offs = (synth.START_JD - dev.epochs) * 1440.0
-            shape = (n_times, n, 3) if layout == _native.TIME_MAJOR else (n, n_times, 3)
+            stride = (n + stride_align - 1) // stride_align * stride_align if (stride_align and layout == _native.TIME_MAJOR) else n
+            shape = (n_times, stride, 3) if layout == _native.TIME_MAJOR else (n, n_times, 3)
             odt = torch.float32 if f32 else torch.float64
             pos = torch.empty(shape, dtype=odt, device=cuda)
             v = torch.empty(shape, dtype=odt, device=cuda) if vel else None
             pp, vp = pos.data_ptr(), (v.data_ptr() if vel else None)
-            dev.propagate_device(times, offs, pp, vp, mode=mode, reference_jd=ref_jd, layout=layout, stream=sptr, f32=f32)
+            dev.propagate_device(times, offs, pp, vp, mode=mode, reference_jd=ref_jd, layout=layout, stride=(stride if layout == _native.TIME_MAJOR else 0), stream=sptr, f32=f32)
             torch.cuda.synchronize()
-            ms = timed(lambda: dev.propagate_device_cached(pp, vp, layout=layout, stream=sptr, f32=f32), warm, steps)
+            ms = timed(lambda: dev.propagate_device_cached(pp, vp, layout=layout, stride=(stride if layout == _native.TIME_MAJOR else 0), stream=sptr, f32=f32), warm, steps)
             props = n * n_times
             nbytes = props * (BYTES_OUT_PV if vel else BYTES_OUT_P) * (0.5 if f32 else 1.0) + n_times * 8 + n * ELEM_BYTES_PER_SAT
             ent.update({"ms_per_step": ms, "value": props / (ms / 1e3), "unit": "propagations/s", "steps": steps, "warmup": warm,
@@ -272,13 +273,13 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
                     tj = times + 0.25 * (j + 1)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    dev.propagate_device(tj, offs, pp, vp, mode=mode, reference_jd=ref_jd, layout=layout, stream=sptr, f32=f32)
+                    dev.propagate_device(tj, offs, pp, vp, mode=mode, reference_jd=ref_jd, layout=layout, stride=(stride if layout == _native.TIME_MAJOR else 0), stream=sptr, f32=f32)
                     torch.cuda.synchronize()
                     cs.append((time.perf_counter() - t0) * 1e3)
                 ent["cold_grid_call_ms"] = {"median": sorted(cs)[len(cs) // 2], "min": min(cs),
                                             "what": "first call on a new time grid: H2D staging + k_prep_inc + k_deep_seed + the step, "
                                                     "host wall clock incl. the final synchronize"}
-                dev.propagate_device(times, offs, pp, vp, mode=mode, reference_jd=ref_jd, layout=layout, stream=sptr, f32=f32)
+                dev.propagate_device(times, offs, pp, vp, mode=mode, reference_jd=ref_jd, layout=layout, stride=(stride if layout == _native.TIME_MAJOR else 0), stream=sptr, f32=f32)
                 torch.cuda.synchronize()
             # parity on sampled rows, all times
             rws = _sample_rows(n, rows)
@@ -310,6 +311,9 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
          "k_rows_fast<pos> + redo", dev2, pairs2, 1440, layout=SM, vel=False)
     case("config2_time_major", "config 2, TIME-major output (the reference benchmark's physical layout, api.py L304-314), fp64 TEME pos+vel",
          "k_tiles_fast<pos+vel> + redo", dev2, pairs2, 1440, layout=TM)
+    case("config2_time_major_aligned", "config 2, TIME-major output with the time rows padded to a multiple of 16 satellites (out_stride_sats = "
+         "13,488: every 384-byte tile run on whole cache lines; what SatrecArray.sgp4_device allocates), fp64 TEME pos+vel",
+         "k_tiles_fast<pos+vel> (streaming flush) + redo", dev2, pairs2, 1440, layout=TM, stride_align=16)
     case("config2_ecef_time_major", "config 2, ECEF time-major (the default of the reference's high-level propagate(), "
          "Constellation.zig L489-506), fp64 pos+vel", "k_tiles_fast<pos+vel,ECEF> + redo", dev2, pairs2, 1440, layout=TM, mode=1, ref_jd=ref_jd)
     case("config2_ecef_sat_major", "config 2, ECEF satellite-major, fp64 pos+vel", "k_rows_fast<pos+vel,FRAME> + redo",

@@ -110,7 +110,7 @@ def test_bench_secondary_block(native):
                      "--secondary-skip", "config5_share,config5_share_f32arith,config5_share_fp64"])
     assert j["metric"].startswith("propagations/sec, 13,478 sats") and j["value"] > 0
     sec = {e["key"]: e for e in j["secondary"]}
-    want = {"config2_pos_only", "config2_time_major", "config2_ecef_time_major", "config2_ecef_sat_major",
+    want = {"config2_pos_only", "config2_time_major", "config2_time_major_aligned", "config2_ecef_time_major", "config2_ecef_sat_major",
             "config2_geodetic_time_major", "config3_sat_major", "config3_time_major", "one_satellite", "fused_screen"}
     assert want <= set(sec), sorted(sec)
     for k in want:
@@ -129,6 +129,9 @@ def test_bench_secondary_block(native):
         if "max_abs_dv_kms" in par:
             assert par["max_abs_dv_kms"] < 1e-9, (k, par)
     assert sec["config3_sat_major"]["cold_grid_call_ms"]["median"] > 0
+    ing = sec["ingest"]
+    assert "failed" not in ing and ing["n_sats"] == 13478 and ing["ms_per_step"] > 0
+    assert ing["reader_1M"]["threads"]["records"] == 13478 * 75 == ing["reader_1M"]["text_to_device"]["records"]
 
 
 def test_bench_config4_reports_three_points(native):
