@@ -8,11 +8,13 @@
 //     one angle addition (4 FMA-class instructions, no polynomial, no vote);
 //   * every small angle sits inside its usual rotation tier, and the orbit is either near-circular
 //     (el^2 < 1.6e-5: the two-step Kepler form) or, ECC = true, converges in five Newton trips with fixed tiers.
-// Instead of choosing tiers with wave votes and branches the step runs straight through and RETURNS a
-// per-lane `bad` predicate; the caller votes once per step and, on a violation, hands the remaining
-// grid points to the generic az_sgp4_step loop (results are only stored after the vote, so nothing
-// wrong ever reaches memory).  ~210 fp64 instructions per propagation against ~300 executed by the
-// generic loop (whose tier votes cost compares, branches and the register moves at every merge).
+// Instead of choosing tiers with wave votes and branches the step runs straight through.  Its assumptions are bounded
+// once per time WINDOW from the satellite's constants alone (az_fast_window_ok: rigorous bounds on every tiered angle,
+// on el^2 and on the J2 factor over the whole window; evaluated per staged grid by k_plan_windows), so a window that
+// passes needs no per-step check; the eccentric form additionally RETURNS a per-lane `bad` predicate for its Newton
+// iteration, on which the caller votes and hands the remaining grid points to the generic az_sgp4_step loop (results
+// are only stored after the vote, so nothing wrong ever reaches memory).  197 fp64 instructions per propagation against
+// ~300 executed by the generic loop (whose tier votes cost compares, branches and the register moves at every merge).
 #pragma once
 #include "propagate_device.h"
 

@@ -1,5 +1,8 @@
-// fast_step_f32.h -- the branch-free uniform-grid step (fast_step.h) in fp32 arithmetic, for fp32 OUTPUTS
+// fast_step_f32.h -- the branch-free uniform-grid step (fast_step.h) for fp32 OUTPUTS, two grid points per lane
 // (BASELINE config 5: 1M satellites x 10,000 steps, an HBM-bound stress case; the reference itself is fp64 only).
+// Two steps: az_sgp4_fast_step_f32 (packed fp32 arithmetic with fp64 islands, opt-in: metres / mm/s; described first) and,
+// at the end of the file, az_sgp4_fast_step_f32p (mixed precision, the default: every O(1) quantity in fp64, the small ones
+// in packed fp32 -- the accuracy of fp32 storage itself).
 //
 // TWO grid points per lane.  On gfx950 a plain v_fma_f32 issues at the same rate as v_fma_f64 (one wave instruction
 // per four cycles); the fp32 vector peak (157 TFLOP/s, twice the fp64 one) belongs to the PACKED forms v_pk_fma_f32 /

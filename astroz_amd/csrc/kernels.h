@@ -743,7 +743,7 @@ __device__ __forceinline__ void az_fill_fast_table(double *table, const double *
 }
 __device__ __forceinline__ ColdBroadcast ColdBroadcast::fresh() const { return ColdBroadcast{p, az_opaque_lds(m)}; }
 #ifndef AZ_ROWSF_WAVES
-#define AZ_ROWSF_WAVES 6 /* k_rows_fast, near-circular Kepler form: 68 VGPRs (7 waves/SIMD fit) */
+#define AZ_ROWSF_WAVES 6 /* k_rows_fast, near-circular Kepler form: 74 VGPRs; forced to 7 (70 VGPRs) or 8 (64 + spills) it measures slower */
 #endif
 #ifndef AZ_ROWSF32_WAVES
 #define AZ_ROWSF32_WAVES 4 /* k_rows_fast32: two grid points per lane */
@@ -871,12 +871,14 @@ __device__ __forceinline__ void az_rows_store(bool staged, bool full, bool live,
 }
 
 // Near-earth rows on a UNIFORM grid: the branch-free step of fast_step.h, one wave per (satellite row, time
-// segment), lane = time.  78 VGPRs (6 waves/SIMD; the generic k_rows needs 135 = 3): the 18 hot constants sit in
-// SGPRs, the 16 once-per-step ones in LDS (broadcast reads), time is t0 + i*step (no staging, no loads in the
+// segment), lane = time.  74 VGPRs (6 waves/SIMD; the generic k_rows needs 135 = 3).  The satellite's constants come
+// from its fast record (k_prep_rec): the 23 hot ones by scalar loads into SGPRs, the 16 once-per-step ones and the
+// polynomial coefficients by one vector load into the wave's LDS table (broadcast reads); the window's constants and the
+// verdict of the validation bounds from the plan (k_plan_windows); time is t0 + i*step (no staging, no loads in the
 // loop).  Two instantiations, launched on the host's two near-earth lists: ECC = false for eccentricity class 0
-// (near-circular Kepler form), ECC = true for the other classes (general form).  A wave whose validation vote
-// fails -- an angle outside its tier, a Newton iteration that needs more than five trips -- appends the rest of its
-// segment to the redo list and exits; the generic kernel runs that list afterwards.
+// (near-circular Kepler form), ECC = true for the other classes (general form).  A window the plan rejected is already an
+// item of the redo list and its wave exits at once; a wave of the eccentric form whose Newton iteration needs more than
+// its five fixed-tier trips appends the rest of its segment to that list; the generic kernel runs the list beside the bulk.
 // FRAME: 0 TEME, 1 ECEF, 2 geodetic (compile-time: the geodetic conversion's registers stay out of the ECEF kernel).  The
 // (sin,cos) of the Greenwich angle of this wave's whole segment (the host keeps FRAME segments at AZ_FRAME_SEG points)
 // are staged in LDS before the loop: no table load inside it (round 2's FRAME kernels loaded two doubles per iteration,
@@ -894,7 +896,6 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
     const unsigned row = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (row >= p.n_list) return;
     const unsigned s = p.list[row]; // wave-uniform
-    const unsigned fl = p.flags[s];
     if (SINK != AZ_SINK_SCREEN && ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi)) return;
     const unsigned t_lo = blockIdx.y * p.tile;
     if (t_lo >= p.n_times) return; // (the screen launches both forms on one grid: the finer tiling decides its height)
