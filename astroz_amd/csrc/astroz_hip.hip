@@ -188,11 +188,11 @@ void destroy(azh_constellation *c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
     if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
-    if (c->s_ecc) (void)hipStreamDestroy(c->s_ecc);
+    if (c->s_ecc && c->s_ecc != c->s_main) (void)hipStreamDestroy(c->s_ecc);
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
+    if (c->s_deep && c->s_deep != c->s_main) (void)hipStreamDestroy(c->s_deep);
     if (c->s_main) (void)hipStreamDestroy(c->s_main);
-    if (c->s_deep) (void)hipStreamDestroy(c->s_deep);
     delete c;
 }
 
@@ -219,9 +219,13 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
     double *d_raw = nullptr;
     do {
         if (set_device(c) != AZ_OK) { rc = AZ_ERR_HIP; break; }
+        // one launch stream + two side streams (deep-space launch; eccentric launch and redo pass beside the bulk).  A handle of
+        // a few satellites -- what sgp4_init / Satrec create, possibly by the thousand -- has nothing to overlap: its side
+        // streams ARE the launch stream (the fork / join events then order a stream with itself)
+        const bool side_streams = n > 16;
         if (!hip_ok(hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking), "hipStreamCreate") ||
-            !hip_ok(hipStreamCreateWithFlags(&c->s_deep, hipStreamNonBlocking), "hipStreamCreate") ||
-            !hip_ok(hipStreamCreateWithFlags(&c->s_ecc, hipStreamNonBlocking), "hipStreamCreate") ||
+            (side_streams && (!hip_ok(hipStreamCreateWithFlags(&c->s_deep, hipStreamNonBlocking), "hipStreamCreate") ||
+                              !hip_ok(hipStreamCreateWithFlags(&c->s_ecc, hipStreamNonBlocking), "hipStreamCreate"))) ||
             !hip_ok(hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate") ||
@@ -230,6 +234,7 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
             rc = AZ_ERR_HIP;
             break;
         }
+        if (!side_streams) c->s_deep = c->s_ecc = c->s_main;
         const size_t np = c->n_pad;
         if (!hip_ok(hipMalloc((void **)&c->d_el, sizeof(double) * AZ_NUM_FIELDS * np), "hipMalloc(el)") ||
             !hip_ok(hipMalloc((void **)&c->d_flags, sizeof(unsigned) * np), "hipMalloc(flags)") ||

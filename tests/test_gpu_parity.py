@@ -251,6 +251,37 @@ def test_c_api_surface(native, golden):
     L.tle_free(h)
 
 
+def test_many_single_satellite_handles(native, orc, synth):
+    """python-sgp4 style use: one handle per satellite, hundreds alive at once (Satrec.twoline2rv + sgp4 in a loop,
+    sgp4_init per TLE in a C host).  A few-satellite handle shares one stream for all its launches; every handle
+    propagates correctly (near-earth and deep-space members, a uniform grid through the fast kernels) and frees cleanly."""
+    import time
+    from astroz_amd.api import Satrec, WGS72
+    pairs = synth.synth_catalog(n_near=270, n_deep=30, seed=5)
+    t0 = time.perf_counter()
+    sats = [Satrec.twoline2rv(a, b, WGS72) for a, b in pairs]
+    jd0 = synth.START_JD
+    outs = [s.sgp4(jd0, 0.25) for s in sats]            # 300 live one-satellite handles
+    dt = time.perf_counter() - t0
+    cat = orc.Catalog.from_pairs(pairs, orc.WGS72)
+    for i, (e, r, v) in enumerate(outs):
+        assert e == 0
+        ts = ((jd0 + 0.25) - cat.epoch_jd[i]) * 1440.0
+        _, r0, v0 = cat.propagate_one(i, ts)
+        assert np.abs(np.array(r) - r0).max() < TOL_R and np.abs(np.array(v) - v0).max() < TOL_V, i
+    # the same handles on a uniform grid (fast kernels, plan, redo pass on the shared stream)
+    jd = np.full(200, jd0)
+    fr = np.arange(200) / 1440.0
+    for i in (0, 137, 269, 270, 299):
+        e, r, v = sats[i].sgp4_array(jd, fr)
+        sub = orc.Catalog.from_pairs([pairs[i]], orc.WGS72)
+        ts = ((jd + fr) - (sats[i].jdsatepoch + sats[i].jdsatepochF)) * 1440.0   # tsince as Satrec forms it (satrec.zig L169-201)
+        _, r0, v0 = sub.propagate(ts, None, layout=orc.SAT_MAJOR)
+        assert np.abs(r - r0[0]).max() < TOL_R and np.abs(v - v0[0]).max() < TOL_V, i
+    del sats
+    assert dt < 60.0
+
+
 def test_python_api_mirror(native, orc, golden):
     """astroz_amd.api behaves like astroz.api on the reference's own usage (README L97-98;
     examples/python_sgp4.py L31-33): ISS x 1,440 one-minute steps = BASELINE config 1."""
