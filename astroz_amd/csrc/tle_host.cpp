@@ -5,7 +5,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <functional>
+#include <system_error>
 #include <thread>
 
 namespace azh {
@@ -200,10 +202,28 @@ void parse_range(std::string_view text, std::vector<TleRecord> &out)
         }
     }
 }
-unsigned g_parse_threads = 0; // 0 = automatic
+std::atomic<unsigned> g_parse_threads{0}; // 0 = automatic
+
+// tasks 0 .. n-1, task 0 on the calling thread; a task whose thread cannot be created runs on the calling thread as well
+void run_tasks(unsigned n, const std::function<void(unsigned)> &task)
+{
+    std::vector<std::thread> th;
+    th.reserve(n);
+    std::vector<unsigned> here;
+    for (unsigned k = 1; k < n; ++k) {
+        try {
+            th.emplace_back(task, k);
+        } catch (const std::system_error &) {
+            here.push_back(k);
+        }
+    }
+    if (n) task(0);
+    for (unsigned k : here) task(k);
+    for (auto &t : th) t.join();
+}
 } // namespace
 
-void set_parse_threads(unsigned n) { g_parse_threads = n; }
+void set_parse_threads(unsigned n) { g_parse_threads.store(n, std::memory_order_relaxed); }
 
 // Catalog-scale text (config 5: 10^6 TLEs = 140 MB) is cut at record boundaries and parsed by several threads.  A cut is
 // moved forward to the start of the next record line that begins with '1': whatever precedes it, the serial reader's
@@ -234,11 +254,7 @@ void parse_all(std::string_view text, std::vector<TleRecord> &out)
         cut[k] = pos;
     }
     std::vector<std::vector<TleRecord>> piece(want);
-    std::vector<std::thread> th;
-    for (unsigned k = 1; k < want; ++k)
-        th.emplace_back([&, k] { parse_range(text.substr(cut[k], cut[k + 1] - cut[k]), piece[k]); });
-    parse_range(text.substr(cut[0], cut[1] - cut[0]), piece[0]);
-    for (auto &t : th) t.join();
+    run_tasks(want, [&](unsigned k) { parse_range(text.substr(cut[k], cut[k + 1] - cut[k]), piece[k]); });
     std::vector<size_t> at(want + 1, out.size());
     for (unsigned k = 0; k < want; ++k) at[k + 1] = at[k] + piece[k].size();
     out.resize(at[want]);
@@ -251,7 +267,8 @@ void parse_all(std::string_view text, std::vector<TleRecord> &out)
 unsigned parse_threads_for(size_t bytes)
 {
     // automatic: the host's cores (at most 16), pieces of at least 256 KiB; an explicit count is honoured down to 4-KiB pieces
-    if (g_parse_threads) return (unsigned)std::min<size_t>(g_parse_threads, std::max<size_t>(1, bytes >> 12));
+    if (const unsigned forced = g_parse_threads.load(std::memory_order_relaxed))
+        return (unsigned)std::min<size_t>(forced, std::max<size_t>(1, bytes >> 12));
     const unsigned want = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     return (unsigned)std::min<size_t>(want, std::max<size_t>(1, bytes >> 18));
 }
@@ -263,10 +280,7 @@ void parallel_ranges(size_t n, unsigned threads, const std::function<void(size_t
         fn(0, n);
         return;
     }
-    std::vector<std::thread> th;
-    for (unsigned k = 1; k < threads; ++k) th.emplace_back([&, k] { fn(n * k / threads, n * (k + 1) / threads); });
-    fn(0, n / threads);
-    for (auto &t : th) t.join();
+    run_tasks(threads, [&](unsigned k) { fn(n * k / threads, n * (k + 1) / threads); });
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -217,6 +217,8 @@ def test_fp32_mixed_step_other_grids(native, orc, synth, t0, step, n_times):
     tol_r, tol_v = F32_MODES["mixed"]
     assert np.isfinite(p).all() and np.isfinite(v).all()
     assert np.linalg.norm(p - p0, axis=2).max() < tol_r and np.linalg.norm(v - v0, axis=2).max() < tol_v
+    with pytest.raises(native.NativeError):   # modes are 0 (mixed), 1 (packed), 2 (fp64 rounded)
+        dev.set_f32_arithmetic(7)
 
 
 def test_row_window_launches_tile_the_full_launch(native, synth):
