@@ -349,17 +349,19 @@ int32_t build_from_records(const std::vector<azh::TleRecord> &recs, int grav, in
 {
     std::vector<double> cols[AZ_NUM_RAW];
     for (auto &v : cols) v.resize(recs.size());
-    for (size_t i = 0; i < recs.size(); ++i) {
-        const azh::TleRecord &r = recs[i];
-        cols[R_epoch_jd][i] = r.epoch_jd;
-        cols[R_mm_revday][i] = r.mm_revday;
-        cols[R_ecc][i] = r.ecc;
-        cols[R_incl_deg][i] = r.incl_deg;
-        cols[R_raan_deg][i] = r.raan_deg;
-        cols[R_argp_deg][i] = r.argp_deg;
-        cols[R_ma_deg][i] = r.ma_deg;
-        cols[R_bstar][i] = r.bstar;
-    }
+    azh::parallel_ranges(recs.size(), azh::parse_threads_for(recs.size() * 140), [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; ++i) {
+            const azh::TleRecord &r = recs[i];
+            cols[R_epoch_jd][i] = r.epoch_jd;
+            cols[R_mm_revday][i] = r.mm_revday;
+            cols[R_ecc][i] = r.ecc;
+            cols[R_incl_deg][i] = r.incl_deg;
+            cols[R_raan_deg][i] = r.raan_deg;
+            cols[R_argp_deg][i] = r.argp_deg;
+            cols[R_ma_deg][i] = r.ma_deg;
+            cols[R_bstar][i] = r.bstar;
+        }
+    });
     return build(cols, recs.size(), grav, device, out);
 }
 
