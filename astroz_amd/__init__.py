@@ -283,5 +283,50 @@ def coarse_screen(positions, num_sats, threshold, valid_mask=None):
     return [tuple(int(x) for x in p) for p in pairs], [int(x) for x in tt]
 
 
+# ---- the four closed-form orbital scalars of the reference's module surface (bindings/python/src/main.zig L24-32 over
+# src/calculations.zig L83-125) that libastroz_hip.so carries for C clients (orbital_*): same names, arguments and error
+# behaviour.  bi_elliptic_transfer, lambert and propagate_numerical are mission analysis, off the propagation path.
+EARTH_MU = 398600.5          # km^3/s^2, WGS84 (src/constants.zig L41-52)
+EARTH_R_EQ = 6378.137        # km
+EARTH_J2 = 0.00108262998905
+
+
+def hohmann_transfer(mu, r1, r2):
+    """hohmann_transfer(mu, r1, r2) -> dict(sma, dv1, dv2, total_dv, transfer_time, transfer_time_days); ValueError for
+    non-positive radii or radii closer than 1,000 km (orbital_mechanics.zig L9-19)."""
+    import ctypes as C
+
+    class _H(C.Structure):
+        _fields_ = [(k, C.c_double) for k in ("sma", "dv1", "dv2", "total_dv", "transfer_time", "transfer_time_days")]
+    h = _H()
+    if _native.lib().orbital_hohmann(float(mu), float(r1), float(r2), C.byref(h)) != 0:
+        raise ValueError("invalid transfer parameters (radii must be positive and differ by >1000 km)")
+    return {k: getattr(h, k) for k, _ in _H._fields_}
+
+
+def orbital_velocity(mu, radius, sma=None):
+    """Vis-viva speed; circular if `sma` is omitted."""
+    v = _native.lib().orbital_velocity(float(mu), float(radius), 0.0 if sma is None else float(sma))
+    if v < 0:
+        raise ValueError("invalid radius / semi-major axis")
+    return v
+
+
+def orbital_period(mu, sma):
+    """Period in seconds (Kepler's third law)."""
+    v = _native.lib().orbital_period(float(mu), float(sma))
+    if v < 0:
+        raise ValueError("invalid semi-major axis")
+    return v
+
+
+def escape_velocity(mu, radius):
+    v = _native.lib().orbital_escape_velocity(float(mu), float(radius))
+    if v < 0:
+        raise ValueError("invalid radius")
+    return v
+
+
 __all__ = ["__version__", "Tle", "Sgp4Constellation", "Constellation", "propagate", "screen", "coarse_screen",
-           "set_fetcher", "celestrak_url", "WGS72", "WGS84"]
+           "set_fetcher", "celestrak_url", "WGS72", "WGS84", "hohmann_transfer", "orbital_velocity", "orbital_period",
+           "escape_velocity", "EARTH_MU", "EARTH_R_EQ", "EARTH_J2"]

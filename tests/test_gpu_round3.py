@@ -168,6 +168,17 @@ def test_orbital_exports(native):
     assert abs(L.orbital_period(mu, r2) - 2 * np.pi * np.sqrt(r2 ** 3 / mu)) < 1e-8
     assert abs(L.orbital_escape_velocity(mu, r1) - np.sqrt(2 * mu / r1)) < 1e-12
     assert L.orbital_velocity(mu, -1.0, 0.0) == -1.0 and L.orbital_period(mu, 0.0) == -1.0 and L.orbital_escape_velocity(mu, 0.0) == -1.0
+    # ... and their Python names (bindings/python/src/main.zig L24-32)
+    import astroz_amd as az
+    d = az.hohmann_transfer(az.EARTH_MU, r1, r2)
+    assert set(d) == {"sma", "dv1", "dv2", "total_dv", "transfer_time", "transfer_time_days"} and abs(d["sma"] - 0.5 * (r1 + r2)) < 1e-9
+    assert abs(az.orbital_velocity(az.EARTH_MU, r1) - np.sqrt(az.EARTH_MU / r1)) < 1e-12
+    assert abs(az.orbital_period(az.EARTH_MU, r2) - 2 * np.pi * np.sqrt(r2 ** 3 / az.EARTH_MU)) < 1e-8
+    assert abs(az.escape_velocity(az.EARTH_MU, r1) - np.sqrt(2 * az.EARTH_MU / r1)) < 1e-12
+    with pytest.raises(ValueError):
+        az.hohmann_transfer(az.EARTH_MU, r1, r1 + 10.0)
+    with pytest.raises(ValueError):
+        az.orbital_period(az.EARTH_MU, -5.0)
 
 
 @pytest.mark.parametrize("n_times,t0,step", [(1440, 0.0, 1.0), (333, -700.0, 3.0), (97, 40.0, 1.0)])
