@@ -18,6 +18,8 @@ SAT_MAJOR, TIME_MAJOR = 0, 1
 OUTPUT_MODES = {"teme": OUT_TEME, "ecef": OUT_ECEF, "geodetic": OUT_GEODETIC}
 
 AZ_ERR_HIP = -200
+# azh_last_path bits (include/astroz_hip.h)
+PATH_ROWS_FAST, PATH_TILES_FAST, PATH_ROWS_GENERIC, PATH_LANE_SAT, PATH_DEEP_ROWS, PATH_QUASI_UNIFORM, PATH_TILES_GENERIC = 1, 2, 4, 8, 16, 32, 64
 
 # every symbol include/astroz_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -29,7 +31,7 @@ EXPORTS = [
     "azh_num_satellites", "azh_num_sgp4", "azh_num_sdp4", "azh_get_epochs", "azh_get_status",
     "azh_get_field", "azh_propagate_host", "azh_propagate_device", "azh_propagate_device_cached", "azh_propagate_device_window",
     "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile", "azh_set_timing", "azh_set_fast_path", "azh_set_tile_kernel", "azh_set_f32_arithmetic",
-    "azh_last_kernel_ms", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
+    "azh_last_kernel_ms", "azh_last_path", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
     "azh_screen_target_host", "azh_screen_target_device", "azh_coarse_screen_device", "azh_coarse_screen_host",
     "azh_screen_all_host", "azh_constellation_from_omm_json", "azh_propagate_one_device", "azh_selftest_math",
     "azh_parse_tle_text", "azh_parse_omm_json", "azh_set_parse_threads", "coords_julian_to_gmst",
@@ -186,6 +188,8 @@ def lib():
     L.azh_set_f32_arithmetic.restype = i32
     L.azh_last_kernel_ms.argtypes = [vp]
     L.azh_last_kernel_ms.restype = dbl
+    L.azh_last_path.argtypes = [vp]
+    L.azh_last_path.restype = u32
     L.azh_propagate_device_f32.argtypes = L.azh_propagate_device.argtypes
     L.azh_propagate_device_f32.restype = i32
     L.azh_propagate_device_cached_f32.argtypes = L.azh_propagate_device_cached.argtypes
@@ -438,6 +442,10 @@ class DeviceConstellation:
 
     def last_kernel_ms(self):
         return lib().azh_last_kernel_ms(self._h)
+
+    def last_path(self):
+        """AZH_PATH_* bits (PATH_* below): which kernel families the most recent call launched."""
+        return int(lib().azh_last_path(self._h))
 
 
 class DeviceGroup:

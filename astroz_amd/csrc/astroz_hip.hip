@@ -116,6 +116,12 @@ struct azh_constellation {
     DevBuf<double> d_inc;       // uniform grids: per-satellite rotation increments (k_prep_inc), [2 * AZ_INC_NUM][n_pad]
     DevBuf<double> d_fast_rec;  // ... and the record of folded constants of the lane = time fast kernels (k_prep_rec), [n_pad][FR_NUM]
     double uniform_step = 0.0;  // step of the staged grid if it is uniform, else 0
+    // quasi-uniform grid (the reference's own (jd, fr) arithmetic: uniform to ~4e-7 min): deviations from the ideal grid,
+    // fp32, and their largest magnitude (0: exactly uniform, d_delta unused)
+    DevBuf<float> d_delta;
+    double delta_max = 0.0;
+    std::vector<float> h_delta; // (source of the asynchronous upload)
+    unsigned last_path = 0;     // AZH_PATH_* bits of the most recent launch set (azh_last_path)
     DevBuf<double> d_tgt, d_part_d2, d_out_d; // fused screen: target track, partial minima, results
     DevBuf<unsigned> d_part_t, d_out_t;
     // one satellite x many times (Satrec.sgp4 / sgp4_array / c_api sgp4_propagate*): persistent scratch so
@@ -170,6 +176,7 @@ void destroy(azh_constellation *c)
     c->d_deep_tmp.release();
     c->d_inc.release();
     c->d_fast_rec.release();
+    c->d_delta.release();
     for (auto &pl : c->plan) { pl.win.release(); pl.flag.release(); pl.redo.release(); }
     c->d_tgt.release();
     c->d_part_d2.release();
@@ -466,6 +473,10 @@ FastShape fast_shape_rows(const PropArgs &a, unsigned n_sgp4, unsigned n_circ)
         f.tile_c = std::min(f.tile_c, (unsigned)AZ_FRAME_SEG);
         f.tile_e = std::min(f.tile_e, (unsigned)AZ_FRAME_SEG);
     }
+    if (a.delta) { // quasi-uniform grid: a wave stages its segment's deviations in LDS
+        f.tile_c = std::min(f.tile_c, (unsigned)AZ_DELTA_SEG);
+        f.tile_e = std::min(f.tile_e, (unsigned)AZ_DELTA_SEG);
+    }
     f.packed32 = a.f32 && a.mode == AZ_OUT_TEME && a.arith32 != 2 && cap >= 128u;
     f.mixed32 = f.packed32 && a.arith32 == 0;
     if (f.packed32) f.tile_c = std::max(128u, f.tile_c / 128u * 128u);
@@ -477,9 +488,30 @@ FastShape fast_shape_tiles(const PropArgs &a, unsigned n_rows)
     FastShape f;
     unsigned tile = std::min(rows_tile(std::max((n_rows + 15u) / 16u, 1u) * 16u, a.n_times, a.tile_forced), fast_window_cap(a.uniform_step));
     if (a.mode != AZ_OUT_TEME) tile = std::min(tile, (unsigned)AZ_TILE_SEG_MAX); // the Greenwich-angle table of a time segment is staged in LDS
+    if (a.delta) tile = std::min(tile, (unsigned)AZ_DELTA_SEG);                  // ... and the deviations of a quasi-uniform grid
     f.tile_c = f.tile_e = tile;
     f.kind = 2;
     return f;
+}
+
+// the fast kernels, exactly uniform or quasi-uniform grid (DELTA instantiations: fast_step.h)
+template <bool VEL, int FRAME, int SINK, bool ECC>
+void launch_rows_fast(const PropArgs &a, dim3 grid, hipStream_t st)
+{
+    if (a.delta) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, SINK, ECC, true>), grid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, SINK, ECC, false>), grid, dim3(64), 0, st, a);
+}
+template <bool VEL, bool MIXED>
+void launch_rows_fast32(const PropArgs &a, dim3 grid, hipStream_t st)
+{
+    if (a.delta) hipLaunchKernelGGL((k_rows_fast32<VEL, MIXED, true>), grid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_rows_fast32<VEL, MIXED, false>), grid, dim3(64), 0, st, a);
+}
+template <bool VEL, int FRAME>
+void launch_tiles_fast(const PropArgs &a, dim3 grid, hipStream_t st)
+{
+    if (a.delta) hipLaunchKernelGGL((k_tiles_fast<VEL, FRAME, true>), grid, dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((k_tiles_fast<VEL, FRAME, false>), grid, dim3(1024), 0, st, a);
 }
 
 template <bool VEL, int FRAME> // FRAME: 0 TEME, 1 ECEF, 2 geodetic (the generic kernels take frame / no frame and p.mode)
@@ -516,16 +548,16 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const
             (void)hipStreamWaitEvent(se, side.fork, 0);
         }
         if (e.n_list) {
-            if (a.f32) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32, true>), egrid, dim3(64), 0, se, e);
-            else hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F64, true>), egrid, dim3(64), 0, se, e);
+            if (a.f32) launch_rows_fast<VEL, FRAME, AZ_SINK_F32, true>(e, egrid, se);
+            else launch_rows_fast<VEL, FRAME, AZ_SINK_F64, true>(e, egrid, se);
         }
         if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FR, AZ_SINK_F32, true>), rgrid, dim3(64), 0, se, a);
         else hipLaunchKernelGGL((k_rows<VEL, FR, AZ_SINK_F64, true>), rgrid, dim3(64), 0, se, a);
         if (c.n_list) {
-            if (packed32 && shape->mixed32) hipLaunchKernelGGL((k_rows_fast32<VEL, true>), cgrid, dim3(64), 0, st, c);
-            else if (packed32) hipLaunchKernelGGL((k_rows_fast32<VEL, false>), cgrid, dim3(64), 0, st, c);
-            else if (a.f32) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F32, false>), cgrid, dim3(64), 0, st, c);
-            else hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, AZ_SINK_F64, false>), cgrid, dim3(64), 0, st, c);
+            if (packed32 && shape->mixed32) launch_rows_fast32<VEL, true>(c, cgrid, st);
+            else if (packed32) launch_rows_fast32<VEL, false>(c, cgrid, st);
+            else if (a.f32) launch_rows_fast<VEL, FRAME, AZ_SINK_F32, false>(c, cgrid, st);
+            else launch_rows_fast<VEL, FRAME, AZ_SINK_F64, false>(c, cgrid, st);
         }
         if (beside) {
             (void)hipEventRecord(side.join, se);
@@ -546,14 +578,14 @@ void launch_tiles(const PropArgs &a0, bool vel, hipStream_t st, const FastShape 
     const bool ecef = a.mode != AZ_OUT_TEME, geo = a.mode == AZ_OUT_GEODETIC;
     dim3 grid(((a.n_rows + 15u) / 16u + 7u) / 8u * 8u, (a.n_times + a.tile - 1) / a.tile); // tiles of 16 catalog rows
     if (geo) {
-        if (vel) hipLaunchKernelGGL((k_tiles_fast<true, 2>), grid, dim3(1024), 0, st, a);
-        else hipLaunchKernelGGL((k_tiles_fast<false, 2>), grid, dim3(1024), 0, st, a);
+        if (vel) launch_tiles_fast<true, 2>(a, grid, st);
+        else launch_tiles_fast<false, 2>(a, grid, st);
     } else if (ecef) {
-        if (vel) hipLaunchKernelGGL((k_tiles_fast<true, 1>), grid, dim3(1024), 0, st, a);
-        else hipLaunchKernelGGL((k_tiles_fast<false, 1>), grid, dim3(1024), 0, st, a);
+        if (vel) launch_tiles_fast<true, 1>(a, grid, st);
+        else launch_tiles_fast<false, 1>(a, grid, st);
     } else {
-        if (vel) hipLaunchKernelGGL((k_tiles_fast<true, 0>), grid, dim3(1024), 0, st, a);
-        else hipLaunchKernelGGL((k_tiles_fast<false, 0>), grid, dim3(1024), 0, st, a);
+        if (vel) launch_tiles_fast<true, 0>(a, grid, st);
+        else launch_tiles_fast<false, 0>(a, grid, st);
     }
     a.tm_rows = 1;
     dim3 rgrid(256, 4);
@@ -566,8 +598,9 @@ void launch_tiles(const PropArgs &a0, bool vel, hipStream_t st, const FastShape 
     }
 }
 
-void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStream_t st, const EccSide &side = EccSide(),
-                      const FastShape *shape = nullptr)
+// returns the AZH_PATH_* bit of the kernel family it launched
+unsigned launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStream_t st, const EccSide &side = EccSide(),
+                          const FastShape *shape = nullptr)
 {
     const bool frame = a.mode != AZ_OUT_TEME;
     if (use_rows(a, layout, deep)) {
@@ -589,14 +622,14 @@ void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStr
             if (vel) launch_rows2<true, 0>(b, grid, deep, st, side, shape);
             else launch_rows2<false, 0>(b, grid, deep, st, side, shape);
         }
-        return;
+        return deep ? AZH_PATH_DEEP_ROWS : (!a.screen_target && b.redo_items != nullptr && shape != nullptr ? AZH_PATH_ROWS_FAST : AZH_PATH_ROWS_GENERIC);
     }
     if (a.screen_target) {
         // fused screen, lane = satellite (deep-space members; near-earth on very short grids)
         dim3 grid(((a.n_list + AZ_BLOCK - 1) / AZ_BLOCK + 7) / 8 * 8, (a.n_times + a.tile - 1) / a.tile);
         if (deep) hipLaunchKernelGGL((k_propagate<0, false, true, false, true>), grid, dim3(AZ_BLOCK), 0, st, a);
         else hipLaunchKernelGGL((k_propagate<0, false, false, false, true>), grid, dim3(AZ_BLOCK), 0, st, a);
-        return;
+        return AZH_PATH_LANE_SAT;
     }
     if (deep) {
         if (frame) launch_propagate2<true, true>(a, layout, vel, st);
@@ -605,6 +638,7 @@ void launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hipStr
         if (frame) launch_propagate2<false, true>(a, layout, vel, st);
         else launch_propagate2<false, false>(a, layout, vel, st);
     }
+    return AZH_PATH_LANE_SAT;
 }
 
 // upload times / offsets / mask and (if needed) build the GMST table
@@ -637,12 +671,30 @@ int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, 
     // uniform grid?  times[i] == times[0] + i*step up to the rounding of the grid itself: the fast step
     // (fast_step.h) then advances its carried angles by per-satellite constant rotations
     c->uniform_step = 0.0;
+    c->delta_max = 0.0;
     if (n_times >= 2) {
+        // ... or QUASI-uniform: within AZ_DELTA_MAX minutes of such a grid.  That is what the reference's own API hands over,
+        // times = ((jd + fr) - reference_jd) * 1440 (api.py L300-302, Constellation.zig L266-269): jd + fr at 2.46e6 days is
+        // quantised to 2^-31 day = 6.7e-7 min.  The fast kernels then run along the ideal grid and correct every point to its
+        // actual time to first order in the deviation (fast_step.h, DELTA).
         const double t0 = times[0], step = (times[n_times - 1] - t0) / (double)(n_times - 1);
         double tmax = std::max(std::fabs(t0), std::fabs(times[n_times - 1]));
         const double tol = 4.0 * 2.220446049250313e-16 * std::max(tmax, std::fabs(step));
         bool uni = std::isfinite(step) && step != 0.0;
-        for (size_t i = 1; uni && i < n_times; ++i) uni = std::fabs(times[i] - (t0 + (double)i * step)) <= tol;
+        double dmax = 0.0;
+        for (size_t i = 1; uni && i < n_times; ++i) {
+            dmax = std::max(dmax, std::fabs(times[i] - std::fma((double)i, step, t0)));
+            uni = dmax <= AZ_DELTA_MAX; // (false for a NaN)
+        }
+        if (uni && dmax > tol) {
+            // (zero-padded by one segment: a wave stages AZ_DELTA_SEG values from its segment start without a bounds test)
+            c->h_delta.assign(n_times + AZ_DELTA_SEG, 0.0f);
+            for (size_t i = 0; i < n_times; ++i) c->h_delta[i] = (float)(times[i] - std::fma((double)i, step, t0));
+            if (c->d_delta.ensure(c->h_delta.size()) != AZ_OK) return AZ_ERR_HIP;
+            // (pageable source, like `times` itself: the runtime has read it when the call returns)
+            HIP_TRY(hipMemcpyAsync(c->d_delta.p, c->h_delta.data(), sizeof(float) * c->h_delta.size(), hipMemcpyHostToDevice, st));
+            c->delta_max = dmax * (1.0 + 1e-6) + 1e-12;
+        }
         if (uni) {
             if (c->d_inc.ensure((size_t)2 * AZ_INC_NUM * c->n_pad) != AZ_OK) return AZ_ERR_HIP;
             hipLaunchKernelGGL(k_prep_inc, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, st, c->d_el, c->n, c->n_pad,
@@ -706,6 +758,7 @@ int32_t ensure_plan(azh_constellation *c, PropArgs &a, const FastShape &shape, h
         q.el = a.el; q.flags = a.flags; q.n_pad = a.n_pad; q.list = a.list; q.n_list = n_list; q.n_circ = a.n_circ;
         q.n_times = a.n_times; q.tile_c = shape.tile_c; q.tile_e = shape.tile_e; q.by_flags = shape.kind == 2 ? 1u : 0u;
         q.times = a.times; q.offsets = a.offsets; q.inc = a.inc; q.step = a.uniform_step; q.dt_mult = shape.kind == 1 ? 128.0 : 64.0;
+        q.delta_max = a.delta ? a.delta_max : 0.0;
         q.f32_mixed = shape.mixed32 ? 1u : 0u;
         q.win = pl.win.p; q.flag = pl.flag.p;
         q.redo_static = pl.redo.p + 2; q.redo_c0 = pl.redo.p; q.redo_c1 = pl.redo.p + 1; q.redo_items = pl.redo.p + 4;
@@ -759,9 +812,12 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     a.uniform_step = c->fast_path ? c->uniform_step : 0.0;
     a.inc = (a.uniform_step != 0.0) ? c->d_inc.p : nullptr;
     a.fast_rec = (a.uniform_step != 0.0) ? c->d_fast_rec.p : nullptr;
+    a.delta = (a.uniform_step != 0.0 && c->delta_max > 0.0) ? c->d_delta.p : nullptr;
+    a.delta_max = c->delta_max;
     a.row_lo = (unsigned)row_lo;
     a.row_hi = (unsigned)row_hi;
 
+    unsigned path = 0;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
     if (d_err) HIP_TRY(hipMemsetAsync(d_err + row_lo * (size_t)n_times, 0, (row_hi - row_lo) * (size_t)n_times, st));
     // time-major output on a uniform grid: the near-earth members take the 16-satellite tile kernel
@@ -786,7 +842,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
             t.pos = c->d_deep_tmp.p;
             t.vel = d_vel ? c->d_deep_tmp.p + words : nullptr;
             t.rows_compact = 1;
-            launch_propagate(t, AZ_LAYOUT_SAT_MAJOR, d_vel != nullptr, true, c->s_deep);
+            path |= launch_propagate(t, AZ_LAYOUT_SAT_MAJOR, d_vel != nullptr, true, c->s_deep);
             HIP_TRY(hipGetLastError());
             a.tmp_pos = t.pos;
             a.tmp_vel = t.vel;
@@ -800,7 +856,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
                 hipLaunchKernelGGL((k_deep_transpose<double>), tg, dim3(192), 0, c->s_deep, t.pos, t.vel, d_pos, d_vel, d.list, c->n_sdp4,
                                    n_times, stride, d.mask, d.row_lo, d.row_hi);
         } else {
-            launch_propagate(d, layout, d_vel != nullptr, true, c->s_deep);
+            path |= launch_propagate(d, layout, d_vel != nullptr, true, c->s_deep);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_join, c->s_deep));
@@ -829,8 +885,13 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
             shape = tiles ? fast_shape_tiles(a, (unsigned)c->n) : fast_shape_rows(a, c->n_sgp4, c->n_circ);
             if (int32_t rc = ensure_plan(c, a, shape, st); rc != AZ_OK) return rc;
         }
-        if (a.n_list > 0 && tiles) launch_tiles(a, d_vel != nullptr, st, shape);
-        else if (a.n_list > 0) launch_propagate(a, layout, d_vel != nullptr, false, st, EccSide{c->s_ecc, c->ev_fork2, c->ev_join2}, fast ? &shape : nullptr);
+        if (a.n_list > 0 && tiles) {
+            launch_tiles(a, d_vel != nullptr, st, shape);
+            path |= AZH_PATH_TILES_FAST;
+        } else if (a.n_list > 0) {
+            path |= launch_propagate(a, layout, d_vel != nullptr, false, st, EccSide{c->s_ecc, c->ev_fork2, c->ev_join2}, fast ? &shape : nullptr);
+        }
+        if (a.delta && (path & (AZH_PATH_TILES_FAST | AZH_PATH_ROWS_FAST))) path |= AZH_PATH_QUASI_UNIFORM;
         HIP_TRY(hipGetLastError());
     }
     if (c->n_bad > 0) {
@@ -840,6 +901,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         HIP_TRY(hipGetLastError());
     }
     if (fork && !tiles) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
+    c->last_path = path;
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t1, st));
         c->timed = true;
@@ -1206,11 +1268,14 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
         a.uniform_step = c->fast_path ? c->uniform_step : 0.0;
         a.inc = (a.uniform_step != 0.0) ? c->d_inc.p : nullptr;
         a.fast_rec = (a.uniform_step != 0.0) ? c->d_fast_rec.p : nullptr;
+        a.delta = (a.uniform_step != 0.0 && c->delta_max > 0.0) ? c->d_delta.p : nullptr;
+        a.delta_max = c->delta_max;
         a.row_lo = 0;
         a.row_hi = 0xffffffffu;
         a.screen_target = c->d_tgt.p;
         PropArgs near = a, deep = a;
         unsigned parts_near = 0, parts_deep = 0;
+        c->last_path = 0;
         // near-earth members on a uniform grid: the branch-free fast kernels with the screen as their sink (no stores at all:
         // the arithmetic-only rate), windows the plan rejects and Newton hand-overs through the generic pass like a propagation
         const bool fast_screen = c->n_sgp4 > 0 && a.inc != nullptr && nt >= 32;
@@ -1257,15 +1322,16 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
                     HIP_TRY(hipEventRecord(c->ev_fork2, st));
                     HIP_TRY(hipStreamWaitEvent(se, c->ev_fork2, 0));
                 }
-                if (e.n_list) hipLaunchKernelGGL((k_rows_fast<false, 0, AZ_SINK_SCREEN, true>), dim3((e.n_list + 7) / 8 * 8, cgrid_y(nt, e.tile)), dim3(64), 0, se, e);
+                if (e.n_list) launch_rows_fast<false, 0, AZ_SINK_SCREEN, true>(e, dim3((e.n_list + 7) / 8 * 8, cgrid_y(nt, e.tile)), se);
                 hipLaunchKernelGGL((k_rows<false, false, AZ_SINK_SCREEN, true>), dim3(256, 4), dim3(64), 0, se, near);
-                if (cc.n_list) hipLaunchKernelGGL((k_rows_fast<false, 0, AZ_SINK_SCREEN, false>), dim3((cc.n_list + 7) / 8 * 8, cgrid_y(nt, cc.tile)), dim3(64), 0, st, cc);
+                if (cc.n_list) launch_rows_fast<false, 0, AZ_SINK_SCREEN, false>(cc, dim3((cc.n_list + 7) / 8 * 8, cgrid_y(nt, cc.tile)), st);
                 if (beside) {
                     HIP_TRY(hipEventRecord(c->ev_join2, se));
                     HIP_TRY(hipStreamWaitEvent(st, c->ev_join2, 0));
                 }
+                c->last_path = AZH_PATH_ROWS_FAST | (near.delta ? AZH_PATH_QUASI_UNIFORM : 0u);
             } else {
-                launch_propagate(near, AZ_LAYOUT_SAT_MAJOR, false, false, st);
+                c->last_path = launch_propagate(near, AZ_LAYOUT_SAT_MAJOR, false, false, st);
             }
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(k_screen_finalize, dim3((c->n_sgp4 + 255) / 256), dim3(256), 0, st, near.part_d2, near.part_t,
@@ -1275,7 +1341,7 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
         if (c->n_sdp4 > 0) {
             deep.part_d2 = c->d_part_d2.p + np_near;
             deep.part_t = c->d_part_t.p + np_near;
-            launch_propagate(deep, AZ_LAYOUT_SAT_MAJOR, false, true, st);
+            c->last_path |= launch_propagate(deep, AZ_LAYOUT_SAT_MAJOR, false, true, st);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(k_screen_finalize, dim3((c->n_sdp4 + 255) / 256), dim3(256), 0, st, deep.part_d2, deep.part_t,
                                parts_deep, deep.list, c->n_sdp4, thr2, (unsigned)target, d_min_dist, d_min_t);
@@ -1532,6 +1598,8 @@ int32_t azh_synchronize(azh_constellation *c)
     HIP_TRY(hipStreamSynchronize(c->s_main));
     return AZ_OK;
 }
+
+uint32_t azh_last_path(const azh_constellation *c) { return c ? c->last_path : 0u; }
 
 double azh_last_kernel_ms(azh_constellation *c)
 {

@@ -16,6 +16,8 @@
 // are only stored after the vote, so nothing wrong ever reaches memory).  197 fp64 instructions per propagation against
 // ~300 executed by the generic loop (whose tier votes cost compares, branches and the register moves at every merge).
 #pragma once
+#include <type_traits>
+
 #include "propagate_device.h"
 
 // per-satellite constants of the fast step (wave-uniform in the lane = time kernel, per lane in the
@@ -33,14 +35,30 @@ enum FastCold {
 #undef X
     FC_NUM
 };
+// QUASI-uniform grids (DELTA): times[i] = t0 + i step + delta_i with |delta_i| <= AZ_DELTA_MAX minutes -- what the reference's
+// own API produces, times = ((jd + fr) - reference_jd) * 1440 (bindings/python/astroz/api.py L300-302, src/Constellation.zig
+// L266-269): jd + fr at 2.46e6 days is quantised to 2^-31 day, so its grids are uniform only to ~4e-7 min.  The carried
+// pairs still advance by constant increments along the IDEAL grid; the step is evaluated at the ACTUAL time t0 + i step +
+// delta_i and corrects the phases to first order in delta (second order: (0.075 rad/min x 4e-6 min)^2 / 2 = 4.5e-14 rad):
+// the rates of M, of W and of the carried phase U (mdot + argpdot + 2 kappa tc).  Three more once-per-step constants.
+#define AZ_FASTK_DELTA(X) X(mdot) X(argpdot) X(udot)
+enum FastColdX {
+    FCX_first_ = FC_NUM - 1,
+#define X(n) FCX_##n,
+    AZ_FASTK_DELTA(X)
+#undef X
+    FCX_NUM
+};
+#define AZ_DELTA_MAX 4.0e-6 /* minutes: largest deviation from the ideal grid the fast kernels take */
+#define AZ_DELTA_SEG 768    /* grid points per time segment whose deviations a wave / tile stages in LDS (fp32) */
 // everything in registers (lane = satellite kernels, host emulation)
 struct FastK {
     static constexpr bool SCALAR = false;
 #define X(n) double n##_;
-    AZ_FASTK_COLD(X) AZ_FASTK_HOT(X)
+    AZ_FASTK_COLD(X) AZ_FASTK_HOT(X) AZ_FASTK_DELTA(X)
 #undef X
 #define X(n) AZ_MEMBER double n() const { return n##_; }
-    AZ_FASTK_COLD(X) AZ_FASTK_HOT(X)
+    AZ_FASTK_COLD(X) AZ_FASTK_HOT(X) AZ_FASTK_DELTA(X)
 #undef X
 };
 // lane = time kernels (one satellite per wave): the 18 constants used several times per step or sitting
@@ -58,6 +76,9 @@ struct FastKBcast {
 #define X(n) AZ_MEMBER double n() const { return cold[FC_##n]; }
     AZ_FASTK_COLD(X)
 #undef X
+#define X(n) AZ_MEMBER double n() const { return cold[FCX_##n]; }
+    AZ_FASTK_DELTA(X)
+#undef X
 };
 
 // lane = satellite kernels: hot constants in registers, the once-per-step ones in a per-lane LDS column
@@ -74,6 +95,9 @@ struct FastKCol {
 #undef X
 #define X(n) AZ_MEMBER double n() const { return cold[FC_##n * AZ_COLD_STRIDE]; }
     AZ_FASTK_COLD(X)
+#undef X
+#define X(n) AZ_MEMBER double n() const { return 0.0; } /* (the lane = satellite kernel has no DELTA form) */
+    AZ_FASTK_DELTA(X)
 #undef X
 };
 
@@ -119,8 +143,12 @@ AZ_DEVICE void az_load_fast(const double *__restrict__ el, size_t n_pad, size_t 
     k.sdA_ = q[(size_t)AZ_INC_sdA * n_pad]; k.cdA_ = q[(size_t)AZ_INC_cdA * n_pad];
     k.sdW_ = q[(size_t)AZ_INC_sdW * n_pad]; k.cdW_ = q[(size_t)AZ_INC_cdW * n_pad];
     k.nodedot_ = L(nodedot);
+    k.mdot_ = L(mdot); k.argpdot_ = L(argpdot);
+    k.udot_ = k.mdot_ + k.argpdot_; // (tc = 0; az_fast_udot once the window's tc is known)
 #undef L
 }
+// rate of the carried phase U about the window centre tc (DELTA: the first-order correction of U)
+AZ_DEVICE void az_fast_udot(FastK &k) { k.udot_ = fma(2.0 * k.nl2_, k.tc_, k.mdot_ + k.argpdot_); }
 
 // Window set-up: the centre tc about which the drag phase is expanded and the increment (sin,cos) of U for
 // steps of dt.  [t_a, t_b]: the tsince range of the window (any order).  Wave-uniform in the lane = time kernels.
@@ -141,6 +169,7 @@ AZ_DEVICE void az_fast_window(const double *__restrict__ el, size_t n_pad, size_
         k.tc_ = 0.5 * (t_a + t_b);
         az_sincos((L(mdot) + L(argpdot) + 2.0 * kappa * k.tc_) * dt, k.sdU_, k.cdU_);
     }
+    if constexpr (std::is_same<K, FastK>::value) az_fast_udot(k);
 #undef L
 }
 
@@ -148,14 +177,14 @@ AZ_DEVICE void az_fast_window(const double *__restrict__ el, size_t n_pad, size_
 // same for every wave that ever works on the satellite, so k_prep_rec evaluates them ONCE per staged grid into an
 // array-of-structures record; a wave then reads its 33 constants with a handful of wide scalar loads (hot fields: straight
 // into SGPRs, no arithmetic on uniform values in the vector ALUs, no v_readfirstlane) and one per-lane vector load (lane j
-// fetches cold field j for the LDS table: no SGPR -> VGPR moves).  Layout: [FC_NUM cold fields in FastCold order |
+// fetches cold field j for the LDS table: no SGPR -> VGPR moves).  Layout: [FCX_NUM cold fields in FastCold / FastColdX order |
 // AZ_FASTK_HOT_REC fields | the four angles of the seeds], padded to a 64-byte multiple.
 #define AZ_FASTK_HOT_REC(X)                                                                                  \
     X(aycof) X(xlcof) X(xnodcf) X(sinio) X(cosio) X(k_mrt) X(k_c2u) X(k_su) X(k_node) X(k_inc) X(x1mth2) X(k_rv) \
     X(sdA) X(cdA) X(sdW) X(cdW) X(nodedot)
 enum FastRec {
     FR_COLD0 = 0,
-    FR_HOT0 = FC_NUM,
+    FR_HOT0 = FCX_NUM,
 #define X(n) FR_##n,
     FR_first_hot_ = FR_HOT0 - 1,
     AZ_FASTK_HOT_REC(X)
@@ -169,6 +198,7 @@ AZ_DEVICE void az_fast_rec_store(const double *__restrict__ el, size_t n_pad, si
 #define X(n) rec[FC_##n] = k.n##_;
     AZ_FASTK_COLD(X)
 #undef X
+    rec[FCX_mdot] = k.mdot_; rec[FCX_argpdot] = k.argpdot_; rec[FCX_udot] = k.mdot_ + k.argpdot_; // (udot: tc = 0; the wave adds 2 kappa tc)
 #define X(n) rec[FR_##n] = k.n##_;
     AZ_FASTK_HOT_REC(X)
 #undef X
@@ -377,10 +407,11 @@ AZ_DEVICE void az_fpq_milli(double d, const RC &k, double &p, double &q)
 // voted on six compares per step).  A window that fails goes to the generic kernel as a whole; the bounds are a few
 // per cent wider than the quantities themselves, which moves well under 1 % more segments there.
 // ECC = true additionally validates its Newton iteration per step (az_sgp4_fast_step's return value).
+// dmax: largest |delta_i| of a quasi-uniform grid (0: exactly uniform): every time bound widens by it, eps by |udot| dmax.
 template <bool ECC>
-AZ_DEVICE bool az_fast_window_ok(const FastK &k, const AzGrav &g, double t_a, double t_b)
+AZ_DEVICE bool az_fast_window_ok(const FastK &k, const AzGrav &g, double t_a, double t_b, double dmax = 0.0)
 {
-    const double T = fmax(fabs(t_a), fabs(t_b));
+    const double T = fmax(fabs(t_a), fabs(t_b)) + dmax;
     const double ae = fabs(k.eta_);
     // th = xmcof ((1 + eta cos M)^3 - (1 + eta cos mo)^3) + omgcof t
     const double th = fma(fabs(k.xmcof_), ae * fma(2.0 * ae, ae, 6.0), fabs(k.omgcof_) * T);
@@ -396,14 +427,15 @@ AZ_DEVICE bool az_fast_window_ok(const FastK &k, const AzGrav &g, double t_a, do
     if (!ECC) ok &= el2 <= AZ_FAST_EL2;
     ok &= el2 <= 0.81;
     // eps = temp xlcof axnl + nl2 (t - tc)^2 + t^3 (nl3 + t (nl4 + t nl5))
-    const double dc = fmax(fabs(t_a - k.tc_), fabs(t_b - k.tc_));
-    const double eps = fma(temp * fabs(k.xlcof_), em, fma(fabs(k.nl2_) * dc, dc, T * T * T * fma(T, fma(T, fabs(k.nl5_), fabs(k.nl4_)), fabs(k.nl3_))));
+    const double dc = fmax(fabs(t_a - k.tc_), fabs(t_b - k.tc_)) + dmax;
+    const double eps = fma(temp * fabs(k.xlcof_), em, fma(fabs(k.nl2_) * dc, dc, T * T * T * fma(T, fma(T, fabs(k.nl5_), fabs(k.nl4_)), fabs(k.nl3_)))) +
+                       fabs(k.udot_) * dmax;
     ok &= eps <= AZ_ROT_MED;
     const double inv_pl = inv_am / (1.0 - el2);
     const double temp2 = g.half_j2 * inv_pl * inv_pl;
     ok &= temp2 <= AZ_FAST_TEMP2;
     // a_nd = k_node temp2 sin2u + nodedot (t - tmid) + xnodcf t^2
-    const double a_nd = fma(fabs(k.k_node_), temp2, fma(fabs(k.nodedot_), 0.5 * fabs(t_b - t_a), fabs(k.xnodcf_) * T * T));
+    const double a_nd = fma(fabs(k.k_node_), temp2, fma(fabs(k.nodedot_), 0.5 * fabs(t_b - t_a) + dmax, fabs(k.xnodcf_) * T * T));
     ok &= a_nd <= AZ_ROT_MED;
     return ok; // (every comparison is false for a NaN operand)
 }
@@ -411,15 +443,25 @@ AZ_DEVICE bool az_fast_window_ok(const FastK &k, const AzGrav &g, double t_a, do
 // one near-earth propagation on a uniform grid, inside a window az_fast_window_ok accepted.  Returns true when
 // the eccentric form's Newton iteration left its assumptions for this lane (ECC = true only; the caller must then
 // discard r/v and use az_sgp4_step); the near-circular form always returns false.
-template <bool VEL, bool ECC = false, class K = FastK, class RC = RotCoefLit>
+// DELTA: the grid is quasi-uniform; t is the ACTUAL time of this point and dl = t - (its place on the ideal grid the carried
+// pairs advance along), |dl| <= AZ_DELTA_MAX.
+template <bool VEL, bool ECC = false, bool DELTA = false, class K = FastK, class RC = RotCoefLit>
 AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, double t, FastCarry &st, double r[3],
-                                  double v[3])
+                                  double v[3], double dl = 0.0)
 {
     // advance the carried pairs by their constant increments
     az_pair_advance<K::SCALAR>(st.sA, st.cA, k.sdA(), k.cdA());
     az_pair_advance<K::SCALAR>(st.sW, st.cW, k.sdW(), k.cdW());
     az_pair_advance<K::SCALAR>(st.sU, st.cU, k.sdU(), k.cdU());
-    const double sA = st.sA, cA = st.cA;
+    double sA = st.sA, cA = st.cA, sW = st.sW, cW = st.cW;
+    if constexpr (DELTA && ECC) {
+        // M and W at the actual time, first order in dl.  (The near-circular form does without: both pairs only enter
+        // scaled by em < 0.004 -- argpdot dl em < 1e-12 rad -- and through th, whose product with em is bounded by the drag
+        // coefficients alone: d(th) em < 1e-13.)
+        const double a = k.mdot() * dl, b = k.argpdot() * dl;
+        sA = fma(st.cA, a, st.sA); cA = fma(-st.sA, a, st.cA);
+        sW = fma(st.cW, b, st.sW); cW = fma(-st.sW, b, st.cW);
+    }
     const double t2 = t * t;
 
     // secular gravity + drag (Sgp4Batch.zig L121-154)
@@ -434,8 +476,8 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, doub
     if (ECC) az_pq_16th(th, rk, p, q);
     else az_pq_ecc_scaled(th, rk, p, q);                       // M + th and W - th only enter scaled by em < 0.004
     const double smm = fma(cA, p, fma(sA, q, sA));            // sin(M + th)
-    const double sw = fma(-st.cW, p, fma(st.sW, q, st.sW));   // (sin,cos)(W - th)
-    const double cw = fma(st.sW, p, fma(st.cW, q, st.cW));
+    const double sw = fma(-cW, p, fma(sW, q, sW));            // (sin,cos)(W - th)
+    const double cw = fma(sW, p, fma(cW, q, cW));
     const double em = fmax(fma(-k.bc5(), smm, fma(-k.bc4(), t, k.ecb())), 1.0e-6);
 
     // am = a_base tempa^2: one reciprocal gives 1/sqrt(am) and 1/(am (1 - em^2))
@@ -451,7 +493,8 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, doub
     // u0 = U + (rest of no*templ) + temp*xlcof*axnl: |.| <= 1/8, sin to d^7 and cos to d^8 (d^9/9! < 2.1e-14)
     double s = st.sU, c = st.cU;
     {
-        const double eps = fma(temp * k.xlcof(), axnl, nl);
+        double eps = fma(temp * k.xlcof(), axnl, nl);
+        if constexpr (DELTA) eps = fma(k.udot(), dl, eps); // U at the actual time
         az_pq_16th(eps, rk, p, q);
         az_rot_apply2(s, c, p, q);
     }

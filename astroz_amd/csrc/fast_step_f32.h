@@ -48,7 +48,8 @@ AZ_DEVICE az_f2 az_cvt2(double a, double b) { az_f2 r; r.x = (float)a; r.y = (fl
 // per-satellite constants of the packed step.  Used once per step (LDS candidates) / several times (registers):
 #define AZ_F32_ONCE(X) \
     X(cc1) X(d2) X(d3) X(d4) X(nl2) X(nl3) X(nl4) X(nl5) X(eta) X(omgcof) X(xmcof) X(xd) X(bc4) X(bc5) X(ecb) X(aycof) \
-    X(xlcof) X(xnodcf) X(k_mrt) X(k_c2u) X(k_su) X(k_node) X(k_inc) X(k_rv) X(nodedot) X(sinio) X(cosio) X(sOc) X(cOc)
+    X(xlcof) X(xnodcf) X(k_mrt) X(k_c2u) X(k_su) X(k_node) X(k_inc) X(k_rv) X(nodedot) X(sinio) X(cosio) X(sOc) X(cOc) \
+    X(udot)
 #define AZ_F32_MANY(X) X(x1mth2) X(sdA32) X(cdA32) X(sdW32) X(cdW32) X(step1) X(inv_sab32) X(abase32) X(rv0_32)
 enum Fast32Once {
 #define X(n) F32_##n,
@@ -168,8 +169,10 @@ AZ_DEVICE void az_rot32_small(az_f2 &s, az_f2 &c, az_f2 d)
 // first, as in az_sgp4_fast_step).  r, v: component j of the even / odd point in r[j].x / r[j].y.
 // Only inside a window az_fast_window_ok<false> accepted (fast_step.h: the bounds are on the fp64 quantities; the fp32
 // ones differ from them by roundings, and no tier has a cliff at its threshold).
-template <bool VEL, class K>
-AZ_DEVICE void az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, FastCarry32 &st, az_f2 r[3], az_f2 v[3])
+// DELTA (quasi-uniform grids, fast_step.h): dl = the two grid points' deviations from the ideal grid, minutes; only the carried
+// phase U needs them at fp32 output precision (udot dl ~ 3e-8 rad = 0.2 m; t itself does not resolve 4e-7 min in fp32).
+template <bool VEL, bool DELTA = false, class K>
+AZ_DEVICE void az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, FastCarry32 &st, az_f2 r[3], az_f2 v[3], az_f2 dl = az_f2())
 {
     {
         const az_f2 nsA = az_fma2(k.cdA32(), st.sA, k.sdA32() * st.cA);
@@ -221,7 +224,8 @@ AZ_DEVICE void az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, Fas
     az_f2 s = az_cvt2(st.sU, fma(st.sU, k.c1U, st.cU * k.s1U));
     az_f2 c = az_cvt2(st.cU, fma(st.cU, k.c1U, -(st.sU * k.s1U)));
     {
-        const az_f2 eps = az_fma2(k.xlcof() * temp, axnl, nl);
+        az_f2 eps = az_fma2(k.xlcof() * temp, axnl, nl);
+        if constexpr (DELTA) eps = az_fma2(k.udot(), dl, eps);
         az_rot32_med(s, c, eps);
     }
 
@@ -326,8 +330,8 @@ AZ_DEVICE bool az_fast32p_window_ok(const K &k, double t_a, double t_b)
     return da <= AZ_F32P_DEV_MAX;
 }
 
-template <bool VEL, class K>
-AZ_DEVICE void az_sgp4_fast_step_f32p(const K &k, const AzGrav &g, double ta, FastCarry32 &st, az_f2 r[3], az_f2 v[3])
+template <bool VEL, bool DELTA = false, class K>
+AZ_DEVICE void az_sgp4_fast_step_f32p(const K &k, const AzGrav &g, double ta, FastCarry32 &st, az_f2 r[3], az_f2 v[3], az_f2 dl = az_f2())
 {
     {
         const az_f2 nsA = az_fma2(k.cdA32(), st.sA, k.sdA32() * st.cA);
@@ -380,7 +384,8 @@ AZ_DEVICE void az_sgp4_fast_step_f32p(const K &k, const AzGrav &g, double ta, Fa
     const double sU_a = st.sU, cU_a = st.cU;
     const double sU_b = fma(st.sU, k.c1U, st.cU * k.s1U), cU_b = fma(st.cU, k.c1U, -(st.sU * k.s1U));
     az_f2 s = az_cvt2(sU_a, sU_b), c = az_cvt2(cU_a, cU_b);
-    const az_f2 eps = az_fma2(k.xlcof() * temp, axnl, nl);
+    az_f2 eps = az_fma2(k.xlcof() * temp, axnl, nl);
+    if constexpr (DELTA) eps = az_fma2(k.udot(), dl, eps);
     az_rot32_med(s, c, eps);
     // Kepler, near-circular: Newton step from E0 = u, then the chord step with the same reciprocal (first order)
     const az_f2 el2 = az_fma2(axnl, axnl, aynl * aynl);

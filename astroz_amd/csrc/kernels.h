@@ -81,6 +81,10 @@ struct PropArgs {
     // uniform grids: times[i] = times[0] + i * uniform_step (0 = not uniform), and the per-satellite
     // rotation increments k_prep_inc prepared for it (fast_step.h); null = generic path only
     double uniform_step;
+    // quasi-uniform grid (what jd + fr arithmetic produces): times[i] = times[0] + i uniform_step + delta[i], |delta| <= delta_max
+    // (fast_step.h, DELTA); null = exactly uniform
+    const float *delta;
+    double delta_max;
     const double *inc;
     const double *fast_rec; // [n_pad][FR_NUM]: per-satellite record of the lane = time fast kernels (k_prep_rec, fast_step.h)
     // row window: only satellites with row_lo <= table index < row_hi are produced by this launch (chunked
@@ -410,7 +414,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
 #if AZ_PROP_FAST
     // Optimistic straight-line loop (fast_step.h): uniform grid, all 64 orbits near-circular, every small
     // angle inside its usual tier; one vote per step, the generic loop takes over on a violation.
-    if (!DEEP && p.inc != nullptr && p.uniform_step != 0.0 && !az_any(AZ_FLAG_ECLASS(fl) != 0)) {
+    if (!DEEP && p.inc != nullptr && p.uniform_step != 0.0 && p.delta == nullptr && !az_any(AZ_FLAG_ECLASS(fl) != 0)) {
         FastKCol k;
         bool window_ok;
         {
@@ -605,7 +609,7 @@ struct PlanArgs {
     unsigned n_list, n_circ, n_times, tile_c, tile_e, by_flags;
     unsigned f32_mixed; // near-circular slots go to the mixed-precision fp32 step: its extra bound (az_fast32p_window_ok)
     const double *times, *offsets, *inc;
-    double step, dt_mult;
+    double step, dt_mult, delta_max;
     double *win;
     unsigned char *flag;
     unsigned *redo_static, *redo_c0, *redo_c1, *redo_items;
@@ -633,7 +637,7 @@ __global__ void __launch_bounds__(256) k_plan_windows(PlanArgs a)
     az_load_fast(a.el, a.n_pad, s, fl, a.inc, 1, k1);
     az_fast_window(a.el, a.n_pad, s, w_a, w_b, a.step, k1);
     // a class the form cannot take (an eccentric member in the near-circular list) is rejected like a failed bound
-    bool ok = ecc ? az_fast_window_ok<true>(k0, a.g, w_a, w_b) : az_fast_window_ok<false>(k0, a.g, w_a, w_b);
+    bool ok = ecc ? az_fast_window_ok<true>(k0, a.g, w_a, w_b, a.delta_max) : az_fast_window_ok<false>(k0, a.g, w_a, w_b, a.delta_max);
     if (!ecc && AZ_FLAG_ECLASS(fl) != 0) ok = false;
     if (!ecc && a.f32_mixed && !az_fast32p_window_ok(k0, w_a, w_b)) ok = false;
     const size_t at = (size_t)seg * a.n_list + slot;
@@ -727,19 +731,20 @@ __device__ const double az_mc_table[MC_NUM] = AZ_MC_VALUES;
 __device__ const double az_rc_table[RC_NUM] = AZ_RC_VALUES;
 // sincos coefficients of a wave's seeds through its LDS table (the first AZ_SC_NUM entries of AzMathConst)
 #define AZ_SC_NUM (MC_C5 + 1)
-#define AZ_FAST_TABLE ((FC_NUM + RC_NUM + AZ_SC_NUM + 1) & ~1) /* doubles per wave, 16-byte multiple */
+#define AZ_FAST_TABLE ((FCX_NUM + RC_NUM + AZ_SC_NUM + 1) & ~1) /* doubles per wave, 16-byte multiple */
 struct McLds {
     const double *p;
     __device__ __forceinline__ double mc(int k) const { return p[k]; }
 };
-// One vector load fills a wave's constant table in LDS: lane j < FC_NUM fetches cold field j of the satellite's record, the
+// One vector load fills a wave's constant table in LDS: lane j < FCX_NUM fetches cold field j of the satellite's record, the
 // next RC_NUM lanes the rotation coefficients, the next AZ_SC_NUM the sincos coefficients (round 3 wrote the first two
 // groups from lane 0, two register moves and a share of an LDS write per constant: 100 VALU slots per segment).
 __device__ __forceinline__ void az_fill_fast_table(double *table, const double *__restrict__ rec, unsigned lane)
 {
-    const double *src = lane < FC_NUM ? rec + lane
-                        : lane < FC_NUM + RC_NUM ? az_rc_table + (lane - FC_NUM) : az_mc_table + (lane - (FC_NUM + RC_NUM));
-    if (lane < FC_NUM + RC_NUM + AZ_SC_NUM) table[lane] = *src;
+    static_assert(FCX_NUM + RC_NUM + AZ_SC_NUM <= 64, "one lane per table entry");
+    const double *src = lane < FCX_NUM ? rec + lane
+                        : lane < FCX_NUM + RC_NUM ? az_rc_table + (lane - FCX_NUM) : az_mc_table + (lane - (FCX_NUM + RC_NUM));
+    if (lane < FCX_NUM + RC_NUM + AZ_SC_NUM) table[lane] = *src;
 }
 __device__ __forceinline__ ColdBroadcast ColdBroadcast::fresh() const { return ColdBroadcast{p, az_opaque_lds(m)}; }
 #ifndef AZ_ROWSF_WAVES
@@ -887,7 +892,9 @@ __device__ __forceinline__ void az_rows_store(bool staged, bool full, bool live,
 // jd = reference_jd + t / 1440 (src/Constellation.zig L573-581), whose rounding at 2.46e6 days moves every table entry by up
 // to 3e-9 rad -- the table, noise included, is what parity is measured against (a carried pair drifts 1e-8 rad = 85 mm).
 #define AZ_FRAME_SEG 256
-template <bool VEL, int FRAME, int SINK, bool ECC>
+// DELTA: quasi-uniform grid (fast_step.h): the segment's deviations delta_i, staged in LDS as fp32 before the loop (|delta| <=
+// 4e-6 min: an fp32 delta is good to 2.4e-13 min, the rounding of t itself), ride on the time value and on the small rotation of U.
+template <bool VEL, int FRAME, int SINK, bool ECC, bool DELTA = false>
 __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES : (FRAME == 1 ? 5 : AZ_ROWSF_WAVES))) k_rows_fast(PropArgs p)
 {
     typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
@@ -923,13 +930,20 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
             if (!window_ok) return;
             az_fast_rec_hot(rec, k); // scalar loads: the hot constants arrive in SGPRs
             az_wave_lds_fence();
+            if (DELTA && k.tc_ != 0.0 && lane == 0) cold_lds[FCX_udot] = fma(2.0 * rec[FC_nl2], k.tc_, rec[FCX_udot]); // rate of U about tc
         }
+        __shared__ float dl_lds[DELTA ? AZ_DELTA_SEG : 1]; // (the host keeps DELTA segments at AZ_DELTA_SEG points)
+        if (DELTA) {
+#pragma unroll
+            for (unsigned j = lane; j < AZ_DELTA_SEG; j += 64) dl_lds[j] = p.delta[t_lo + j]; // (the table is zero-padded by one segment)
+        }
+        az_wave_lds_fence();
         const double step = p.uniform_step;
         const double t_first = p.times[0] + off; // tsince of grid point 0; grid point i is t_first + i*step
         FastCarry fc;
         // seed one increment (64 grid steps) BEFORE this lane's first grid point
         az_seed_fast_rec(rec, rec[FC_nl2], fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, fc,
-                         McLds{cold_lds + FC_NUM + RC_NUM});
+                         McLds{cold_lds + FCX_NUM + RC_NUM});
         __shared__ double gst_lds[FRAME ? 2 * AZ_FRAME_SEG : 2];
         if (FRAME) {
 #pragma unroll
@@ -946,19 +960,23 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
         for (; window_ok && base < t_hi; base += 64) {
             const unsigned i = base + lane;
             const bool live = i < t_hi;
-            const double t = fma((double)i, step, t_first);
+            double t = fma((double)i, step, t_first), dl = 0.0;
+            if (DELTA) {
+                dl = (double)dl_lds[i - t_lo]; // (segments are multiples of 64 points, at most AZ_DELTA_SEG)
+                t += dl;
+            }
             // the cold constants are re-read from LDS where they are used: an address the compiler cannot see through
             // keeps it from hoisting 16 loop-invariant loads into 32 VGPRs.  The opaque value is the LDS byte address of
             // the table itself, in a VGPR: DS addresses are VGPRs, and from one VGPR base every read is an immediate
             // offset (round 2's opaque scalar zero cost an s_add + v_mov per read: twelve VALU slots per iteration)
             const double *cold_now = az_opaque_lds(cold_lds);
             k.cold = cold_now;
-            const RotCoefLds rk{cold_now + FC_NUM};
+            const RotCoefLds rk{cold_now + FCX_NUM};
             double r[3], v[3];
 #if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
             r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
 #else
-            const bool bad = az_sgp4_fast_step<VEL, ECC>(k, p.g, rk, t, fc, r, v);
+            const bool bad = az_sgp4_fast_step<VEL, ECC, DELTA>(k, p.g, rk, t, fc, r, v, dl);
             if (az_any(bad && live)) break;
 #endif
             if (SINK == AZ_SINK_SCREEN) {
@@ -1020,7 +1038,7 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
 #define AZ_TILE_SATS 16
 #define AZ_TILE_SEG_MAX 1024 /* longest time segment of an ECEF launch (its Greenwich-angle table sits in LDS) */
 #define AZ_TILE_PITCH 49 /* doubles per staged time row: 48 + 1 (lane stride 98 dwords: ds_write_b64 conflict-free per half-wave) */
-template <bool VEL, int FRAME = 0> // FRAME: 0 TEME, 1 ECEF, 2 geodetic positions (+ ECEF velocities)
+template <bool VEL, int FRAME = 0, bool DELTA = false> // FRAME: 0 TEME, 1 ECEF, 2 geodetic positions (+ ECEF velocities); DELTA: see k_rows_fast
 __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
 {
     constexpr unsigned NA = VEL ? 2u : 1u;
@@ -1059,11 +1077,16 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
             gst[2 * j] = p.sin_g[t_lo + j];
             gst[2 * j + 1] = p.cos_g[t_lo + j];
         }
-        __syncthreads();
     }
     const bool ecc = AZ_FLAG_ECLASS(fl) != 0; // wave-uniform
     const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
     const double step = p.uniform_step, t_first = p.times[0] + off;
+    __shared__ float dl_lds[DELTA ? AZ_DELTA_SEG : 1]; // the segment's deviations from the ideal grid, one table per tile
+    if (DELTA) {
+        if (threadIdx.x < AZ_DELTA_SEG) dl_lds[threadIdx.x] = p.delta[t_lo + threadIdx.x]; // (zero-padded by one segment)
+        if (!ECEF) __syncthreads();
+    }
+    if (ECEF) __syncthreads(); // (gst above, and dl_lds)
     FastKBcast k;
     FastCarry fc;
     if (!dead) {
@@ -1074,7 +1097,9 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
         if (!az_plan_window(p, blockIdx.y, slot, w_a, w_b, k)) dead = true;
         az_fast_rec_hot(rec, k);
         az_wave_lds_fence();
-        az_seed_fast_rec(rec, rec[FC_nl2], fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, fc, McLds{cold_lds + FC_NUM + RC_NUM});
+        if (DELTA && k.tc_ != 0.0 && lane == 0) cold_lds[FCX_udot] = fma(2.0 * rec[FC_nl2], k.tc_, rec[FCX_udot]); // rate of U about tc
+        az_wave_lds_fence();
+        az_seed_fast_rec(rec, rec[FC_nl2], fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, fc, McLds{cold_lds + FCX_NUM + RC_NUM});
     }
     // This thread's share of a tile flush, fixed for the whole kernel: pieces q = 1024 m + tid, m < 3, of the 3,072
     // sixteen-byte pieces of a full tile (positions: 64 time rows x 24 pieces, then velocities).  Per piece the LDS byte
@@ -1100,11 +1125,15 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
         const bool live = i < t_hi;
         double r[3], v[3];
         if (!dead) {
-            const double t = fma((double)i, step, t_first);
+            double t = fma((double)i, step, t_first), dl = 0.0;
+            if (DELTA) {
+                dl = (double)dl_lds[i - t_lo]; // (segments are multiples of 64 points, at most AZ_DELTA_SEG)
+                t += dl;
+            }
             const double *cold_now = az_opaque_lds(cold_lds);
             k.cold = cold_now;
-            const RotCoefLds rk{cold_now + FC_NUM};
-            const bool bad = ecc ? az_sgp4_fast_step<VEL, true>(k, p.g, rk, t, fc, r, v) : az_sgp4_fast_step<VEL, false>(k, p.g, rk, t, fc, r, v);
+            const RotCoefLds rk{cold_now + FCX_NUM};
+            const bool bad = ecc ? az_sgp4_fast_step<VEL, true, DELTA>(k, p.g, rk, t, fc, r, v, dl) : az_sgp4_fast_step<VEL, false, DELTA>(k, p.g, rk, t, fc, r, v, dl);
             if (ECEF) {
                 const unsigned jj = min(i, t_hi - 1) - t_lo;
                 const double sg = gst[2 * jj], cg = gst[2 * jj + 1];
@@ -1200,7 +1229,7 @@ __device__ __forceinline__ void az_flush_pair3(unsigned a, float *out, unsigned 
 // k_rows_fast in PACKED fp32 arithmetic (fast_step_f32.h) for fp32 outputs: near-circular members, TEME, uniform
 // grid.  A lane carries two adjacent grid points (2i, 2i+1), a wave 128 per iteration: 1,536 contiguous bytes per
 // array, staged through LDS like the fp64 rows.  All constants are wave-uniform scalars (SGPRs).
-template <bool VEL, bool MIXED = false> // MIXED: az_sgp4_fast_step_f32p (O(1) quantities in fp64: the default for fp32 outputs)
+template <bool VEL, bool MIXED = false, bool DELTA = false> // MIXED: az_sgp4_fast_step_f32p (O(1) quantities in fp64: the default for fp32 outputs); DELTA: see k_rows_fast
 __global__ void __launch_bounds__(64, MIXED ? AZ_ROWSF32P_WAVES : AZ_ROWSF32_WAVES) k_rows_fast32(PropArgs p)
 {
     const unsigned lane = threadIdx.x;
@@ -1234,6 +1263,7 @@ __global__ void __launch_bounds__(64, MIXED ? AZ_ROWSF32P_WAVES : AZ_ROWSF32_WAV
             az_double_increments(k0);                           // ... of 128: one lane step
             window_ok = az_plan_window(p, blockIdx.y, row + p.redo_slot0, w_a, w_b, k0);
             if (!window_ok) return;                             // (a static item of the redo list)
+            az_fast_udot(k0);                                   // (DELTA: rate of U about the window's tc)
             az_load_fast(p.el, p.n_pad, s, fl, p.inc, 1, k1);   // increments of one grid step
             {
                 const double *w = p.plan_win + ((size_t)blockIdx.y * p.plan_stride + row + p.redo_slot0) * AZ_PLAN_NUM;
@@ -1258,6 +1288,12 @@ __global__ void __launch_bounds__(64, MIXED ? AZ_ROWSF32P_WAVES : AZ_ROWSF32_WAV
             az_seed_fast(p.el, p.n_pad, s, fma((double)(t_lo + 2 * lane) - 128.0, step, t_first), k.tc, f0);
             az_seed_fast32(f0, k1, fc);
         }
+        __shared__ __attribute__((aligned(8))) float dl_lds[DELTA ? AZ_DELTA_SEG : 2];
+        if (DELTA) {
+#pragma unroll
+            for (unsigned j = lane; j < AZ_DELTA_SEG; j += 64) dl_lds[j] = p.delta[t_lo + j]; // (the table is zero-padded by one segment)
+            az_wave_lds_fence();
+        }
 #pragma unroll 1
         for (; window_ok && base < t_hi; base += 128) {
             const unsigned i = base + 2 * lane;
@@ -1272,8 +1308,10 @@ __global__ void __launch_bounds__(64, MIXED ? AZ_ROWSF32P_WAVES : AZ_ROWSF32_WAV
 #if defined(AZ_ABLATE) && AZ_ABLATE == 2 /* tuning experiment: stores only */
             r[0] = az_splat2((float)t); r[1] = r[0] + 1.0f; r[2] = r[0] + 2.0f; v[0] = r[0] + 3.0f; v[1] = r[0] + 4.0f; v[2] = r[0] + 5.0f;
 #else
-            if (MIXED) az_sgp4_fast_step_f32p<VEL>(k, p.g, t, fc, r, v);
-            else az_sgp4_fast_step_f32<VEL>(k, p.g, t, fc, r, v);
+            az_f2 dl = az_splat2(0.0f);
+            if (DELTA) dl = *reinterpret_cast<const az_f2 *>(dl_lds + (i - t_lo)); // (i - t_lo is even, below AZ_DELTA_SEG)
+            if (MIXED) az_sgp4_fast_step_f32p<VEL, DELTA>(k, p.g, t, fc, r, v, dl);
+            else az_sgp4_fast_step_f32<VEL, DELTA>(k, p.g, t, fc, r, v, dl);
 #endif
 #if defined(AZ_ABLATE) && AZ_ABLATE == 1 /* tuning experiment: arithmetic only (every component stays live) */
             if (!(live_a && (r[0].x + r[1].x + r[2].x + r[0].y + r[1].y + r[2].y +
@@ -1494,7 +1532,7 @@ __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
         }
     }
     const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
-    const bool uniform = p.uniform_step != 0.0;
+    const bool uniform = p.uniform_step != 0.0 && p.delta == nullptr; // (a quasi-uniform grid: the time table, like any other grid)
     const double step = p.uniform_step, t_first = uniform ? p.times[0] + off : 0.0;
     const RotK rk = az_rotk();
     const size_t out_row = p.rows_compact ? row : s;

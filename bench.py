@@ -241,7 +241,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
         return e0.elapsed_time(e1) / steps
 
     def case(key, workload, kernel, dev, pairs, n_times, *, layout, vel=True, f32=False, mode=0, steps=50, warm=20,
-             cold=False, rows=16, ref_jd=0.0, arith32=False, stride_align=0):
+             cold=False, rows=16, ref_jd=0.0, arith32=False, stride_align=0, grid="uniform"):
         if key in skip:
             return
         ent = {"key": key, "workload": workload, "kernel": kernel}
@@ -250,6 +250,21 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             dev.set_f32_arithmetic(arith32)
             times = np.arange(n_times, dtype=np.float64)
             offs = (synth.START_JD - dev.epochs) * 1440.0
+            if grid == "jdfr":
+                # the reference's own call: SatrecArray.sgp4(jd, fr) with jd = full(n, day), fr = f0 + arange(n)/1440
+                # (examples/python_sgp4.py L31-33) -> times = ((jd + fr) - reference_jd) * 1440 (api.py L300-302): uniform only to
+                # ~4e-7 min after the rounding of jd + fr at 2.46e6 days
+                jd = np.full(n_times, synth.START_JD)
+                fr = 0.32853009 + np.arange(n_times) / 1440.0
+                rjd = jd[0] + fr[0]
+                times = ((jd + fr) - rjd) * 1440.0
+                offs = (rjd - dev.epochs) * 1440.0
+                st_ = (times[-1] - times[0]) / (n_times - 1)
+                ent["grid"] = {"kind": "jd+fr (api.py L300-302)", "max_dev_from_uniform_min": float(np.abs(times - (times[0] + np.arange(n_times) * st_)).max())}
+            elif grid == "irregular":
+                # one-minute grid with +-20 s of jitter per point (sorted): no fast path applies
+                times = times + np.random.default_rng(7).uniform(-1.0 / 3.0, 1.0 / 3.0, n_times)
+                ent["grid"] = {"kind": "one-minute steps + uniform(-20 s, 20 s) jitter"}
             stride = (n + stride_align - 1) // stride_align * stride_align if (stride_align and layout == _native.TIME_MAJOR) else n
             shape = (n_times, stride, 3) if layout == _native.TIME_MAJOR else (n, n_times, 3)
             odt = torch.float32 if f32 else torch.float64
@@ -258,6 +273,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             pp, vp = pos.data_ptr(), (v.data_ptr() if vel else None)
             dev.propagate_device(times, offs, pp, vp, mode=mode, reference_jd=ref_jd, layout=layout, stride=(stride if layout == _native.TIME_MAJOR else 0), stream=sptr, f32=f32)
             torch.cuda.synchronize()
+            ent["path"] = dev.last_path()  # azh_last_path: 1 k_rows_fast, 2 k_tiles_fast, 4 k_rows, 8 k_propagate, 16 k_rows_deep, 32 quasi-uniform form, 64 k_tiles
             ms = timed(lambda: dev.propagate_device_cached(pp, vp, layout=layout, stride=(stride if layout == _native.TIME_MAJOR else 0), stream=sptr, f32=f32), warm, steps)
             props = n * n_times
             nbytes = props * (BYTES_OUT_PV if vel else BYTES_OUT_P) * (0.5 if f32 else 1.0) + n_times * 8 + n * ELEM_BYTES_PER_SAT
@@ -314,6 +330,15 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
     case("config2_time_major_aligned", "config 2, TIME-major output with the time rows padded to a multiple of 16 satellites (out_stride_sats = "
          "13,488: every 384-byte tile run on whole cache lines; what SatrecArray.sgp4_device allocates), fp64 TEME pos+vel",
          "k_tiles_fast<pos+vel> (streaming flush) + redo", dev2, pairs2, 1440, layout=TM, stride_align=16)
+    case("config2_time_major_jdfr", "config 2, TIME-major, on the grid the reference's own API call produces: SatrecArray.sgp4(jd, fr), "
+         "times = ((jd + fr) - reference_jd) * 1440 (quasi-uniform: first-order correction of every point to its rounded time)",
+         "k_tiles_fast<pos+vel,DELTA> + redo", dev2, pairs2, 1440, layout=TM, grid="jdfr")
+    case("config2_sat_major_jdfr", "config 2, satellite-major, on the (jd, fr) grid of the reference's API call",
+         "k_rows_fast<pos+vel,DELTA> + redo", dev2, pairs2, 1440, layout=SM, grid="jdfr")
+    case("config2_time_major_irregular", "config 2, TIME-major, irregular grid (one-minute steps with +-20 s jitter)",
+         "generic time-major kernel", dev2, pairs2, 1440, layout=TM, grid="irregular", steps=20, warm=5)
+    case("config2_sat_major_irregular", "config 2, satellite-major, irregular grid (one-minute steps with +-20 s jitter)",
+         "k_rows (generic, lane = time)", dev2, pairs2, 1440, layout=SM, grid="irregular", steps=20, warm=5)
     case("config2_ecef_time_major", "config 2, ECEF time-major (the default of the reference's high-level propagate(), "
          "Constellation.zig L489-506), fp64 pos+vel", "k_tiles_fast<pos+vel,ECEF> + redo", dev2, pairs2, 1440, layout=TM, mode=1, ref_jd=ref_jd)
     case("config2_ecef_sat_major", "config 2, ECEF satellite-major, fp64 pos+vel", "k_rows_fast<pos+vel,FRAME> + redo",

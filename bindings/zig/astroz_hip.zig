@@ -116,6 +116,7 @@ pub extern "c" fn azh_propagate_device_window(h: ?*Handle, row_lo: usize, row_hi
 pub extern "c" fn azh_set_f32_arithmetic(h: ?*Handle, mode: i32) i32; // 0 mixed precision (default), 1 packed fp32, 2 fp64 rounded at the store
 pub extern "c" fn azh_set_fast_path(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_set_tile_kernel(h: ?*Handle, enabled: i32) i32;
+pub extern "c" fn azh_last_path(h: ?*const Handle) u32; // AZH_PATH_* bits: which kernel families the last call launched
 pub extern "c" fn azh_propagate_one_device(h: ?*Handle, sat_index: usize, d_tsince_min: [*]const f64, n: usize, d_pos: [*]f64,
     d_vel: ?[*]f64, d_err: ?[*]u8, stream: ?*anyopaque) i32;
 pub extern "c" fn azh_selftest_math(x: [*]const f64, n: usize, out6n: [*]f64, device: i32) i32;

@@ -334,6 +334,19 @@ int32_t azh_set_timing(azh_constellation *c, int32_t enabled);
 /* elapsed GPU milliseconds of the most recent propagate call's kernels (hipEvent on the
  * launch stream; valid after azh_synchronize) */
 double azh_last_kernel_ms(azh_constellation *c);
+/* which kernel families the most recent propagate / screen call of this handle launched (bit mask): lets a caller -- and the
+ * tests -- see that a grid took the branch-free kernels.  A grid counts as uniform when times[i] = times[0] + i*step within
+ * 4e-6 min: exactly uniform grids, and the quasi-uniform ones the reference's own (jd, fr) arithmetic produces
+ * (times = ((jd + fr) - reference_jd) * 1440 is quantised to 2^-31 day = 6.7e-7 min; api.py L300-302, Constellation.zig
+ * L266-269), which run the same kernels with a first-order correction of every point to its actual time. */
+#define AZH_PATH_ROWS_FAST 1u     /* k_rows_fast / k_rows_fast32: lane = time, branch-free, satellite-major rows (or the screen) */
+#define AZH_PATH_TILES_FAST 2u    /* k_tiles_fast: lane = time, branch-free, 16-row time-major tiles */
+#define AZH_PATH_ROWS_GENERIC 4u  /* k_rows over the whole near-earth list: lane = time, any grid */
+#define AZH_PATH_LANE_SAT 8u      /* k_propagate: lane = satellite (short grids; time-major with masks / fp32 / irregular grids) */
+#define AZH_PATH_DEEP_ROWS 16u    /* k_rows_deep: lane = time deep-space rows */
+#define AZH_PATH_QUASI_UNIFORM 32u /* the staged grid is quasi-uniform: the fast kernels ran in their DELTA form */
+#define AZH_PATH_TILES_GENERIC 64u /* k_tiles: lane = time, any grid / masks / fp32, 16-row time-major tiles */
+uint32_t azh_last_path(const azh_constellation *c);
 
 #ifdef __cplusplus
 }

@@ -93,8 +93,9 @@ static void emul_fast_run(const double* fields, unsigned flags, const double* gr
 // set-up and validation per segment over ALL its grid points, lane l producing points t_lo + l + 64 j with increments of
 // 64 grid steps.  out6: n_times rows; bad_out[i] = 1 where the point belongs to a rejected segment (window bounds) or,
 // eccentric form, follows a rejected step of its segment (the kernel hands the rest of the segment to the generic path).
-void emul_rows_fast(const double* fields, unsigned flags, const double* grav6, double t_first, double step, int n_times, int tile,
-                    int ecc, double* out6, int* bad_out)
+// delta (may be null): quasi-uniform grid, point i sits at t_first + i step + delta[i] (fast_step.h, DELTA); dmax >= max |delta|
+static void emul_rows_fast_impl(const double* fields, unsigned flags, const double* grav6, double t_first, double step, int n_times, int tile,
+                                int ecc, double* out6, int* bad_out, const float* delta, double dmax)
 {
     AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
     double inc[2 * AZ_INC_NUM];
@@ -108,7 +109,7 @@ void emul_rows_fast(const double* fields, unsigned flags, const double* grav6, d
         az_load_fast(fields, 1, 0, flags, inc, 0, k);
         const double w_a = fma((double)t_lo, step, t_first), w_b = fma((double)(t_hi - 1), step, t_first);
         az_fast_window(fields, 1, 0, w_a, w_b, 64.0 * step, k);
-        const bool ok = ecc ? az_fast_window_ok<true>(k, g, w_a, w_b) : az_fast_window_ok<false>(k, g, w_a, w_b);
+        const bool ok = ecc ? az_fast_window_ok<true>(k, g, w_a, w_b, dmax) : az_fast_window_ok<false>(k, g, w_a, w_b, dmax);
         int first_bad_base = ok ? t_hi : t_lo; // the wave leaves the loop at the first iteration any live lane rejects
         for (int lane = 0; lane < 64 && ok; ++lane) {
             FastCarry st;
@@ -116,9 +117,17 @@ void emul_rows_fast(const double* fields, unsigned flags, const double* grav6, d
             for (int base = t_lo; base < t_hi; base += 64) {
                 const int i = base + lane;
                 double r[3], v[3];
-                const double t = fma((double)i, step, t_first);
-                const bool bad = ecc ? az_sgp4_fast_step<true, true>(k, g, RotCoefLit(), t, st, r, v)
-                                     : az_sgp4_fast_step<true, false>(k, g, RotCoefLit(), t, st, r, v);
+                double t = fma((double)i, step, t_first);
+                bool bad;
+                if (delta) {
+                    const double dl = i < n_times ? (double)delta[i] : 0.0;
+                    t += dl;
+                    bad = ecc ? az_sgp4_fast_step<true, true, true>(k, g, RotCoefLit(), t, st, r, v, dl)
+                              : az_sgp4_fast_step<true, false, true>(k, g, RotCoefLit(), t, st, r, v, dl);
+                } else {
+                    bad = ecc ? az_sgp4_fast_step<true, true>(k, g, RotCoefLit(), t, st, r, v)
+                              : az_sgp4_fast_step<true, false>(k, g, RotCoefLit(), t, st, r, v);
+                }
                 if (i >= t_hi) break;
                 if (bad && base < first_bad_base) first_bad_base = base;
                 memcpy(out6 + 6 * (size_t)i, r, 24); memcpy(out6 + 6 * (size_t)i + 3, v, 24);
@@ -126,6 +135,17 @@ void emul_rows_fast(const double* fields, unsigned flags, const double* grav6, d
         }
         for (int i = t_lo; i < t_hi; ++i) bad_out[i] = (t_lo + (i - t_lo) / 64 * 64 >= first_bad_base) ? 1 : 0;
     }
+}
+
+void emul_rows_fast(const double* fields, unsigned flags, const double* grav6, double t_first, double step, int n_times, int tile,
+                    int ecc, double* out6, int* bad_out)
+{
+    emul_rows_fast_impl(fields, flags, grav6, t_first, step, n_times, tile, ecc, out6, bad_out, nullptr, 0.0);
+}
+void emul_rows_fast_delta(const double* fields, unsigned flags, const double* grav6, double t_first, double step, int n_times, int tile,
+                          int ecc, const float* delta, double dmax, double* out6, int* bad_out)
+{
+    emul_rows_fast_impl(fields, flags, grav6, t_first, step, n_times, tile, ecc, out6, bad_out, delta, dmax);
 }
 
 void emul_propagate_fast(const double* fields, unsigned flags, const double* grav6, double ts0, double dt, int n,
@@ -139,7 +159,7 @@ void emul_propagate_fast(const double* fields, unsigned flags, const double* gra
 // windows of at most 6 lane steps (a 768-point segment) and ~3,000 minutes.  out6: 2n rows in the order
 // (even_0, odd_0, even_1, ...), bad_out: n.
 static void emul_fast32_run(const double* fields, unsigned flags, const double* grav6, double ts0, double step, int lane_steps,
-                            int n, double* out6, int* bad_out, bool precise)
+                            int n, double* out6, int* bad_out, bool precise, const float* delta2 = nullptr)
 {
     AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
     const double dt = step * lane_steps;
@@ -170,7 +190,12 @@ static void emul_fast32_run(const double* fields, unsigned flags, const double* 
         az_seed_fast32(f0, k1, st);
         for (int i = w0; i < w1; ++i) {
             az_f2 r[3], v[3];
-            if (precise) az_sgp4_fast_step_f32p<true>(k32, g, ts0 + i * dt, st, r, v);
+            if (delta2) {
+                // delta2[2 i], [2 i + 1]: deviations of the lane's two grid points from the ideal grid
+                az_f2 dl; dl.x = delta2[2 * i]; dl.y = delta2[2 * i + 1];
+                if (precise) az_sgp4_fast_step_f32p<true, true>(k32, g, ts0 + i * dt, st, r, v, dl);
+                else az_sgp4_fast_step_f32<true, true>(k32, g, ts0 + i * dt, st, r, v, dl);
+            } else if (precise) az_sgp4_fast_step_f32p<true>(k32, g, ts0 + i * dt, st, r, v);
             else az_sgp4_fast_step_f32<true>(k32, g, ts0 + i * dt, st, r, v);
             bad_out[i] = (win_bad || (precise && !az_fast32p_window_ok(k0, w_a, w_b))) ? 1 : 0;
             for (int j = 0; j < 3; ++j) {
@@ -191,6 +216,12 @@ void emul_propagate_fast32p(const double* fields, unsigned flags, const double* 
                             int n, double* out6, int* bad_out)
 {
     emul_fast32_run(fields, flags, grav6, ts0, step, lane_steps, n, out6, bad_out, true);
+}
+
+void emul_propagate_fast32p_delta(const double* fields, unsigned flags, const double* grav6, double ts0, double step, int lane_steps,
+                                  int n, const float* delta2, double* out6, int* bad_out)
+{
+    emul_fast32_run(fields, flags, grav6, ts0, step, lane_steps, n, out6, bad_out, true, delta2);
 }
 
 // the generic deep-space step as one lane of k_rows_deep runs it: per iteration the lane starts from a chunk seed (the

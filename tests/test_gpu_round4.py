@@ -1,0 +1,192 @@
+"""GPU parity tests (-m gpu), fourth batch.
+
+1. The reference's OWN (jd, fr) time grids -- `times = ((jd + fr) - reference_jd) * 1440` (bindings/python/astroz/api.py
+   L300-302, src/Constellation.zig L266-269), uniform only to ~4e-7 min after the rounding of jd + fr -- run the
+   branch-free kernels (k_rows_fast / k_tiles_fast in their DELTA form), proven through azh_last_path, with parity against
+   the oracle AT THE ROUNDED TIMES on every row of BASELINE configs 2 and 3, both layouts.
+2. Irregular grids, masks and fp32 outputs in the time-major layout run the generic tile kernel (k_tiles).
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL_R, TOL_V = 1e-6, 1e-9   # km, km/s (north_star: <10 m, <1 um/s)
+
+
+@pytest.fixture(scope="module")
+def native():
+    import __graft_entry__ as g
+    g.build()
+    from astroz_amd import _native
+    assert _native.device_count() >= 1, "no HIP device: GPU tests must run on the MI355X box"
+    return _native
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from astroz_amd import synth
+    return synth
+
+
+def jdfr_grid(kind, n, start_jd):
+    """The (jd, fr) forms of the reference's callers: examples/python_sgp4.py L31-33 ('example'), the same from the top of
+    a day ('midnight'), benchmarks/sgp4_compat_test.py L120-133 ('linspace')."""
+    jd = np.full(n, start_jd)
+    fr = {"example": 0.32853009 + np.arange(n) / 1440.0,
+          "midnight": np.arange(n) / 1440.0,
+          "linspace": np.linspace(0.0, 1.0, n)}[kind]
+    return jd, fr
+
+
+def api_times(jd, fr, epochs):
+    """SatrecArray._grid = api.py L300-302."""
+    reference_jd = jd[0] + fr[0]
+    return ((jd + fr) - reference_jd) * 1440.0, (reference_jd - epochs) * 1440.0, reference_jd
+
+
+def test_reference_grids_are_only_quasi_uniform():
+    """The premise: none of the reference's canonical grids is uniform to rounding, all are inside AZ_DELTA_MAX."""
+    for kind in ("example", "midnight", "linspace"):
+        jd, fr = jdfr_grid(kind, 1440, 2460800.5)
+        t, _, _ = api_times(jd, fr, np.zeros(1))
+        step = (t[-1] - t[0]) / (len(t) - 1)
+        dev = np.abs(t - (t[0] + np.arange(len(t)) * step)).max()
+        assert 4 * 2.3e-16 * 1440 < 1e-8 < dev < 4e-6, (kind, dev)
+
+
+@pytest.mark.parametrize("n_deep,kind", [(0, "example"), (0, "linspace"), (1522, "example"), (1522, "midnight")])
+def test_jdfr_grids_full_size_all_rows_take_the_fast_kernels(native, orc, synth, n_deep, kind):
+    """BASELINE configs 2 and 3 at FULL size on the reference's own (jd, fr) grids: every row vs the oracle at the rounded
+    times, both layouts, and azh_last_path shows the branch-free kernels in their quasi-uniform form."""
+    import torch
+    pairs = synth.synth_catalog(n_near=13478, n_deep=n_deep)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    n = 1440
+    jd, fr = jdfr_grid(kind, n, synth.START_JD)
+    times, off, _ = api_times(jd, fr, dev.epochs)
+    e0, p0, v0 = cat.propagate(times, off, layout=orc.SAT_MAJOR, threads=16)
+    pos = torch.empty((dev.n, n, 3), dtype=torch.float64, device="cuda")
+    vel = torch.empty_like(pos)
+    err = torch.empty((dev.n, n), dtype=torch.uint8, device="cuda")
+    dev.propagate_device(times, off, pos.data_ptr(), vel.data_ptr(), layout=native.SAT_MAJOR, d_err=err.data_ptr())
+    dev.synchronize()
+    path = dev.last_path()
+    assert path & native.PATH_ROWS_FAST and path & native.PATH_QUASI_UNIFORM, path
+    assert not path & (native.PATH_ROWS_GENERIC | native.PATH_LANE_SAT), path
+    assert np.array_equal(err.cpu().numpy(), e0)
+    dr = float(np.abs(pos.cpu().numpy() - p0).max())
+    dv = float(np.abs(vel.cpu().numpy() - v0).max())
+    assert dr < TOL_R and dv < TOL_V, (dr, dv)
+    del pos, vel
+    ptm = torch.empty((n, dev.n, 3), dtype=torch.float64, device="cuda")
+    vtm = torch.empty_like(ptm)
+    dev.propagate_device_cached(ptm.data_ptr(), vtm.data_ptr(), layout=native.TIME_MAJOR)
+    dev.synchronize()
+    path = dev.last_path()
+    assert path & native.PATH_TILES_FAST and path & native.PATH_QUASI_UNIFORM, path
+    assert not path & (native.PATH_LANE_SAT | native.PATH_TILES_GENERIC), path
+    dr = float(np.abs(ptm.cpu().numpy().transpose(1, 0, 2) - p0).max())
+    dv = float(np.abs(vtm.cpu().numpy().transpose(1, 0, 2) - v0).max())
+    assert dr < TOL_R and dv < TOL_V, (dr, dv)
+
+
+def test_jdfr_grid_matches_the_generic_path_and_ecef(native, orc, synth):
+    """The quasi-uniform form against the generic kernels on the same grid (fast path off), ECEF / geodetic output, a grid
+    running backwards, positions only, and a grid too ragged for the fast path (falls back, still correct)."""
+    pairs = synth.synth_catalog(n_near=900, n_deep=80, seed=33)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    n = 700
+    jd, fr = jdfr_grid("example", n, synth.START_JD + 3.0)
+    times, off, ref = api_times(jd, fr, dev.epochs)
+    for layout, olay in ((native.SAT_MAJOR, orc.SAT_MAJOR), (native.TIME_MAJOR, orc.TIME_MAJOR)):
+        for mode, omode in ((native.OUT_TEME, orc.TEME), (native.OUT_ECEF, orc.ECEF), (native.OUT_GEODETIC, orc.GEODETIC)):
+            shape = (dev.n, n, 3) if layout == native.SAT_MAJOR else (n, dev.n, 3)
+            pos, vel = np.empty(shape), np.empty(shape)
+            dev.propagate_host(times, off, pos=pos, vel=vel, mode=mode, reference_jd=ref, layout=layout)
+            path = dev.last_path()
+            assert path & native.PATH_QUASI_UNIFORM and path & (native.PATH_ROWS_FAST | native.PATH_TILES_FAST), (layout, mode, path)
+            _, p0, v0 = cat.propagate(times, off, layout=olay, mode=omode, reference_jd=ref)
+            dq = np.abs(pos - p0)
+            if mode == native.OUT_GEODETIC:
+                dq[..., 1] = np.minimum(dq[..., 1], 2 * np.pi - dq[..., 1])   # longitude wraps
+            assert dq.max() < TOL_R, (layout, mode, dq.max())
+            assert np.abs(vel - v0).max() < TOL_V
+    # fast path off: the generic kernels on the very same grid
+    pos, vel = np.empty((dev.n, n, 3)), np.empty((dev.n, n, 3))
+    dev.propagate_host(times, off, pos=pos, vel=vel, layout=native.SAT_MAJOR)
+    dev.set_fast_path(False)
+    pos2, vel2 = np.empty_like(pos), np.empty_like(vel)
+    dev.propagate_host(times, off, pos=pos2, vel=vel2, layout=native.SAT_MAJOR)
+    assert not dev.last_path() & (native.PATH_ROWS_FAST | native.PATH_QUASI_UNIFORM)
+    dev.set_fast_path(True)
+    assert np.abs(pos - pos2).max() < 2e-7 and np.abs(vel - vel2).max() < 2e-10
+    # backwards in time, positions only
+    tb = times[::-1].copy()
+    pos = np.empty((dev.n, n, 3))
+    dev.propagate_host(tb, off, pos=pos, layout=native.SAT_MAJOR)
+    assert dev.last_path() & native.PATH_QUASI_UNIFORM
+    _, p0, _ = cat.propagate(tb, off, velocities=False)
+    assert np.abs(pos - p0).max() < TOL_R
+    # a grid with 20-second jitter is not quasi-uniform: generic kernels, same answers
+    rng = np.random.default_rng(4)
+    tj = times + rng.uniform(-1 / 3, 1 / 3, n)
+    pos, vel = np.empty((dev.n, n, 3)), np.empty((dev.n, n, 3))
+    dev.propagate_host(tj, off, pos=pos, vel=vel, layout=native.SAT_MAJOR)
+    assert not dev.last_path() & (native.PATH_ROWS_FAST | native.PATH_QUASI_UNIFORM)
+    _, p0, v0 = cat.propagate(tj, off)
+    assert np.abs(pos - p0).max() < TOL_R and np.abs(vel - v0).max() < TOL_V
+
+
+def test_satrec_array_jdfr_runs_the_tile_kernel(native, orc, synth):
+    """The call the reference's headline is quoted on: SatrecArray.sgp4(jd, fr) / sgp4_device(jd, fr)."""
+    from astroz_amd.api import Satrec, SatrecArray
+    pairs = synth.synth_catalog(n_near=1000, n_deep=0, seed=8)
+    arr = SatrecArray([Satrec.twoline2rv(a, b) for a, b in pairs])
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    n = 1440
+    jd, fr = jdfr_grid("linspace", n, synth.START_JD)
+    times, off, _ = api_times(jd, fr, cat.epoch_jd)
+    e0, p0, v0 = cat.propagate(times, off)
+    e, r, v = arr.sgp4(jd, fr)
+    path = arr._dev.last_path()
+    assert path & native.PATH_TILES_FAST and path & native.PATH_QUASI_UNIFORM and not path & native.PATH_LANE_SAT, path
+    assert np.array_equal(e, e0) and np.abs(r - p0).max() < TOL_R and np.abs(v - v0).max() < TOL_V
+    e, r_tm, v_tm = arr.sgp4_device(jd, fr)
+    arr.synchronize()
+    path = arr._dev.last_path()
+    assert path & native.PATH_TILES_FAST and path & native.PATH_QUASI_UNIFORM, path
+    assert np.abs(r_tm.cpu().numpy().transpose(1, 0, 2) - p0).max() < TOL_R
+    assert np.abs(v_tm.cpu().numpy().transpose(1, 0, 2) - v0).max() < TOL_V
+
+
+def test_jdfr_grid_fp32_and_screen(native, orc, synth):
+    """fp32 outputs (mixed and packed arithmetic) and the fused screen on a (jd, fr) grid."""
+    import torch
+    pairs = synth.synth_catalog(n_near=700, n_deep=0, seed=14)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    n = 1536
+    jd, fr = jdfr_grid("example", n, synth.START_JD)
+    times, off, _ = api_times(jd, fr, dev.epochs)
+    _, p0, v0 = cat.propagate(times, off)
+    for mode, tr, tv in (("mixed", 6.0e-4, 6.0e-7), ("packed", 4.0e-3, 6.0e-6), ("fp64", 4.95e-4, 4.85e-7)):
+        dev.set_f32_arithmetic(mode)
+        pos = torch.empty((dev.n, n, 3), dtype=torch.float32, device="cuda")
+        vel = torch.empty_like(pos)
+        dev.propagate_device(times, off, pos.data_ptr(), vel.data_ptr(), layout=native.SAT_MAJOR, f32=True)
+        dev.synchronize()
+        assert dev.last_path() & native.PATH_ROWS_FAST and dev.last_path() & native.PATH_QUASI_UNIFORM
+        dr = float(np.abs(pos.cpu().numpy().astype(np.float64) - p0).max())
+        dv = float(np.abs(vel.cpu().numpy().astype(np.float64) - v0).max())
+        assert dr < tr and dv < tv, (mode, dr, dv)
+    dev.set_f32_arithmetic("mixed")
+    d, t = dev.screen_target(times, 5, 2000.0, off)
+    assert dev.last_path() & native.PATH_ROWS_FAST and dev.last_path() & native.PATH_QUASI_UNIFORM
+    d0, t0 = cat.screen_target(times, 5, 2000.0, off)
+    assert np.array_equal(t, t0) and np.abs(d - d0).max() < TOL_R
