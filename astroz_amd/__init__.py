@@ -30,6 +30,8 @@ _UNIX_EPOCH_JD = 2440587.5
 
 
 _CELESTRAK_GP = "https://celestrak.org/NORAD/elements/gp.php"
+# group aliases of the reference's loader (bindings/python/astroz/__init__.py L131-136): short names -> CelesTrak GROUP values
+_GROUP_ALIASES = {"all": "active", "iss": "stations", "gps": "gps-ops", "glonass": "glo-ops"}
 _fetcher = None
 
 
@@ -48,7 +50,8 @@ def celestrak_url(group=None, norad_id=None, fmt="tle"):
     if norad_id is not None:
         ids = norad_id if isinstance(norad_id, (list, tuple)) else [norad_id]
         return "%s?CATNR=%s&FORMAT=%s" % (_CELESTRAK_GP, ",".join(str(int(i)) for i in ids), fmt)
-    return "%s?GROUP=%s&FORMAT=%s" % (_CELESTRAK_GP, str(group).strip().lower(), fmt)
+    name = str(group).strip().lower()
+    return "%s?GROUP=%s&FORMAT=%s" % (_CELESTRAK_GP, _GROUP_ALIASES.get(name, name), fmt)
 
 
 def _urllib_fetch(url):
@@ -74,6 +77,8 @@ def _as_text(source, norad_id=None, fetch=None, allow_network=False):
     local file it names, or -- opt-in, see the module docstring -- what a URL / CelesTrak group name / `norad_id`
     resolves to (reference: bindings/python/astroz/__init__.py L163-181)."""
     if norad_id is not None:
+        if source is not None:
+            raise ValueError("pass either 'source' or 'norad_id', not both")
         return _download(celestrak_url(norad_id=norad_id), fetch, allow_network)
     if source is None:
         raise ValueError("Must specify 'source' or 'norad_id'")
@@ -91,7 +96,14 @@ def _as_text(source, norad_id=None, fetch=None, allow_network=False):
     if any(ln.lstrip().startswith("1 ") for ln in source.splitlines()):
         return source
     name = source.strip()
+    if name.lower().startswith("celestrak:"):
+        name = name[len("celestrak:"):].strip()   # explicit form: never mistaken for a mistyped file name
+        if not name:
+            raise ValueError("empty CelesTrak group name")
+        return _download(celestrak_url(group=name), fetch, allow_network)
     if one_line and name and all(c.isalnum() or c in "-_" for c in name):
+        if "." in name or os.sep in name:
+            raise FileNotFoundError(name)
         return _download(celestrak_url(group=name), fetch, allow_network)
     raise ValueError("source is neither TLE text, OMM JSON, an existing local file, a URL nor a CelesTrak group name")
 
@@ -299,32 +311,35 @@ def hohmann_transfer(mu, r1, r2):
     class _H(C.Structure):
         _fields_ = [(k, C.c_double) for k in ("sma", "dv1", "dv2", "total_dv", "transfer_time", "transfer_time_days")]
     h = _H()
-    if _native.lib().orbital_hohmann(float(mu), float(r1), float(r2), C.byref(h)) != 0:
+    rc = _native.lib().orbital_hohmann(float(mu), float(r1), float(r2), C.byref(h))
+    if rc == _native.AZ_ERR_HIP:
+        raise _native.NativeError(rc, "orbital_hohmann")   # no device: not an argument error
+    if rc != 0:
         raise ValueError("invalid transfer parameters (radii must be positive and differ by >1000 km)")
     return {k: getattr(h, k) for k, _ in _H._fields_}
 
 
+def _scalar(v, what, bad):
+    if v != v:   # NaN: the closed forms run on the device like every other floating-point path -- none visible
+        raise _native.NativeError(_native.AZ_ERR_HIP, what)
+    if v < 0:
+        raise ValueError(bad)
+    return v
+
+
 def orbital_velocity(mu, radius, sma=None):
     """Vis-viva speed; circular if `sma` is omitted."""
-    v = _native.lib().orbital_velocity(float(mu), float(radius), 0.0 if sma is None else float(sma))
-    if v < 0:
-        raise ValueError("invalid radius / semi-major axis")
-    return v
+    return _scalar(_native.lib().orbital_velocity(float(mu), float(radius), 0.0 if sma is None else float(sma)),
+                   "orbital_velocity", "invalid radius / semi-major axis")
 
 
 def orbital_period(mu, sma):
     """Period in seconds (Kepler's third law)."""
-    v = _native.lib().orbital_period(float(mu), float(sma))
-    if v < 0:
-        raise ValueError("invalid semi-major axis")
-    return v
+    return _scalar(_native.lib().orbital_period(float(mu), float(sma)), "orbital_period", "invalid semi-major axis")
 
 
 def escape_velocity(mu, radius):
-    v = _native.lib().orbital_escape_velocity(float(mu), float(radius))
-    if v < 0:
-        raise ValueError("invalid radius")
-    return v
+    return _scalar(_native.lib().orbital_escape_velocity(float(mu), float(radius)), "orbital_escape_velocity", "invalid radius")
 
 
 __all__ = ["__version__", "Tle", "Sgp4Constellation", "Constellation", "propagate", "screen", "coarse_screen",

@@ -30,8 +30,8 @@ EXPORTS = [
     "azh_constellation_from_tle_lines", "azh_constellation_from_elements", "azh_constellation_subset", "azh_constellation_free",
     "azh_num_satellites", "azh_num_sgp4", "azh_num_sdp4", "azh_get_epochs", "azh_get_status",
     "azh_get_field", "azh_propagate_host", "azh_propagate_device", "azh_propagate_device_cached", "azh_propagate_device_window",
-    "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile", "azh_set_timing", "azh_set_fast_path", "azh_set_tile_kernel", "azh_set_f32_arithmetic",
-    "azh_last_kernel_ms", "azh_last_path", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
+    "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile", "azh_set_timing", "azh_set_fast_path", "azh_set_tile_kernel", "azh_set_f32_arithmetic", "azh_set_f32_mode",
+    "azh_last_kernel_ms", "azh_last_path", "azh_set_host_copy_threads", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
     "azh_screen_target_host", "azh_screen_target_device", "azh_coarse_screen_device", "azh_coarse_screen_host",
     "azh_screen_all_host", "azh_constellation_from_omm_json", "azh_propagate_one_device", "azh_selftest_math",
     "azh_parse_tle_text", "azh_parse_omm_json", "azh_set_parse_threads", "coords_julian_to_gmst",
@@ -130,9 +130,9 @@ def lib():
     L.azh_group_padded_rows.restype = sz
     L.azh_group_get_epochs.argtypes = [vp, vp]
     L.azh_group_get_epochs.restype = i32
-    L.azh_group_propagate_host.argtypes = [vp, vp, sz, vp, vp, vp, i32, dbl, vp]
+    L.azh_group_propagate_host.argtypes = [vp, vp, sz, vp, sz, vp, vp, i32, dbl, vp]
     L.azh_group_propagate_host.restype = i32
-    L.azh_group_propagate_allgather.argtypes = [vp, vp, sz, vp, vp, vp]
+    L.azh_group_propagate_allgather.argtypes = [vp, vp, sz, vp, sz, vp, vp]
     L.azh_group_propagate_allgather.restype = i32
     L.azh_constellation_from_omm_json.argtypes = [C.c_char_p, sz, i32, i32, C.POINTER(vp)]
     L.azh_constellation_from_omm_json.restype = i32
@@ -186,8 +186,12 @@ def lib():
     L.azh_set_tile_kernel.restype = i32
     L.azh_set_f32_arithmetic.argtypes = [vp, i32]
     L.azh_set_f32_arithmetic.restype = i32
+    L.azh_set_f32_mode.argtypes = [vp, i32]
+    L.azh_set_f32_mode.restype = i32
     L.azh_last_kernel_ms.argtypes = [vp]
     L.azh_last_kernel_ms.restype = dbl
+    L.azh_set_host_copy_threads.argtypes = [i32]
+    L.azh_set_host_copy_threads.restype = None
     L.azh_last_path.argtypes = [vp]
     L.azh_last_path.restype = u32
     L.azh_propagate_device_f32.argtypes = L.azh_propagate_device.argtypes
@@ -419,14 +423,18 @@ class DeviceConstellation:
     F32_MODES = {"mixed": 0, "packed": 1, "fp64": 2}
 
     def set_f32_arithmetic(self, mode):
-        """Arithmetic behind fp32 outputs.  "mixed" / 0 / False (default): the mixed-precision step where it applies
-        (near-circular members, TEME, uniform grid: O(1) quantities in fp64, small ones in packed fp32 -- within 0.6 m /
-        0.6 mm/s of the fp64 oracle, i.e. the level of fp32 storage itself), fp64 rounded at the store elsewhere;
-        "packed" / 1 / True: packed fp32 arithmetic where it applies (opt-in: 4 m / 6 mm/s); "fp64" / 2: fp64 arithmetic
-        rounded once at the store everywhere (0.5 m / 0.4 mm/s).  Which kernel runs depends on whether the staged grid is
-        uniform, so fp32 results are not bit-stable across grids in the first two modes."""
+        """Arithmetic behind fp32 outputs (azh_set_f32_mode).  "mixed" / 0 (default): the mixed-precision step where it
+        applies (near-circular members on a uniform grid, satellite-major TEME: within 0.6 m / 0.6 mm/s of the fp64 oracle,
+        the level of fp32 storage itself), fp64 rounded at the store elsewhere; "packed" / 1: packed fp32 arithmetic where it
+        applies (opt-in: 4 m / 6 mm/s); "fp64" / 2: fp64 arithmetic rounded once at the store everywhere (0.5 m / 0.4 mm/s).
+        A bool keeps the meaning this setter was introduced with: False = "fp64", True = "packed".  Which kernel runs
+        depends on whether the staged grid is uniform, so fp32 results are not bit-stable across grids in the first two modes."""
+        if isinstance(mode, (bool, np.bool_)):
+            # the boolean this setter was introduced with: False = fp64 arithmetic rounded at the store, True = packed fp32
+            check(lib().azh_set_f32_arithmetic(self._h, 1 if mode else 0), "azh_set_f32_arithmetic")
+            return
         m = self.F32_MODES[mode] if isinstance(mode, str) else int(mode)
-        check(lib().azh_set_f32_arithmetic(self._h, m), "azh_set_f32_arithmetic")
+        check(lib().azh_set_f32_mode(self._h, m), "azh_set_f32_mode")
 
     def set_fast_path(self, enabled):
         check(lib().azh_set_fast_path(self._h, 1 if enabled else 0), "azh_set_fast_path")
@@ -492,7 +500,7 @@ class DeviceGroup:
         pos = np.empty((self.n, len(t), 3))
         vel = np.empty_like(pos) if velocities else None
         err = np.zeros((self.n, len(t)), dtype=np.uint8) if errors else None
-        check(lib().azh_group_propagate_host(self._h, t.ctypes.data, len(t), _ptr(off), pos.ctypes.data, _ptr(vel), mode,
+        check(lib().azh_group_propagate_host(self._h, t.ctypes.data, len(t), _ptr(off), 0 if off is None else len(off), pos.ctypes.data, _ptr(vel), mode,
                                              float(reference_jd), _ptr(err)), "azh_group_propagate_host")
         return pos, vel, err
 
@@ -503,8 +511,13 @@ class DeviceGroup:
         off = self._offsets(offsets_min)
         pp = (C.c_void_p * self.n_devices)(*d_pos_ptrs)
         vv = (C.c_void_p * self.n_devices)(*d_vel_ptrs) if d_vel_ptrs is not None else None
-        check(lib().azh_group_propagate_allgather(self._h, t.ctypes.data, len(t), _ptr(off), pp, vv),
+        check(lib().azh_group_propagate_allgather(self._h, t.ctypes.data, len(t), _ptr(off), 0 if off is None else len(off), pp, vv),
               "azh_group_propagate_allgather")
+
+
+def set_host_copy_threads(n):
+    """Threads that map the pages of a fresh result array ahead of a host-returning copy (-1 automatic, 0 off)."""
+    lib().azh_set_host_copy_threads(int(n))
 
 
 def parse_tle_lines(line1, line2):

@@ -7,13 +7,16 @@
 #include <rccl/rccl.h> // types and prototypes only: librccl is loaded on first use (azh_group_propagate_allgather)
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels.h"
@@ -909,6 +912,115 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     return AZ_OK;
 }
 
+// Device -> caller's host arrays.  A caller's result array is usually FRESH (numpy.empty: pages never touched), and a pageable
+// D2H into untouched pages runs at the rate the runtime faults them in one by one -- 25 GB/s measured, 54 ms for config 2's
+// 932 MB where the PCIe link needs 16.4 ms (tools/host_path_probe2.py).  So a few threads touch the destination ahead of the
+// copy (one atomic OR of zero per page: a single write fault, contents unchanged), block by block in copy order, while the
+// main thread copies chunk k as soon as its blocks are mapped: the call is bound by the link again.
+class PageToucher {
+  public:
+    static constexpr size_t kBlock = size_t(4) << 20;
+    // one range per destination array (or per cell of one); returns its id
+    size_t add(void *p, size_t bytes)
+    {
+        ranges_.push_back({static_cast<char *>(p), bytes, n_flags_});
+        n_flags_ += (bytes + kBlock - 1) / kBlock;
+        return ranges_.size() - 1;
+    }
+    // interleave: hand the blocks out round-robin over the ranges (several copies run side by side: one per device of a
+    // group) instead of range after range (one copy stream)
+    void start(unsigned n_threads, bool interleave)
+    {
+        order_.reserve(n_flags_);
+        if (interleave) {
+            size_t longest = 0;
+            for (auto &r : ranges_) longest = std::max(longest, (r.bytes + kBlock - 1) / kBlock);
+            for (size_t j = 0; j < longest; ++j)
+                for (size_t k = 0; k < ranges_.size(); ++k)
+                    if (j * kBlock < ranges_[k].bytes) order_.push_back({k, j});
+        } else {
+            for (size_t k = 0; k < ranges_.size(); ++k)
+                for (size_t j = 0; j * kBlock < ranges_[k].bytes; ++j) order_.push_back({k, j});
+        }
+        done_.reset(new std::atomic<unsigned char>[n_flags_ + 1]);
+        for (size_t b = 0; b < n_flags_; ++b) done_[b].store(0, std::memory_order_relaxed);
+        for (unsigned k = 0; k < n_threads; ++k) {
+            try {
+                th_.emplace_back([this] { work(); });
+            } catch (const std::system_error &) {
+                break; // (the copy itself faults in whatever no thread reaches)
+            }
+        }
+        started_ = !th_.empty();
+    }
+    // bytes [0, hi) of range r are mapped (returns at once when no thread could be started); any thread may call it
+    void wait(size_t r, size_t hi) const
+    {
+        if (!started_) return;
+        const size_t nb = (std::min(hi, ranges_[r].bytes) + kBlock - 1) / kBlock;
+        for (size_t j = 0; j < nb; ++j)
+            while (!done_[ranges_[r].flag0 + j].load(std::memory_order_acquire)) std::this_thread::yield();
+    }
+    ~PageToucher()
+    {
+        next_.store(order_.size(), std::memory_order_relaxed); // abandon what is left
+        for (auto &t : th_) t.join();
+    }
+
+  private:
+    struct Range {
+        char *p;
+        size_t bytes, flag0;
+    };
+    void work()
+    {
+        for (;;) {
+            const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
+            if (i >= order_.size()) return;
+            const Range &r = ranges_[order_[i].first];
+            const size_t o0 = order_[i].second * kBlock, n = std::min(kBlock, r.bytes - o0);
+            char *q = r.p + o0;
+            for (size_t o = 0; o < n; o += 4096) __atomic_fetch_or(q + o, 0, __ATOMIC_RELAXED);
+            __atomic_fetch_or(q + n - 1, 0, __ATOMIC_RELAXED);
+            done_[r.flag0 + order_[i].second].store(1, std::memory_order_release);
+        }
+    }
+    std::vector<Range> ranges_;
+    std::vector<std::pair<size_t, size_t>> order_; // (range, block of it), in the order the threads take them
+    size_t n_flags_ = 0;
+    std::unique_ptr<std::atomic<unsigned char>[]> done_;
+    std::atomic<size_t> next_{0};
+    std::vector<std::thread> th_;
+    bool started_ = false;
+};
+std::atomic<int> g_host_touch_threads{-1}; // azh_set_host_copy_threads: -1 automatic, 0 off
+
+// arrays[k] (host) <- src[k] (device), bytes[k] each, in order, on `st`; returns after the last copy has been ISSUED
+int32_t copy_back(void *const *dst, const void *const *src, const size_t *bytes, int n_arrays, hipStream_t st)
+{
+    constexpr size_t kChunk = size_t(32) << 20;
+    size_t total = 0;
+    for (int k = 0; k < n_arrays; ++k) total += bytes[k];
+    int want = g_host_touch_threads.load(std::memory_order_relaxed);
+    if (want < 0) want = (int)std::min(6u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    if (total < (size_t(16) << 20) || want == 0) {
+        for (int k = 0; k < n_arrays; ++k)
+            if (bytes[k]) HIP_TRY(hipMemcpyAsync(dst[k], src[k], bytes[k], hipMemcpyDeviceToHost, st));
+        return AZ_OK;
+    }
+    PageToucher pt;
+    for (int k = 0; k < n_arrays; ++k) pt.add(dst[k], bytes[k]);
+    pt.start((unsigned)want, false);
+    for (int k = 0; k < n_arrays; ++k) {
+        for (size_t o = 0; o < bytes[k]; o += kChunk) {
+            const size_t len = std::min(kChunk, bytes[k] - o);
+            pt.wait((size_t)k, o + len);
+            HIP_TRY(hipMemcpyAsync(static_cast<char *>(dst[k]) + o, static_cast<const char *>(src[k]) + o, len, hipMemcpyDeviceToHost, st));
+        }
+    }
+    return AZ_OK;
+}
+
 constexpr size_t kOneStage = 1024; // points served through the pinned staging buffer
 
 // one satellite x n times.  interleaved = 1: out6 is n x 6 (x,y,z,vx,vy,vz; c_api batch layout); otherwise
@@ -968,6 +1080,25 @@ int32_t run_one_satellite(azh_constellation *c, size_t sat, const double *tsince
 
 } // namespace
 
+// host-side text entry points: nothing may unwind through the C boundary (a catalog-scale parse allocates hundreds of MB)
+namespace {
+template <class F>
+int32_t guarded(F &&f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        g_last_error = "out of host memory";
+        return AZ_ERR_ALLOC_FAILED;
+    } catch (const std::exception &e) {
+        g_last_error = e.what();
+        return AZ_ERR_UNKNOWN;
+    } catch (...) {
+        return AZ_ERR_UNKNOWN;
+    }
+}
+} // namespace
+
 // ======================================================================================= (B)
 extern "C" {
 
@@ -1016,58 +1147,68 @@ int32_t azh_parse_tle_lines(const char *line1, const char *line2, double *o)
 
 int32_t azh_parse_tle_text(const char *text, size_t len, double *out16, size_t max_records, size_t *n_found)
 {
-    if (!text) return AZ_ERR_NULL_POINTER;
-    std::vector<azh::TleRecord> recs;
-    azh::parse_all(std::string_view(text, len), recs);
-    return records_out(recs, out16, max_records, n_found);
+    return guarded([&]() -> int32_t {
+        if (!text) return AZ_ERR_NULL_POINTER;
+        std::vector<azh::TleRecord> recs;
+        azh::parse_all(std::string_view(text, len), recs);
+        return records_out(recs, out16, max_records, n_found);
+    });
 }
 
 void azh_set_parse_threads(int32_t n) { azh::set_parse_threads(n > 0 ? (unsigned)n : 0u); }
 
 int32_t azh_parse_omm_json(const char *text, size_t len, double *out16, size_t max_records, size_t *n_found)
 {
-    if (!text) return AZ_ERR_NULL_POINTER;
-    std::vector<azh::TleRecord> recs;
-    const int rc = azh::parse_omm_json(std::string_view(text, len), recs);
-    if (rc == -1) return AZ_ERR_BAD_TLE_LENGTH;
-    if (rc != 0) return AZ_ERR_VALUE;
-    return records_out(recs, out16, max_records, n_found);
+    return guarded([&]() -> int32_t {
+        if (!text) return AZ_ERR_NULL_POINTER;
+        std::vector<azh::TleRecord> recs;
+        const int rc = azh::parse_omm_json(std::string_view(text, len), recs);
+        if (rc == -1) return AZ_ERR_BAD_TLE_LENGTH;
+        if (rc != 0) return AZ_ERR_VALUE;
+        return records_out(recs, out16, max_records, n_found);
+    });
 }
 
 int32_t azh_constellation_from_tle_text(const char *text, size_t len, int32_t grav, int32_t device,
                                         azh_constellation **out)
 {
-    if (!text || !out) return AZ_ERR_NULL_POINTER;
-    std::vector<azh::TleRecord> recs;
-    azh::parse_all(std::string_view(text, len), recs);
-    if (recs.empty()) return AZ_ERR_BAD_TLE_LENGTH;
-    return build_from_records(recs, grav, device, out);
+    return guarded([&]() -> int32_t {
+        if (!text || !out) return AZ_ERR_NULL_POINTER;
+        std::vector<azh::TleRecord> recs;
+        azh::parse_all(std::string_view(text, len), recs);
+        if (recs.empty()) return AZ_ERR_BAD_TLE_LENGTH;
+        return build_from_records(recs, grav, device, out);
+    });
 }
 
 int32_t azh_constellation_from_omm_json(const char *text, size_t len, int32_t grav, int32_t device,
                                         azh_constellation **out)
 {
-    if (!text || !out) return AZ_ERR_NULL_POINTER;
-    std::vector<azh::TleRecord> recs;
-    const int rc = azh::parse_omm_json(std::string_view(text, len), recs);
-    if (rc == -1) return AZ_ERR_BAD_TLE_LENGTH; // Tle.zig L199: epoch string too short
-    if (rc != 0) return AZ_ERR_VALUE;
-    if (recs.empty()) return AZ_ERR_BAD_TLE_LENGTH;
-    return build_from_records(recs, grav, device, out);
+    return guarded([&]() -> int32_t {
+        if (!text || !out) return AZ_ERR_NULL_POINTER;
+        std::vector<azh::TleRecord> recs;
+        const int rc = azh::parse_omm_json(std::string_view(text, len), recs);
+        if (rc == -1) return AZ_ERR_BAD_TLE_LENGTH; // Tle.zig L199: epoch string too short
+        if (rc != 0) return AZ_ERR_VALUE;
+        if (recs.empty()) return AZ_ERR_BAD_TLE_LENGTH;
+        return build_from_records(recs, grav, device, out);
+    });
 }
 
 int32_t azh_constellation_from_tle_lines(const char *const *line1, const char *const *line2, size_t n,
                                          int32_t grav, int32_t device, azh_constellation **out)
 {
-    if (!line1 || !line2 || !out) return AZ_ERR_NULL_POINTER;
-    std::vector<azh::TleRecord> recs(n);
-    for (size_t i = 0; i < n; ++i) {
-        if (!line1[i] || !line2[i]) return AZ_ERR_NULL_POINTER;
-        int rc = azh::parse_lines(line1[i], line2[i], recs[i]);
-        if (rc == -1) return AZ_ERR_BAD_TLE_LENGTH;
-        if (rc != 0) return AZ_ERR_UNKNOWN;
-    }
-    return build_from_records(recs, grav, device, out);
+    return guarded([&]() -> int32_t {
+        if (!line1 || !line2 || !out) return AZ_ERR_NULL_POINTER;
+        std::vector<azh::TleRecord> recs(n);
+        for (size_t i = 0; i < n; ++i) {
+            if (!line1[i] || !line2[i]) return AZ_ERR_NULL_POINTER;
+            int rc = azh::parse_lines(line1[i], line2[i], recs[i]);
+            if (rc == -1) return AZ_ERR_BAD_TLE_LENGTH;
+            if (rc != 0) return AZ_ERR_UNKNOWN;
+        }
+        return build_from_records(recs, grav, device, out);
+    });
 }
 
 int32_t azh_constellation_from_elements(size_t n, const double *epoch_jd, const double *mm, const double *ecc,
@@ -1075,25 +1216,29 @@ int32_t azh_constellation_from_elements(size_t n, const double *epoch_jd, const 
                                         const double *ma, const double *bstar, int32_t grav, int32_t device,
                                         azh_constellation **out)
 {
-    if (!epoch_jd || !mm || !ecc || !incl || !raan || !argp || !ma || !bstar || !out) return AZ_ERR_NULL_POINTER;
-    std::vector<double> cols[AZ_NUM_RAW];
-    const double *src[AZ_NUM_RAW] = {epoch_jd, mm, ecc, incl, raan, argp, ma, bstar};
-    for (int k = 0; k < AZ_NUM_RAW; ++k) cols[k].assign(src[k], src[k] + n);
-    return build(cols, n, grav, device, out);
+    return guarded([&]() -> int32_t {
+        if (!epoch_jd || !mm || !ecc || !incl || !raan || !argp || !ma || !bstar || !out) return AZ_ERR_NULL_POINTER;
+        std::vector<double> cols[AZ_NUM_RAW];
+        const double *src[AZ_NUM_RAW] = {epoch_jd, mm, ecc, incl, raan, argp, ma, bstar};
+        for (int k = 0; k < AZ_NUM_RAW; ++k) cols[k].assign(src[k], src[k] + n);
+        return build(cols, n, grav, device, out);
+    });
 }
 
 int32_t azh_constellation_subset(const azh_constellation *c, const uint32_t *indices, size_t n, int32_t device,
                                  azh_constellation **out)
 {
-    if (!c || !indices || !out) return AZ_ERR_NULL_POINTER;
-    std::vector<double> cols[AZ_NUM_RAW];
-    for (auto &v : cols) v.resize(n);
-    for (size_t i = 0; i < n; ++i) {
-        if (indices[i] >= c->n) return AZ_ERR_VALUE;
-        for (int k = 0; k < AZ_NUM_RAW; ++k) cols[k][i] = c->h_raw[k][indices[i]];
-    }
-    const int grav = (c->g.radius_km == 6378.135) ? AZ_WGS72 : AZ_WGS84;
-    return build(cols, n, grav, device < 0 ? c->device : device, out);
+    return guarded([&]() -> int32_t {
+        if (!c || !indices || !out) return AZ_ERR_NULL_POINTER;
+        std::vector<double> cols[AZ_NUM_RAW];
+        for (auto &v : cols) v.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            if (indices[i] >= c->n) return AZ_ERR_VALUE;
+            for (int k = 0; k < AZ_NUM_RAW; ++k) cols[k][i] = c->h_raw[k][indices[i]];
+        }
+        const int grav = (c->g.radius_km == 6378.135) ? AZ_WGS72 : AZ_WGS84;
+        return build(cols, n, grav, device < 0 ? c->device : device, out);
+    });
 }
 
 void azh_constellation_free(azh_constellation *c) { destroy(c); }
@@ -1142,13 +1287,20 @@ int32_t azh_set_timing(azh_constellation *c, int32_t enabled)
     return AZ_OK;
 }
 
-int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t mode)
+int32_t azh_set_f32_mode(azh_constellation *c, int32_t mode)
 {
     if (!c) return AZ_ERR_NULL_POINTER;
     if (mode < 0 || mode > 2) return AZ_ERR_VALUE;
     c->f32_mode = mode;
     return AZ_OK;
 }
+
+int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t enabled)
+{
+    return azh_set_f32_mode(c, enabled ? AZH_F32_PACKED : AZH_F32_FP64_ROUNDED);
+}
+
+void azh_set_host_copy_threads(int32_t n) { g_host_touch_threads.store(n < 0 ? -1 : n, std::memory_order_relaxed); }
 
 int32_t azh_set_tile_kernel(azh_constellation *c, int32_t enabled)
 {
@@ -1563,9 +1715,10 @@ int32_t azh_propagate_host(azh_constellation *c, const double *times, size_t n_t
         }
         rc = azh_propagate_device(c, times, n_times, offsets, d_pos, d_vel, mode, reference_jd, mask, layout, stride, d_err, nullptr);
         if (rc != AZ_OK) break;
-        if (!hip_ok(hipMemcpyAsync(pos, d_pos, bytes, hipMemcpyDeviceToHost, c->s_main), "D2H pos")) { rc = AZ_ERR_HIP; break; }
-        if (vel && !hip_ok(hipMemcpyAsync(vel, d_vel, bytes, hipMemcpyDeviceToHost, c->s_main), "D2H vel")) { rc = AZ_ERR_HIP; break; }
-        if (err && !hip_ok(hipMemcpyAsync(err, d_err, c->n * n_times, hipMemcpyDeviceToHost, c->s_main), "D2H err")) { rc = AZ_ERR_HIP; break; }
+        void *const dst[3] = {pos, vel, err};
+        const void *const src[3] = {d_pos, d_vel, d_err};
+        const size_t len[3] = {bytes, vel ? bytes : 0, err ? c->n * n_times : 0};
+        if ((rc = copy_back(dst, src, len, 3, c->s_main)) != AZ_OK) break;
         if (!hip_ok(hipStreamSynchronize(c->s_main), "sync")) { rc = AZ_ERR_HIP; break; }
     } while (0);
     if (rc != AZ_OK) (void)hipStreamSynchronize(c->s_main);
@@ -1797,22 +1950,26 @@ int32_t group_stage(azh_group *g, int d, const double *times, size_t n_times, co
 int32_t azh_group_create_from_tle_text(const char *text, size_t len, int32_t grav, const int32_t *devices,
                                        int32_t n_devices, int32_t n_chunks, azh_group **out)
 {
-    if (!text) return AZ_ERR_NULL_POINTER;
-    std::vector<azh::TleRecord> recs;
-    azh::parse_all(std::string_view(text, len), recs);
-    if (recs.empty()) return AZ_ERR_BAD_TLE_LENGTH;
-    return group_build(recs, grav, devices, n_devices, n_chunks, out);
+    return guarded([&]() -> int32_t {
+        if (!text) return AZ_ERR_NULL_POINTER;
+        std::vector<azh::TleRecord> recs;
+        azh::parse_all(std::string_view(text, len), recs);
+        if (recs.empty()) return AZ_ERR_BAD_TLE_LENGTH;
+        return group_build(recs, grav, devices, n_devices, n_chunks, out);
+    });
 }
 
 int32_t azh_group_create_from_omm_json(const char *text, size_t len, int32_t grav, const int32_t *devices,
                                        int32_t n_devices, int32_t n_chunks, azh_group **out)
 {
-    if (!text) return AZ_ERR_NULL_POINTER;
-    std::vector<azh::TleRecord> recs;
-    const int rc = azh::parse_omm_json(std::string_view(text, len), recs);
-    if (rc == -1 || (rc == 0 && recs.empty())) return AZ_ERR_BAD_TLE_LENGTH;
-    if (rc != 0) return AZ_ERR_VALUE;
-    return group_build(recs, grav, devices, n_devices, n_chunks, out);
+    return guarded([&]() -> int32_t {
+        if (!text) return AZ_ERR_NULL_POINTER;
+        std::vector<azh::TleRecord> recs;
+        const int rc = azh::parse_omm_json(std::string_view(text, len), recs);
+        if (rc == -1 || (rc == 0 && recs.empty())) return AZ_ERR_BAD_TLE_LENGTH;
+        if (rc != 0) return AZ_ERR_VALUE;
+        return group_build(recs, grav, devices, n_devices, n_chunks, out);
+    });
 }
 
 void azh_group_free(azh_group *g) { group_destroy(g); }
@@ -1829,11 +1986,11 @@ int32_t azh_group_get_epochs(const azh_group *g, double *out)
     return AZ_OK;
 }
 
-int32_t azh_group_propagate_host(azh_group *g, const double *times, size_t n_times, const double *offsets, double *pos,
-                                 double *vel, int32_t mode, double reference_jd, uint8_t *err)
+int32_t azh_group_propagate_host(azh_group *g, const double *times, size_t n_times, const double *offsets, size_t n_offsets,
+                                 double *pos, double *vel, int32_t mode, double reference_jd, uint8_t *err)
 {
     if (!g || !pos || (n_times && !times)) return AZ_ERR_NULL_POINTER;
-    if (mode < 0 || mode > 2) return AZ_ERR_VALUE;
+    if (mode < 0 || mode > 2 || (offsets && n_offsets < g->n)) return AZ_ERR_VALUE;
     if (n_times == 0) return AZ_OK;
     const size_t row = n_times * 3;
     int32_t rc = AZ_OK;
@@ -1845,17 +2002,71 @@ int32_t azh_group_propagate_host(azh_group *g, const double *times, size_t n_tim
         rc = launch_all(c, c->d_host_pos.p, vel ? c->d_host_vel.p : nullptr, AZ_LAYOUT_SAT_MAJOR, 0,
                         err ? c->d_host_err.p : nullptr, c->s_main);
         if (rc != AZ_OK) break;
-        // a cell = consecutive catalog rows = consecutive local rows: one copy per cell and array
-        size_t local = 0;
-        for (size_t k = 0; k < g->n_chunks && rc == AZ_OK; ++k) {
-            const size_t lo = g->cell_lo(k, d), cnt = g->cell_hi(k, d) - lo;
-            if (!cnt) continue;
-            if (!hip_ok(hipMemcpyAsync(pos + lo * row, c->d_host_pos.p + local * row, cnt * row * sizeof(double), hipMemcpyDeviceToHost, c->s_main), "D2H pos") ||
-                (vel && !hip_ok(hipMemcpyAsync(vel + lo * row, c->d_host_vel.p + local * row, cnt * row * sizeof(double), hipMemcpyDeviceToHost, c->s_main), "D2H vel")) ||
-                (err && !hip_ok(hipMemcpyAsync(err + lo * n_times, c->d_host_err.p + local * n_times, cnt * n_times, hipMemcpyDeviceToHost, c->s_main), "D2H err")))
-                rc = AZ_ERR_HIP;
-            local += cnt;
+    }
+    // Copies: a cell = consecutive catalog rows = consecutive local rows, one copy per cell and array.  A D2H into pageable
+    // memory holds its host thread until the data has landed, so every device gets its OWN copier thread -- the N PCIe links
+    // then run side by side (issued from one thread they would take turns) -- and the destination pages are mapped ahead of
+    // the copies, round-robin over the cells (copy_back's reasoning, for several copy streams at once).
+    struct Piece {
+        int d;
+        size_t range;
+        char *dst;
+        const char *src;
+        size_t bytes;
+    };
+    std::vector<Piece> pieces;
+    PageToucher pt;
+    if (rc == AZ_OK) {
+        for (int arr = 0; arr < 3; ++arr) {
+            if ((arr == 1 && !vel) || (arr == 2 && !err)) continue;
+            const size_t unit = arr == 2 ? n_times : row * sizeof(double); // bytes per satellite row
+            for (int d = 0; d < g->n_dev; ++d) {
+                azh_constellation *c = g->shard[d];
+                if (!c) continue;
+                const char *base = arr == 0 ? (const char *)c->d_host_pos.p : arr == 1 ? (const char *)c->d_host_vel.p : (const char *)c->d_host_err.p;
+                char *out = arr == 0 ? (char *)pos : arr == 1 ? (char *)vel : (char *)err;
+                size_t local = 0;
+                for (size_t k = 0; k < g->n_chunks; ++k) {
+                    const size_t lo = g->cell_lo(k, d), cnt = g->cell_hi(k, d) - lo;
+                    if (!cnt) continue;
+                    pieces.push_back({d, pt.add(out + lo * unit, cnt * unit), out + lo * unit, base + local * unit, cnt * unit});
+                    local += cnt;
+                }
+            }
         }
+        size_t total = 0;
+        for (auto &q : pieces) total += q.bytes;
+        int want = g_host_touch_threads.load(std::memory_order_relaxed);
+        if (want < 0) want = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
+        if (want > 0 && total >= (size_t(16) << 20)) pt.start((unsigned)want, true);
+        std::vector<int32_t> rcs(g->n_dev, AZ_OK);
+        auto copier = [&](int d) {
+            azh_constellation *c = g->shard[d];
+            if (!c) return;
+            if (hipSetDevice(c->device) != hipSuccess) { rcs[d] = AZ_ERR_HIP; return; }
+            constexpr size_t kChunk = size_t(32) << 20;
+            for (auto &q : pieces) {
+                if (q.d != d) continue;
+                for (size_t o = 0; o < q.bytes; o += kChunk) {
+                    const size_t len = std::min(kChunk, q.bytes - o);
+                    pt.wait(q.range, o + len);
+                    if (hipMemcpyAsync(q.dst + o, q.src + o, len, hipMemcpyDeviceToHost, c->s_main) != hipSuccess) { rcs[d] = AZ_ERR_HIP; return; }
+                }
+            }
+            if (hipStreamSynchronize(c->s_main) != hipSuccess) rcs[d] = AZ_ERR_HIP;
+        };
+        std::vector<std::thread> th;
+        for (int d = 1; d < g->n_dev; ++d) {
+            try {
+                th.emplace_back(copier, d);
+            } catch (const std::system_error &) {
+                copier(d);
+            }
+        }
+        copier(0);
+        for (auto &t : th) t.join();
+        for (int d = 0; d < g->n_dev; ++d)
+            if (rcs[d] != AZ_OK) { rc = rcs[d]; g_last_error = "device-to-host copy failed"; (void)hipGetLastError(); }
     }
     for (int d = 0; d < g->n_dev; ++d) {
         azh_constellation *c = g->shard[d];
@@ -1866,10 +2077,11 @@ int32_t azh_group_propagate_host(azh_group *g, const double *times, size_t n_tim
     return rc;
 }
 
-int32_t azh_group_propagate_allgather(azh_group *g, const double *times, size_t n_times, const double *offsets,
+int32_t azh_group_propagate_allgather(azh_group *g, const double *times, size_t n_times, const double *offsets, size_t n_offsets,
                                       double *const *d_pos, double *const *d_vel)
 {
     if (!g || !d_pos || (n_times && !times)) return AZ_ERR_NULL_POINTER;
+    if (offsets && n_offsets < g->n) return AZ_ERR_VALUE;
     if (n_times == 0) return AZ_OK;
     for (int d = 0; d < g->n_dev; ++d)
         if (!g->shard[d]) { g_last_error = "more devices than 64-satellite cells"; return AZ_ERR_VALUE; }

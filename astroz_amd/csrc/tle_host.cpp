@@ -8,6 +8,8 @@
 #include <atomic>
 #include <functional>
 #include <system_error>
+#include <exception>
+#include <mutex>
 #include <thread>
 
 namespace azh {
@@ -204,22 +206,40 @@ void parse_range(std::string_view text, std::vector<TleRecord> &out)
 }
 std::atomic<unsigned> g_parse_threads{0}; // 0 = automatic
 
-// tasks 0 .. n-1, task 0 on the calling thread; a task whose thread cannot be created runs on the calling thread as well
+// tasks 0 .. n-1, task 0 on the calling thread; a task whose thread cannot be created runs on the calling thread as well.
+// Exception-safe: a task that throws (bad_alloc on a 140-MB catalog) is caught inside its thread, every thread is joined, and
+// the FIRST exception is rethrown on the calling thread -- where the extern "C" entry points turn it into an error code.
 void run_tasks(unsigned n, const std::function<void(unsigned)> &task)
 {
     std::vector<std::thread> th;
-    th.reserve(n);
     std::vector<unsigned> here;
-    for (unsigned k = 1; k < n; ++k) {
+    std::exception_ptr first;
+    std::mutex mu;
+    auto guarded = [&](unsigned k) {
         try {
-            th.emplace_back(task, k);
-        } catch (const std::system_error &) {
-            here.push_back(k);
+            task(k);
+        } catch (...) {
+            std::lock_guard<std::mutex> lock(mu);
+            if (!first) first = std::current_exception();
         }
+    };
+    try {
+        th.reserve(n);
+        for (unsigned k = 1; k < n; ++k) {
+            try {
+                th.emplace_back(guarded, k);
+            } catch (const std::system_error &) {
+                here.push_back(k);
+            }
+        }
+    } catch (...) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!first) first = std::current_exception();
     }
-    if (n) task(0);
-    for (unsigned k : here) task(k);
+    if (n) guarded(0);
+    for (unsigned k : here) guarded(k);
     for (auto &t : th) t.join();
+    if (first) std::rethrow_exception(first);
 }
 } // namespace
 

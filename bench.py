@@ -74,7 +74,7 @@ def parse_args():
     ap.add_argument("--config5-share", action="store_true",
                     help="BASELINE config 5, one GPU's share: 125,000 synthetic satellites (seed 20260927) x 10,000 one-minute "
                          "steps, fp32 pos+vel (30 GB); mixed-precision arithmetic unless --f32-arith (packed fp32) / --f32-fp64; parity on sampled rows")
-    ap.add_argument("--f32-fp64", action="store_true", help="fp32 outputs from fp64 arithmetic rounded at the store (azh_set_f32_arithmetic(c, 2))")
+    ap.add_argument("--f32-fp64", action="store_true", help="fp32 outputs from fp64 arithmetic rounded at the store (azh_set_f32_mode(c, 2))")
     ap.add_argument("--f32-arith", action="store_true",
                     help="with fp32 outputs: opt into the packed-fp32-arithmetic kernel (4 m / 6 mm/s) instead of the default "
                          "fp64 arithmetic rounded once at the store (0.25 m / 0.24 mm/s)")
@@ -130,8 +130,31 @@ def cpu_baseline(pairs, times, offsets, seconds, sat_major):
         cat.propagate_batch8(times, offsets[:n_s], layout=olayout, threads=threads, out=bout)
         passes += 1
         dt = time.perf_counter() - t0
+    # ... and the same code on ONE thread (next to the reference's published 37.7 M/s single-thread figure): whole
+    # passes over the first 1,024 satellites for ~1.5 s
+    n1 = min(n_s, 1024)
+    cat1 = oracle.Catalog.from_pairs(pairs[:n1], oracle.WGS72)
+    b1 = cat1.propagate_batch8(times, offsets[:n1], layout=olayout, threads=1)[1:]
+    p1, d1 = 0, 0.0
+    t0 = time.perf_counter()
+    while p1 == 0 or (d1 < 1.5 and p1 < 2000):
+        cat1.propagate_batch8(times, offsets[:n1], layout=olayout, threads=1, out=b1)
+        p1 += 1
+        d1 = time.perf_counter() - t0
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "value": passes * n_s * len(times) / dt, "unit": "propagations/s", "cores": threads, "kind": "port",
+        "threads_1": {"value": p1 * n1 * len(times) / d1, "unit": "propagations/s", "cores": 1,
+                      "sample": "%d pass(es) over the first %d satellites x %d times, %.1f s" % (p1, n1, len(times), d1),
+                      "reference_published": "37.7 M propagations/s, 1 thread, Ryzen 7 7840U (README.md L35-45 of the reference)"},
+        "cpu_model": model, "host_threads_visible": os.cpu_count(),
         "sample": "%d pass(es) over all %d satellites x %d times of the same catalog, %.1f s wall (%.0f core-seconds), "
                   "fp64 pos+vel; C restatement of the reference's SIMD CPU design (8 satellites per AVX-512 register, "
                   "polynomial sincos/atan2, OpenMP over %s ranges), gcc -O3 -march=native" % (
@@ -241,7 +264,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
         return e0.elapsed_time(e1) / steps
 
     def case(key, workload, kernel, dev, pairs, n_times, *, layout, vel=True, f32=False, mode=0, steps=50, warm=20,
-             cold=False, rows=16, ref_jd=0.0, arith32=False, stride_align=0, grid="uniform"):
+             cold=False, rows=16, ref_jd=0.0, arith32="mixed", stride_align=0, grid="uniform"):
         if key in skip:
             return
         ent = {"key": key, "workload": workload, "kernel": kernel}
@@ -345,6 +368,49 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
          dev2, pairs2, 1440, layout=SM, mode=1, ref_jd=ref_jd)
     case("config2_geodetic_time_major", "config 2, geodetic (lat, lon [rad], alt km) time-major, positions only",
          "k_propagate<time-major,pos,FRAME> (lane = satellite)", dev2, pairs2, 1440, layout=TM, vel=False, mode=2, ref_jd=ref_jd, steps=10)
+    if "api_host" not in skip:
+        ent = {"key": "api_host", "kernel": "k_tiles_fast<pos+vel,DELTA> + redo, then device -> host over PCIe",
+               "workload": "the reference's flagship Python call, host arrays out: SatrecArray.sgp4(jd, fr) -> (e, r, v) numpy, %d x 1,440, "
+                           "fp64 TEME pos+vel, time-major physical layout (api.py L296-320; the call the reference's 290 M/s figure is "
+                           "quoted on).  Host wall clock per call INCLUDING fresh result arrays, staging, kernels and the two 466-MB "
+                           "device-to-host copies" % n2}
+        try:
+            from astroz_amd.api import Satrec, SatrecArray
+            arr = SatrecArray([Satrec.twoline2rv(a_, b_) for a_, b_ in pairs2], device=cuda.index or 0)
+            jd = np.full(1440, synth.START_JD)
+            fr = 0.32853009 + np.arange(1440) / 1440.0
+
+            def calls(k):
+                ws = []
+                for _ in range(k):
+                    t0 = time.perf_counter()
+                    e_, r_, v_ = arr.sgp4(jd, fr)
+                    ws.append((time.perf_counter() - t0) * 1e3)
+                return ws, (e_, r_, v_)
+            calls(2)
+            ws, (e_, r_, v_) = calls(7)
+            _native.set_host_copy_threads(0)           # the plain path: the copy faults the fresh pages in itself
+            ws0, _ = calls(3)
+            _native.set_host_copy_threads(-1)
+            ms = sorted(ws)[len(ws) // 2]
+            out_bytes = r_.nbytes + v_.nbytes + e_.nbytes
+            ent.update({"ms_per_step": ms, "value": n2 * 1440 / (ms / 1e3), "unit": "propagations/s (host arrays, PCIe-inclusive)",
+                        "n_sats": n2, "n_times": 1440, "calls_ms": ws, "d2h_GB_per_s_of_wall": out_bytes / (ms / 1e3) / 1e9,
+                        "path": arr._dev.last_path(),
+                        "without_page_touch_threads_ms": sorted(ws0)[len(ws0) // 2],
+                        "what": "page-touch threads map the fresh result arrays ahead of the chunked D2H (azh_set_host_copy_threads); "
+                                "without them the copy runs at the rate the runtime faults pages in.  PCIe Gen5 x16 moves the 932 MB "
+                                "in ~16.4 ms: that, not the 0.3-ms kernel, bounds this call"})
+            rws = _sample_rows(n2, 16)
+            cat = oracle.Catalog.from_pairs([pairs2[i] for i in rws], oracle.WGS72)
+            rjd = jd[0] + fr[0]
+            _, p0, v0 = cat.propagate(((jd + fr) - rjd) * 1440.0, (rjd - arr._epochs[rws]) * 1440.0, layout=oracle.SAT_MAJOR)
+            ent["parity"] = {"rows": int(len(rws)), "max_abs_dr_km": float(np.abs(r_[rws] - p0).max()),
+                             "max_abs_dv_kms": float(np.abs(v_[rws] - v0).max()), "err_nonzero": int(np.count_nonzero(e_))}
+            del arr, e_, r_, v_
+        except Exception as exc:
+            ent["failed"] = repr(exc)
+        res.append(ent)
     dev3 = pairs3 = None
     if not {"config3_sat_major", "config3_time_major"} <= set(skip):
         pairs3 = synth.synth_catalog(n_near=13478, n_deep=1522, seed=20260926)
@@ -461,12 +527,12 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             c5 = "config 5, ONE GPU's share of 8: 125,000 synthetic satellites (seed 20260927) x 10,000 one-minute steps, fp32 pos+vel (30 GB), satellite-major, "
             case("config5_share", c5 + "DEFAULT arithmetic: mixed precision (O(1) quantities fp64, small ones packed fp32; eccentric members fp64 rounded at the store)",
                  "k_rows_fast32<MIXED> (+ eccentric members, redo)", dev5, pairs5, 10000, layout=SM, f32=True, steps=5, warm=2, rows=24)
-            case("config5_share_fp64", c5 + "fp64 arithmetic, every component rounded once at the store (azh_set_f32_arithmetic(c, 2))",
+            case("config5_share_fp64", c5 + "fp64 arithmetic, every component rounded once at the store (azh_set_f32_mode(c, 2))",
                  "k_rows_fast<SINK_F32> (+ eccentric members, redo)", dev5, pairs5, 10000, layout=SM, f32=True, steps=5, warm=2, rows=24,
-                 arith32=2)
-            case("config5_share_f32arith", c5 + "OPT-IN packed fp32 arithmetic (azh_set_f32_arithmetic(c, 1): 4 m / 6 mm/s)",
+                 arith32="fp64")
+            case("config5_share_f32arith", c5 + "OPT-IN packed fp32 arithmetic (azh_set_f32_mode(c, 1): 4 m / 6 mm/s)",
                  "k_rows_fast32 (+ eccentric members, redo)", dev5, pairs5, 10000, layout=SM, f32=True, steps=5, warm=2, rows=24,
-                 arith32=True)
+                 arith32="packed")
             dev5.close()
         except Exception as exc:
             res.append({"key": "config5_share", "failed": repr(exc)})
@@ -542,7 +608,7 @@ def main():
         dev.set_fast_path(False)
     if a.no_tile_kernel:
         dev.set_tile_kernel(False)
-    dev.set_f32_arithmetic(1 if a.f32_arith else (2 if a.f32_fp64 else 0))
+    dev.set_f32_arithmetic("packed" if a.f32_arith else ("fp64" if a.f32_fp64 else "mixed"))
     n_local = dev.n
     offsets = (synth.START_JD - dev.epochs) * 1440.0
     layout = _native.TIME_MAJOR if a.layout == "time" else _native.SAT_MAJOR
@@ -688,6 +754,34 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    # config 4, host-returning consumers (the C-host route, azh_group_propagate_host): ONE process, all N devices, every
+    # device copies its shard straight into the caller's catalog-ordered host arrays over its own PCIe link -- no collective.
+    # The one case where sharding this path pays: the call is PCIe-bound (16.4 ms for 932 MB over one link).  Rank 0 only,
+    # after the timed region, the other ranks idle at the barrier.
+    group_host = None
+    if sharded:
+        if rank == 0:
+            try:
+                text = "\n".join(x + "\n" + y for x, y in allp)
+                devs = list(range(world)) if world > 1 else [local_rank]
+                grp = _native.DeviceGroup(text, devs, _native.WGS72, n_chunks=1)
+                goff = (synth.START_JD - grp.epochs) * 1440.0
+                ws = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    gp, gv, _ = grp.propagate_host(times, goff, velocities=vel_on)
+                    ws.append((time.perf_counter() - t0) * 1e3)
+                gms = sorted(ws[1:])[len(ws[1:]) // 2]
+                group_host = {"ms_per_call": gms, "calls_ms": ws, "devices": len(devs), "value": n_total * n_times / (gms / 1e3),
+                              "GB_per_s": (gp.nbytes + (gv.nbytes if gv is not None else 0)) / (gms / 1e3) / 1e9,
+                              "what": "azh_group_propagate_host: one process, N devices, fresh host arrays each call; wall clock"}
+                del gp, gv
+                grp.close()
+            except Exception as exc:
+                group_host = {"failed": repr(exc)}
+        if world > 1:
+            dist.barrier()
+
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -777,6 +871,7 @@ def main():
                 "t_replicate_ms": replicate_ms, "replicate_value": props_per_step / (replicate_ms / 1e3),
                 "replicate_note": "every GPU propagates the FULL catalog itself (no shards, zero bytes moved): the same "
                                   "deliverable as the gathered run -- the full arrays on every GPU",
+                "group_host": group_host,
                 "gather_bytes_per_gpu": (plan.padded - plan.local_capacity()) * n_times * 3 * 8 * (2 if vel_on else 1)}
                if kernel_only_ms is not None else {}),
             "parallelism": par,

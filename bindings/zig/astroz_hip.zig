@@ -113,9 +113,11 @@ pub extern "c" fn azh_constellation_subset(h: ?*const Handle, indices: [*]const 
 // row windows (chunked multi-GPU pipelines), arithmetic / path switches, device-pointer one-satellite call
 pub extern "c" fn azh_propagate_device_window(h: ?*Handle, row_lo: usize, row_hi: usize, d_pos: [*]f64, d_vel: ?[*]f64, layout: i32,
     out_stride_sats: usize, d_err: ?[*]u8, stream: ?*anyopaque) i32;
-pub extern "c" fn azh_set_f32_arithmetic(h: ?*Handle, mode: i32) i32; // 0 mixed precision (default), 1 packed fp32, 2 fp64 rounded at the store
+pub extern "c" fn azh_set_f32_mode(h: ?*Handle, mode: i32) i32; // 0 mixed precision (default), 1 packed fp32, 2 fp64 rounded at the store
+pub extern "c" fn azh_set_f32_arithmetic(h: ?*Handle, enabled: i32) i32; // boolean: 0 = fp64 rounded at the store, else packed fp32
 pub extern "c" fn azh_set_fast_path(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_set_tile_kernel(h: ?*Handle, enabled: i32) i32;
+pub extern "c" fn azh_set_host_copy_threads(n: i32) void; // page-touch threads ahead of host-returning copies (-1 auto, 0 off)
 pub extern "c" fn azh_last_path(h: ?*const Handle) u32; // AZH_PATH_* bits: which kernel families the last call launched
 pub extern "c" fn azh_propagate_one_device(h: ?*Handle, sat_index: usize, d_tsince_min: [*]const f64, n: usize, d_pos: [*]f64,
     d_vel: ?[*]f64, d_err: ?[*]u8, stream: ?*anyopaque) i32;
@@ -139,6 +141,6 @@ pub extern "c" fn azh_group_num_devices(g: ?*const Group) i32;
 pub extern "c" fn azh_group_padded_rows(g: ?*const Group) usize;
 pub extern "c" fn azh_group_get_epochs(g: ?*const Group, out: [*]f64) i32;
 pub extern "c" fn azh_group_propagate_host(g: ?*Group, times_min: [*]const f64, n_times: usize, epoch_offsets_min: ?[*]const f64,
-    pos: [*]f64, vel: ?[*]f64, output_mode: i32, reference_jd: f64, err: ?[*]u8) i32;
+    n_offsets: usize, pos: [*]f64, vel: ?[*]f64, output_mode: i32, reference_jd: f64, err: ?[*]u8) i32;
 pub extern "c" fn azh_group_propagate_allgather(g: ?*Group, times_min: [*]const f64, n_times: usize,
-    epoch_offsets_min: ?[*]const f64, d_pos: [*]const [*]f64, d_vel: ?[*]const [*]f64) i32;
+    epoch_offsets_min: ?[*]const f64, n_offsets: usize, d_pos: [*]const [*]f64, d_vel: ?[*]const [*]f64) i32;

@@ -209,7 +209,7 @@ int32_t azh_propagate_device_cached(azh_constellation *c, double *d_pos, double 
 int32_t azh_propagate_device_window(azh_constellation *c, size_t row_lo, size_t row_hi, double *d_pos, double *d_vel,
                                     int32_t layout, size_t out_stride_sats, uint8_t *d_err, void *stream);
 /* fp32 OUTPUT variants (BASELINE config 5: 1M satellites x 10,000 steps would be 480 GB in fp64); d_pos/d_vel
- * are float arrays of the same shapes.  No reference counterpart (astroz is fp64 only).  Arithmetic:
+ * are float arrays of the same shapes.  No reference counterpart (astroz is fp64 only).  Arithmetic, azh_set_f32_mode:
  *   mode 0 (default)  mixed precision for near-circular members on uniform grids, satellite-major TEME
  *                     (astroz_amd/csrc/fast_step_f32.h, az_sgp4_fast_step_f32p): every O(1) quantity -- the along-track
  *                     phase pair and the rotation applied to it, node and inclination pairs, orientation, radius, speed --
@@ -221,8 +221,15 @@ int32_t azh_propagate_device_window(azh_constellation *c, size_t row_lo, size_t 
  *   mode 1            opt-in: packed fp32 arithmetic with fp64 phase and radius chains for the same members -- 1.15x the
  *                     rate of mode 0, positions within 4 m and velocities within 6 mm/s (measured 2.4 m / 4.0 mm/s).
  *   mode 2            fp64 arithmetic throughout, every component rounded ONCE when it is stored: float32(fp64 result).
- * Returns AZ_ERR_VALUE for any other mode. */
-int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t mode);
+ * Returns AZ_ERR_VALUE for any other mode.
+ * azh_set_f32_arithmetic keeps the BOOLEAN meaning it was introduced with (round 2): 0 = fp64 arithmetic rounded once at the
+ * store (= mode 2), non-zero = packed fp32 arithmetic (= mode 1).  (Round 3 had overloaded it with the mode numbers above, so
+ * that a caller passing 0 to pin float32(fp64 result) silently got the mixed step: the modes now have their own entry point.) */
+#define AZH_F32_MIXED 0
+#define AZH_F32_PACKED 1
+#define AZH_F32_FP64_ROUNDED 2
+int32_t azh_set_f32_mode(azh_constellation *c, int32_t mode);
+int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t enabled);
 int32_t azh_propagate_device_f32(azh_constellation *c, const double *times_min, size_t n_times,
                                  const double *epoch_offsets_min, float *d_pos, float *d_vel, int32_t output_mode,
                                  double reference_jd, const uint8_t *sat_mask, int32_t layout,
@@ -277,9 +284,8 @@ int32_t azh_screen_all_host(azh_constellation *c, const double *times_min, size_
  *                                  buffers on devices[i] of azh_group_padded_rows() x n_times x 3 doubles (rows beyond
  *                                  n_sats are padding and arrive as zeros); RCCL all-gathers over xGMI (librccl is
  *                                  loaded on first use), chunk k in flight while chunk k+1 is propagated.  Synchronous.
- * epoch_offsets_min (both calls): NULL, or azh_group_num_satellites() doubles indexed by catalog row -- like the reference's
- * epochOffsets slice (src/Constellation.zig L541-552) it carries no length of its own here: a shorter array is read out of
- * bounds (the Python wrapper checks the length before the call). */
+ * epoch_offsets_min (both calls): NULL, or n_offsets doubles indexed by catalog row (the length of the reference's
+ * epochOffsets slice, src/Constellation.zig L541-552); n_offsets < azh_group_num_satellites() is AZ_ERR_VALUE. */
 typedef struct azh_group azh_group;
 int32_t azh_group_create_from_tle_text(const char *text, size_t len, int32_t grav, const int32_t *devices,
                                        int32_t n_devices, int32_t n_chunks, azh_group **out);
@@ -291,9 +297,11 @@ int32_t azh_group_num_devices(const azh_group *g);
 size_t azh_group_padded_rows(const azh_group *g);
 int32_t azh_group_get_epochs(const azh_group *g, double *out_n);
 int32_t azh_group_propagate_host(azh_group *g, const double *times_min, size_t n_times, const double *epoch_offsets_min,
-                                 double *pos, double *vel, int32_t output_mode, double reference_jd, uint8_t *err);
+                                 size_t n_offsets, double *pos, double *vel, int32_t output_mode, double reference_jd,
+                                 uint8_t *err);
 int32_t azh_group_propagate_allgather(azh_group *g, const double *times_min, size_t n_times,
-                                      const double *epoch_offsets_min, double *const *d_pos, double *const *d_vel);
+                                      const double *epoch_offsets_min, size_t n_offsets, double *const *d_pos,
+                                      double *const *d_vel);
 
 /* Constellation.propagate (src/Constellation.zig L245-308): absolute times jd[t]+fr[t]; the
  * reference epoch is that of the first near-earth member (the first entry of the reference's SGP4 batch list,
@@ -328,6 +336,10 @@ int32_t azh_set_fast_path(azh_constellation *c, int32_t enabled);
  * time arithmetic, transposed through LDS); disabled, the lane = satellite kernel serves that layout.  Results of the
  * two agree to rounding; the switch exists so that tests and benchmarks can compare them. */
 int32_t azh_set_tile_kernel(azh_constellation *c, int32_t enabled);
+/* host-returning calls (azh_propagate_host, azh_propagate_jd_host, azh_group_propagate_host): threads that touch the pages of
+ * the caller's (typically fresh) result arrays ahead of the device-to-host copy, so that the copy runs at the rate of the
+ * PCIe link instead of the rate pages are faulted in (config 2: 54 -> 20 ms).  -1 automatic (default), 0 off. */
+void azh_set_host_copy_threads(int32_t n);
 /* enable (default) / disable the hipEvent pair recorded around every propagate call; disabling it
  * removes two event records per call from tight replay loops (azh_last_kernel_ms then returns -1) */
 int32_t azh_set_timing(azh_constellation *c, int32_t enabled);

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # within half an fp32 ulp of the oracle per component (0.25 m at 7,000 km; 0.24 mm/s at 7.5 km/s) + the fp64 gate.
 F32_ROUNDED_TOL_R = 4.9e-4 * 1.01   # km: half an ulp of 8,192 km
 F32_ROUNDED_TOL_V = 4.8e-7 * 1.01   # km/s: half an ulp of 8 km/s
-# opt-in packed-fp32 arithmetic (azh_set_f32_arithmetic(c, 1)): documented tolerance
+# opt-in packed-fp32 arithmetic (azh_set_f32_mode(c, 1)): documented tolerance
 F32_ARITH_TOL_R = 4.0e-3
 F32_ARITH_TOL_V = 6.0e-6
 # the DEFAULT for fp32 outputs, the mixed-precision step (fast_step_f32.h, az_sgp4_fast_step_f32p): per component within 0.6 m
