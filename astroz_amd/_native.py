@@ -516,7 +516,7 @@ class DeviceGroup:
 
 
 def set_host_copy_threads(n):
-    """Threads that map the pages of a fresh result array ahead of a host-returning copy (-1 automatic, 0 off)."""
+    """Host threads behind the pinned staging of host-returning copies (-1 automatic, 0 = direct pageable copies)."""
     lib().azh_set_host_copy_threads(int(n))
 
 

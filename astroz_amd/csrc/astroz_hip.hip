@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -89,6 +91,34 @@ struct DevBuf {
     }
 };
 
+// pinned staging slots of the host-returning calls (copy_back_staged)
+constexpr int kStageSlots = 3;
+constexpr size_t kStageChunk = size_t(16) << 20;
+struct HostStager {
+    void *slot[kStageSlots] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[kStageSlots] = {nullptr, nullptr, nullptr};
+    bool ready = false;
+    int32_t ensure()
+    {
+        if (ready) return AZ_OK;
+        for (int k = 0; k < kStageSlots; ++k) {
+            if (!slot[k] && !hip_ok(hipHostMalloc(&slot[k], kStageChunk, hipHostMallocDefault), "hipHostMalloc(stage)")) return AZ_ERR_HIP;
+            if (!ev[k] && !hip_ok(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming), "hipEventCreate")) return AZ_ERR_HIP;
+        }
+        ready = true;
+        return AZ_OK;
+    }
+    void release()
+    {
+        for (int k = 0; k < kStageSlots; ++k) {
+            if (slot[k]) (void)hipHostFree(slot[k]);
+            if (ev[k]) (void)hipEventDestroy(ev[k]);
+            slot[k] = nullptr;
+            ev[k] = nullptr;
+        }
+        ready = false;
+    }
+};
 } // namespace
 
 struct azh_constellation {
@@ -105,6 +135,7 @@ struct azh_constellation {
     unsigned n_sgp4 = 0, n_sdp4 = 0, n_bad = 0;
     // per-call scratch
     DevBuf<double> d_times, d_offsets, d_sin, d_cos, d_seeds;
+    DevBuf<double> d_node_cache; // [3][n_pad]: per satellite, the resonance integrator node nearest to epoch the last seeding pass reached
     // window plans of the staged uniform grid (k_plan_windows), one per launch shape: [0] row kernels (64 grid points per
     // lane step), [1] the packed fp32 row kernel (128), [2] the time-major tile kernel.  redo: [0],[1] item counters
     // (alternating launches, re-armed to the number of static items), [2] number of static items (windows the validation
@@ -132,6 +163,7 @@ struct azh_constellation {
     DevBuf<double> d_one_t, d_one_o;
     DevBuf<unsigned char> d_one_e;
     void *h_stage = nullptr; // pinned host staging for small calls (kOneStage points)
+    HostStager stager;       // pinned staging slots of the host-returning calls (copy_back_staged), allocated on first use
     bool seeds_valid = false; // resonance seeds match the staged times/offsets and tile
     unsigned seeds_tile = 0;
     bool seeds_rows = false; // seed table laid out for the lane = time kernel (64-point chunks)
@@ -176,6 +208,7 @@ void destroy(azh_constellation *c)
     c->d_sin.release();
     c->d_cos.release();
     c->d_seeds.release();
+    c->d_node_cache.release();
     c->d_deep_tmp.release();
     c->d_inc.release();
     c->d_fast_rec.release();
@@ -190,6 +223,7 @@ void destroy(azh_constellation *c)
     c->d_one_o.release();
     c->d_one_e.release();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->stager.release();
     c->d_mask.release();
     c->d_host_pos.release();
     c->d_host_vel.release();
@@ -731,8 +765,12 @@ int32_t prepare_deep(azh_constellation *c, PropArgs &d, hipStream_t st, bool row
     const unsigned n_tiles = (n_times + seed_tile - 1) / seed_tile;
     if (!c->seeds_valid || c->seeds_tile != seed_tile || c->seeds_rows != rows) {
         if (c->d_seeds.ensure((size_t)n_tiles * 3 * c->n_sdp4) != AZ_OK) return AZ_ERR_HIP;
+        if (c->d_node_cache.p == nullptr) {
+            if (c->d_node_cache.ensure(3 * c->n_pad) != AZ_OK) return AZ_ERR_HIP;
+            HIP_TRY(hipMemsetAsync(c->d_node_cache.p, 0, sizeof(double) * 3 * c->n_pad, st)); // atime = 0: start from epoch
+        }
         hipLaunchKernelGGL(k_deep_seed, dim3((c->n_sdp4 + 63) / 64), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
-                           d.list, c->n_sdp4, d.times, n_times, d.offsets, seed_tile, c->d_seeds.p, rows ? 1 : 0);
+                           d.list, c->n_sdp4, d.times, n_times, d.offsets, seed_tile, c->d_seeds.p, rows ? 1 : 0, c->d_node_cache.p);
         HIP_TRY(hipGetLastError());
         c->seeds_valid = true;
         c->seeds_tile = seed_tile;
@@ -912,113 +950,129 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     return AZ_OK;
 }
 
-// Device -> caller's host arrays.  A caller's result array is usually FRESH (numpy.empty: pages never touched), and a pageable
-// D2H into untouched pages runs at the rate the runtime faults them in one by one -- 25 GB/s measured, 54 ms for config 2's
-// 932 MB where the PCIe link needs 16.4 ms (tools/host_path_probe2.py).  So a few threads touch the destination ahead of the
-// copy (one atomic OR of zero per page: a single write fault, contents unchanged), block by block in copy order, while the
-// main thread copies chunk k as soon as its blocks are mapped: the call is bound by the link again.
-class PageToucher {
+// Device -> caller's host arrays.  A D2H straight into pageable memory runs at the PCIe rate only when the runtime has seen
+// the destination before: config 2's 932 MB take 17 ms into arrays a previous call wrote, but 55 ms into FRESH ones
+// (numpy.empty every call -- what SatrecArray.sgp4 does), and mapping the pages beforehand does not help (measured with 0-16
+// page-touch threads: 55 ms throughout; tools/host_path_probe3.py) -- the cost is the runtime's first-time pinning of the
+// range.  So the copy goes through pinned staging slots that live in the handle (device -> slot at the link rate, slots
+// cycling) and a few host threads move each landed chunk into the caller's array while the next chunk is on the link.
+// K threads that copy [src, src + len) to dst in K pieces; jobs are handed over one chunk at a time
+class CopyPool {
   public:
-    static constexpr size_t kBlock = size_t(4) << 20;
-    // one range per destination array (or per cell of one); returns its id
-    size_t add(void *p, size_t bytes)
+    explicit CopyPool(unsigned k)
     {
-        ranges_.push_back({static_cast<char *>(p), bytes, n_flags_});
-        n_flags_ += (bytes + kBlock - 1) / kBlock;
-        return ranges_.size() - 1;
-    }
-    // interleave: hand the blocks out round-robin over the ranges (several copies run side by side: one per device of a
-    // group) instead of range after range (one copy stream)
-    void start(unsigned n_threads, bool interleave)
-    {
-        order_.reserve(n_flags_);
-        if (interleave) {
-            size_t longest = 0;
-            for (auto &r : ranges_) longest = std::max(longest, (r.bytes + kBlock - 1) / kBlock);
-            for (size_t j = 0; j < longest; ++j)
-                for (size_t k = 0; k < ranges_.size(); ++k)
-                    if (j * kBlock < ranges_[k].bytes) order_.push_back({k, j});
-        } else {
-            for (size_t k = 0; k < ranges_.size(); ++k)
-                for (size_t j = 0; j * kBlock < ranges_[k].bytes; ++j) order_.push_back({k, j});
-        }
-        done_.reset(new std::atomic<unsigned char>[n_flags_ + 1]);
-        for (size_t b = 0; b < n_flags_; ++b) done_[b].store(0, std::memory_order_relaxed);
-        for (unsigned k = 0; k < n_threads; ++k) {
+        for (unsigned i = 0; i < k; ++i) {
             try {
-                th_.emplace_back([this] { work(); });
+                th_.emplace_back([this, i] { work(i); });
             } catch (const std::system_error &) {
-                break; // (the copy itself faults in whatever no thread reaches)
+                break;
             }
         }
-        started_ = !th_.empty();
     }
-    // bytes [0, hi) of range r are mapped (returns at once when no thread could be started); any thread may call it
-    void wait(size_t r, size_t hi) const
+    unsigned size() const { return (unsigned)th_.size(); }
+    // start copying; returns a ticket
+    size_t submit(char *dst, const char *src, size_t len)
     {
-        if (!started_) return;
-        const size_t nb = (std::min(hi, ranges_[r].bytes) + kBlock - 1) / kBlock;
-        for (size_t j = 0; j < nb; ++j)
-            while (!done_[ranges_[r].flag0 + j].load(std::memory_order_acquire)) std::this_thread::yield();
+        std::lock_guard<std::mutex> lock(mu_);
+        jobs_.push_back({dst, src, len, (unsigned)th_.size()});
+        cv_.notify_all();
+        return jobs_.size() - 1;
     }
-    ~PageToucher()
+    void wait(size_t ticket)
     {
-        next_.store(order_.size(), std::memory_order_relaxed); // abandon what is left
+        std::unique_lock<std::mutex> lock(mu_);
+        done_cv_.wait(lock, [&] { return jobs_[ticket].left == 0; });
+    }
+    ~CopyPool()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            stop_ = true;
+            cv_.notify_all();
+        }
         for (auto &t : th_) t.join();
     }
 
   private:
-    struct Range {
-        char *p;
-        size_t bytes, flag0;
+    struct Job {
+        char *dst;
+        const char *src;
+        size_t len;
+        unsigned left;
     };
-    void work()
+    void work(unsigned me)
     {
+        size_t next = 0;
         for (;;) {
-            const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
-            if (i >= order_.size()) return;
-            const Range &r = ranges_[order_[i].first];
-            const size_t o0 = order_[i].second * kBlock, n = std::min(kBlock, r.bytes - o0);
-            char *q = r.p + o0;
-            for (size_t o = 0; o < n; o += 4096) __atomic_fetch_or(q + o, 0, __ATOMIC_RELAXED);
-            __atomic_fetch_or(q + n - 1, 0, __ATOMIC_RELAXED);
-            done_[r.flag0 + order_[i].second].store(1, std::memory_order_release);
+            Job j;
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                cv_.wait(lock, [&] { return stop_ || next < jobs_.size(); });
+                if (next >= jobs_.size()) return; // (stop, nothing left)
+                j = jobs_[next];
+            }
+            const size_t k = th_.size(), piece = (j.len / k + 63) & ~size_t(63);
+            const size_t lo = std::min(j.len, piece * me), hi = std::min(j.len, piece * (me + 1));
+            if (hi > lo) memcpy(j.dst + lo, j.src + lo, hi - lo);
+            {
+                std::lock_guard<std::mutex> lock(mu_);
+                if (--jobs_[next].left == 0) done_cv_.notify_all();
+            }
+            ++next;
         }
     }
-    std::vector<Range> ranges_;
-    std::vector<std::pair<size_t, size_t>> order_; // (range, block of it), in the order the threads take them
-    size_t n_flags_ = 0;
-    std::unique_ptr<std::atomic<unsigned char>[]> done_;
-    std::atomic<size_t> next_{0};
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    std::deque<Job> jobs_;
     std::vector<std::thread> th_;
-    bool started_ = false;
+    bool stop_ = false;
 };
-std::atomic<int> g_host_touch_threads{-1}; // azh_set_host_copy_threads: -1 automatic, 0 off
+std::atomic<int> g_host_copy_threads{-1}; // azh_set_host_copy_threads: -1 automatic, 0 = plain pageable copies
 
-// arrays[k] (host) <- src[k] (device), bytes[k] each, in order, on `st`; returns after the last copy has been ISSUED
-int32_t copy_back(void *const *dst, const void *const *src, const size_t *bytes, int n_arrays, hipStream_t st)
+// arrays[k] (host) <- src[k] (device), bytes[k] each, in order, on `st`.  threads: host copy threads (0: the calling thread
+// moves the chunks itself -- one copier thread per device of a group).  The data has landed when this returns.
+int32_t copy_back_staged(HostStager &hs, void *const *dst, const void *const *src, const size_t *bytes, int n_arrays, hipStream_t st,
+                         unsigned threads)
 {
-    constexpr size_t kChunk = size_t(32) << 20;
-    size_t total = 0;
-    for (int k = 0; k < n_arrays; ++k) total += bytes[k];
-    int want = g_host_touch_threads.load(std::memory_order_relaxed);
-    if (want < 0) want = (int)std::min(6u, std::max(1u, std::thread::hardware_concurrency() / 2));
-    if (total < (size_t(16) << 20) || want == 0) {
-        for (int k = 0; k < n_arrays; ++k)
-            if (bytes[k]) HIP_TRY(hipMemcpyAsync(dst[k], src[k], bytes[k], hipMemcpyDeviceToHost, st));
+    if (int32_t rc = hs.ensure(); rc != AZ_OK) return rc;
+    struct Chunk {
+        char *dst;
+        const char *src;
+        size_t len;
+    };
+    std::vector<Chunk> chunks;
+    for (int k = 0; k < n_arrays; ++k)
+        for (size_t o = 0; o < bytes[k]; o += kStageChunk)
+            chunks.push_back({static_cast<char *>(dst[k]) + o, static_cast<const char *>(src[k]) + o, std::min(kStageChunk, bytes[k] - o)});
+    CopyPool pool(threads);
+    const bool pooled = pool.size() > 0;
+    std::vector<size_t> ticket(chunks.size(), 0);
+    auto land = [&](size_t i) -> int32_t { // chunk i has been issued into slot i % S: wait for it, move it out
+        HIP_TRY(hipEventSynchronize(hs.ev[i % kStageSlots]));
+        if (pooled) ticket[i] = pool.submit(chunks[i].dst, static_cast<const char *>(hs.slot[i % kStageSlots]), chunks[i].len);
+        else memcpy(chunks[i].dst, hs.slot[i % kStageSlots], chunks[i].len);
         return AZ_OK;
+    };
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        if (pooled && i >= (size_t)kStageSlots) pool.wait(ticket[i - kStageSlots]); // the slot is free again
+        HIP_TRY(hipMemcpyAsync(hs.slot[i % kStageSlots], chunks[i].src, chunks[i].len, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(hs.ev[i % kStageSlots], st));
+        // (inline mode: chunk i - 1 is moved out while chunk i is on the link; with S >= 2 slots its slot is not reused before)
+        if (i >= 1)
+            if (int32_t rc = land(i - 1); rc != AZ_OK) return rc;
     }
-    PageToucher pt;
-    for (int k = 0; k < n_arrays; ++k) pt.add(dst[k], bytes[k]);
-    pt.start((unsigned)want, false);
-    for (int k = 0; k < n_arrays; ++k) {
-        for (size_t o = 0; o < bytes[k]; o += kChunk) {
-            const size_t len = std::min(kChunk, bytes[k] - o);
-            pt.wait((size_t)k, o + len);
-            HIP_TRY(hipMemcpyAsync(static_cast<char *>(dst[k]) + o, static_cast<const char *>(src[k]) + o, len, hipMemcpyDeviceToHost, st));
-        }
-    }
+    if (!chunks.empty())
+        if (int32_t rc = land(chunks.size() - 1); rc != AZ_OK) return rc;
+    if (pooled)
+        for (size_t i = chunks.size() > (size_t)kStageSlots ? chunks.size() - kStageSlots : 0; i < chunks.size(); ++i) pool.wait(ticket[i]);
     return AZ_OK;
+}
+
+unsigned host_copy_threads()
+{
+    const int want = g_host_copy_threads.load(std::memory_order_relaxed);
+    if (want >= 0) return (unsigned)want;
+    return std::min(6u, std::max(1u, std::thread::hardware_concurrency() / 2));
 }
 
 constexpr size_t kOneStage = 1024; // points served through the pinned staging buffer
@@ -1300,7 +1354,7 @@ int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t enabled)
     return azh_set_f32_mode(c, enabled ? AZH_F32_PACKED : AZH_F32_FP64_ROUNDED);
 }
 
-void azh_set_host_copy_threads(int32_t n) { g_host_touch_threads.store(n < 0 ? -1 : n, std::memory_order_relaxed); }
+void azh_set_host_copy_threads(int32_t n) { g_host_copy_threads.store(n < 0 ? -1 : n, std::memory_order_relaxed); }
 
 int32_t azh_set_tile_kernel(azh_constellation *c, int32_t enabled)
 {
@@ -1718,7 +1772,14 @@ int32_t azh_propagate_host(azh_constellation *c, const double *times, size_t n_t
         void *const dst[3] = {pos, vel, err};
         const void *const src[3] = {d_pos, d_vel, d_err};
         const size_t len[3] = {bytes, vel ? bytes : 0, err ? c->n * n_times : 0};
-        if ((rc = copy_back(dst, src, len, 3, c->s_main)) != AZ_OK) break;
+        const unsigned thr = host_copy_threads();
+        if (thr > 0 && len[0] + len[1] + len[2] >= (size_t(8) << 20)) {
+            if ((rc = copy_back_staged(c->stager, dst, src, len, 3, c->s_main, thr)) != AZ_OK) break;
+        } else {
+            for (int k = 0; k < 3 && rc == AZ_OK; ++k)
+                if (len[k] && !hip_ok(hipMemcpyAsync(dst[k], src[k], len[k], hipMemcpyDeviceToHost, c->s_main), "D2H")) rc = AZ_ERR_HIP;
+            if (rc != AZ_OK) break;
+        }
         if (!hip_ok(hipStreamSynchronize(c->s_main), "sync")) { rc = AZ_ERR_HIP; break; }
     } while (0);
     if (rc != AZ_OK) (void)hipStreamSynchronize(c->s_main);
@@ -2003,55 +2064,39 @@ int32_t azh_group_propagate_host(azh_group *g, const double *times, size_t n_tim
                         err ? c->d_host_err.p : nullptr, c->s_main);
         if (rc != AZ_OK) break;
     }
-    // Copies: a cell = consecutive catalog rows = consecutive local rows, one copy per cell and array.  A D2H into pageable
-    // memory holds its host thread until the data has landed, so every device gets its OWN copier thread -- the N PCIe links
-    // then run side by side (issued from one thread they would take turns) -- and the destination pages are mapped ahead of
-    // the copies, round-robin over the cells (copy_back's reasoning, for several copy streams at once).
-    struct Piece {
-        int d;
-        size_t range;
-        char *dst;
-        const char *src;
-        size_t bytes;
-    };
-    std::vector<Piece> pieces;
-    PageToucher pt;
+    // Copies: a cell = consecutive catalog rows = consecutive local rows, one copy per cell and array.  Every device gets its
+    // OWN copier thread, which stages its cells through that device's pinned slots while its share of the host copy threads
+    // moves each landed chunk into the caller's array (copy_back_staged): the N PCIe links run side by side (issued from one
+    // thread, host-synchronous pageable copies would take turns) and at least N threads write the host arrays.
     if (rc == AZ_OK) {
-        for (int arr = 0; arr < 3; ++arr) {
-            if ((arr == 1 && !vel) || (arr == 2 && !err)) continue;
-            const size_t unit = arr == 2 ? n_times : row * sizeof(double); // bytes per satellite row
-            for (int d = 0; d < g->n_dev; ++d) {
-                azh_constellation *c = g->shard[d];
-                if (!c) continue;
+        std::vector<int32_t> rcs(g->n_dev, AZ_OK);
+        const bool staged = host_copy_threads() > 0;
+        const unsigned per_dev = std::max(1u, host_copy_threads() / (unsigned)std::max(1, g->n_dev)); // host threads behind each device
+        auto copier = [&](int d) {
+            azh_constellation *c = g->shard[d];
+            if (!c) return;
+            if (hipSetDevice(c->device) != hipSuccess) { rcs[d] = AZ_ERR_HIP; return; }
+            std::vector<void *> dst;
+            std::vector<const void *> src;
+            std::vector<size_t> len;
+            for (int arr = 0; arr < 3; ++arr) {
+                if ((arr == 1 && !vel) || (arr == 2 && !err)) continue;
+                const size_t unit = arr == 2 ? n_times : row * sizeof(double); // bytes per satellite row
                 const char *base = arr == 0 ? (const char *)c->d_host_pos.p : arr == 1 ? (const char *)c->d_host_vel.p : (const char *)c->d_host_err.p;
                 char *out = arr == 0 ? (char *)pos : arr == 1 ? (char *)vel : (char *)err;
                 size_t local = 0;
                 for (size_t k = 0; k < g->n_chunks; ++k) {
                     const size_t lo = g->cell_lo(k, d), cnt = g->cell_hi(k, d) - lo;
                     if (!cnt) continue;
-                    pieces.push_back({d, pt.add(out + lo * unit, cnt * unit), out + lo * unit, base + local * unit, cnt * unit});
+                    dst.push_back(out + lo * unit); src.push_back(base + local * unit); len.push_back(cnt * unit);
                     local += cnt;
                 }
             }
-        }
-        size_t total = 0;
-        for (auto &q : pieces) total += q.bytes;
-        int want = g_host_touch_threads.load(std::memory_order_relaxed);
-        if (want < 0) want = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
-        if (want > 0 && total >= (size_t(16) << 20)) pt.start((unsigned)want, true);
-        std::vector<int32_t> rcs(g->n_dev, AZ_OK);
-        auto copier = [&](int d) {
-            azh_constellation *c = g->shard[d];
-            if (!c) return;
-            if (hipSetDevice(c->device) != hipSuccess) { rcs[d] = AZ_ERR_HIP; return; }
-            constexpr size_t kChunk = size_t(32) << 20;
-            for (auto &q : pieces) {
-                if (q.d != d) continue;
-                for (size_t o = 0; o < q.bytes; o += kChunk) {
-                    const size_t len = std::min(kChunk, q.bytes - o);
-                    pt.wait(q.range, o + len);
-                    if (hipMemcpyAsync(q.dst + o, q.src + o, len, hipMemcpyDeviceToHost, c->s_main) != hipSuccess) { rcs[d] = AZ_ERR_HIP; return; }
-                }
+            if (staged) {
+                rcs[d] = copy_back_staged(c->stager, dst.data(), src.data(), len.data(), (int)dst.size(), c->s_main, per_dev);
+            } else {
+                for (size_t k = 0; k < dst.size(); ++k)
+                    if (hipMemcpyAsync(dst[k], src[k], len[k], hipMemcpyDeviceToHost, c->s_main) != hipSuccess) { rcs[d] = AZ_ERR_HIP; return; }
             }
             if (hipStreamSynchronize(c->s_main) != hipSuccess) rcs[d] = AZ_ERR_HIP;
         };
@@ -2066,7 +2111,7 @@ int32_t azh_group_propagate_host(azh_group *g, const double *times, size_t n_tim
         copier(0);
         for (auto &t : th) t.join();
         for (int d = 0; d < g->n_dev; ++d)
-            if (rcs[d] != AZ_OK) { rc = rcs[d]; g_last_error = "device-to-host copy failed"; (void)hipGetLastError(); }
+            if (rcs[d] != AZ_OK) { rc = rcs[d]; if (g_last_error.empty()) g_last_error = "device-to-host copy failed"; (void)hipGetLastError(); }
     }
     for (int d = 0; d < g->n_dev; ++d) {
         azh_constellation *c = g->shard[d];

@@ -503,10 +503,15 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
 // record (atime, xli, xni) for every tile.  Lane = deep-space list slot; sequential in time like the
 // reference's carry (src/Constellation.zig L448-476), but only the integrator -- a few dozen
 // instructions per 720 minutes of elapsed time -- so the serial chain is short.
+// node_cache (may be null): [3][n_pad], per SATELLITE the integrator state (atime, xli, xni) the previous seeding pass left
+// nearest to epoch.  The integrator's nodes -- epoch + k * 720 min -- depend on the satellite alone, not on the grid
+// (src/Sdp4.zig L774-820; the reference keeps them as its carry, src/Sdp4Batch.zig L241-249), so a new grid continues from the
+// cached node instead of re-integrating from epoch (a 300-day-old resonant element set: 600 steps per new grid otherwise);
+// az_resonance_advance's own restart rule rejects a cached node the new grid lies inside of or on the other side of epoch.
 __global__ void __launch_bounds__(64) k_deep_seed(const double *el, const unsigned *flags, size_t n_pad,
                                                   const unsigned *list, unsigned n_list, const double *times,
                                                   unsigned n_times, const double *offsets, unsigned tile,
-                                                  double *seeds, int nearest)
+                                                  double *seeds, int nearest, double *node_cache)
 {
     __shared__ double cold_lds[D_NUM * 64];
     const unsigned li = blockIdx.x * 64 + threadIdx.x;
@@ -520,6 +525,13 @@ __global__ void __launch_bounds__(64) k_deep_seed(const double *el, const unsign
     cy.atime = 0.0;
     cy.xli = e(H_xlamo);
     cy.xni = e(H_no_unkozai);
+    if (node_cache && node_cache[s] != 0.0) {
+        cy.atime = node_cache[s];
+        cy.xli = node_cache[n_pad + s];
+        cy.xni = node_cache[2 * n_pad + s];
+    }
+    Sdp4Carry near = cy; // the state nearest to epoch this pass comes by
+    bool have_near = false;
     const double off = offsets ? offsets[s] : 0.0;
     const unsigned n_tiles = (n_times + tile - 1) / tile;
     for (unsigned k = 0; k < n_tiles; ++k) {
@@ -533,12 +545,21 @@ __global__ void __launch_bounds__(64) k_deep_seed(const double *el, const unsign
             else if (fabs(t_end) < fabs(t)) t = t_end;
         }
         if (az_any(e.irez != 0)) az_resonance_advance(e, ColdLds{cold}, t, cy);
+        if (!have_near || fabs(cy.atime) < fabs(near.atime)) {
+            near = cy;
+            have_near = true;
+        }
         if (in_range) {
             double *sd = seeds + (size_t)k * 3 * n_list + li;
             sd[0] = cy.atime;
             sd[n_list] = cy.xli;
             sd[2 * (size_t)n_list] = cy.xni;
         }
+    }
+    if (node_cache && in_range && e.irez != 0 && have_near) {
+        node_cache[s] = near.atime;
+        node_cache[n_pad + s] = near.xli;
+        node_cache[2 * n_pad + s] = near.xni;
     }
 }
 

@@ -382,14 +382,18 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
 
             def calls(k):
                 ws = []
+                e_ = r_ = v_ = None
                 for _ in range(k):
+                    del e_, r_, v_          # (the previous result is returned to the OS outside the timed call)
                     t0 = time.perf_counter()
-                    e_, r_, v_ = arr.sgp4(jd, fr)
+                    res_ = arr.sgp4(jd, fr)
                     ws.append((time.perf_counter() - t0) * 1e3)
+                    e_, r_, v_ = res_
+                    del res_
                 return ws, (e_, r_, v_)
             calls(2)
             ws, (e_, r_, v_) = calls(7)
-            _native.set_host_copy_threads(0)           # the plain path: the copy faults the fresh pages in itself
+            _native.set_host_copy_threads(0)           # the plain path: pageable D2H straight into the fresh arrays
             ws0, _ = calls(3)
             _native.set_host_copy_threads(-1)
             ms = sorted(ws)[len(ws) // 2]
@@ -397,10 +401,11 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             ent.update({"ms_per_step": ms, "value": n2 * 1440 / (ms / 1e3), "unit": "propagations/s (host arrays, PCIe-inclusive)",
                         "n_sats": n2, "n_times": 1440, "calls_ms": ws, "d2h_GB_per_s_of_wall": out_bytes / (ms / 1e3) / 1e9,
                         "path": arr._dev.last_path(),
-                        "without_page_touch_threads_ms": sorted(ws0)[len(ws0) // 2],
-                        "what": "page-touch threads map the fresh result arrays ahead of the chunked D2H (azh_set_host_copy_threads); "
-                                "without them the copy runs at the rate the runtime faults pages in.  PCIe Gen5 x16 moves the 932 MB "
-                                "in ~16.4 ms: that, not the 0.3-ms kernel, bounds this call"})
+                        "direct_pageable_copy_ms": sorted(ws0)[len(ws0) // 2],
+                        "what": "results travel device -> pinned staging slots -> the fresh numpy arrays, the second hop by host threads while "
+                                "the next chunk is on the link (azh_set_host_copy_threads); direct_pageable_copy_ms: the same call with "
+                                "plain pageable D2H copies (the runtime pins the fresh range first).  PCIe Gen5 x16 moves the 932 MB in "
+                                "~16.4 ms: that, not the 0.3-ms kernel, bounds this call"})
             rws = _sample_rows(n2, 16)
             cat = oracle.Catalog.from_pairs([pairs2[i] for i in rws], oracle.WGS72)
             rjd = jd[0] + fr[0]
@@ -767,10 +772,14 @@ def main():
                 grp = _native.DeviceGroup(text, devs, _native.WGS72, n_chunks=1)
                 goff = (synth.START_JD - grp.epochs) * 1440.0
                 ws = []
+                gp = gv = None
                 for _ in range(5):
+                    del gp, gv              # (the previous result is returned to the OS outside the timed call)
                     t0 = time.perf_counter()
-                    gp, gv, _ = grp.propagate_host(times, goff, velocities=vel_on)
+                    res_ = grp.propagate_host(times, goff, velocities=vel_on)
                     ws.append((time.perf_counter() - t0) * 1e3)
+                    gp, gv = res_[0], res_[1]
+                    del res_
                 gms = sorted(ws[1:])[len(ws[1:]) // 2]
                 group_host = {"ms_per_call": gms, "calls_ms": ws, "devices": len(devs), "value": n_total * n_times / (gms / 1e3),
                               "GB_per_s": (gp.nbytes + (gv.nbytes if gv is not None else 0)) / (gms / 1e3) / 1e9,

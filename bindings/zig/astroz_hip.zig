@@ -117,7 +117,7 @@ pub extern "c" fn azh_set_f32_mode(h: ?*Handle, mode: i32) i32; // 0 mixed preci
 pub extern "c" fn azh_set_f32_arithmetic(h: ?*Handle, enabled: i32) i32; // boolean: 0 = fp64 rounded at the store, else packed fp32
 pub extern "c" fn azh_set_fast_path(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_set_tile_kernel(h: ?*Handle, enabled: i32) i32;
-pub extern "c" fn azh_set_host_copy_threads(n: i32) void; // page-touch threads ahead of host-returning copies (-1 auto, 0 off)
+pub extern "c" fn azh_set_host_copy_threads(n: i32) void; // host threads behind the pinned staging of host-returning copies (-1 auto, 0 = direct pageable copies)
 pub extern "c" fn azh_last_path(h: ?*const Handle) u32; // AZH_PATH_* bits: which kernel families the last call launched
 pub extern "c" fn azh_propagate_one_device(h: ?*Handle, sat_index: usize, d_tsince_min: [*]const f64, n: usize, d_pos: [*]f64,
     d_vel: ?[*]f64, d_err: ?[*]u8, stream: ?*anyopaque) i32;

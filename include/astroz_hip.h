@@ -336,9 +336,10 @@ int32_t azh_set_fast_path(azh_constellation *c, int32_t enabled);
  * time arithmetic, transposed through LDS); disabled, the lane = satellite kernel serves that layout.  Results of the
  * two agree to rounding; the switch exists so that tests and benchmarks can compare them. */
 int32_t azh_set_tile_kernel(azh_constellation *c, int32_t enabled);
-/* host-returning calls (azh_propagate_host, azh_propagate_jd_host, azh_group_propagate_host): threads that touch the pages of
- * the caller's (typically fresh) result arrays ahead of the device-to-host copy, so that the copy runs at the rate of the
- * PCIe link instead of the rate pages are faulted in (config 2: 54 -> 20 ms).  -1 automatic (default), 0 off. */
+/* host-returning calls (azh_propagate_host, azh_propagate_jd_host, azh_group_propagate_host): results travel device -> pinned
+ * staging slots (kept in the handle) -> the caller's arrays, the second hop by n host threads while the next chunk is on the
+ * link.  A direct copy into FRESH pageable arrays pays the runtime's first-time pinning of the range (config 2: 55 ms instead
+ * of the link's 17).  -1 automatic (default: 6), 0 = direct pageable copies. */
 void azh_set_host_copy_threads(int32_t n);
 /* enable (default) / disable the hipEvent pair recorded around every propagate call; disabling it
  * removes two event records per call from tight replay loops (azh_last_kernel_ms then returns -1) */

@@ -190,3 +190,32 @@ def test_jdfr_grid_fp32_and_screen(native, orc, synth):
     assert dev.last_path() & native.PATH_ROWS_FAST and dev.last_path() & native.PATH_QUASI_UNIFORM
     d0, t0 = cat.screen_target(times, 5, 2000.0, off)
     assert np.array_equal(t, t0) and np.abs(d - d0).max() < TOL_R
+
+
+def test_resonance_node_cache_is_invisible(native, orc, synth):
+    """k_deep_seed continues from the integrator node the previous grid left in the handle (the nodes depend on the satellite
+    only).  Whatever the history -- later grid, earlier grid (inside the cached node: restart), other side of epoch,
+    different offsets -- a handle with history and a fresh handle agree BIT FOR BIT, and with the oracle."""
+    import torch
+    pairs = synth.synth_catalog(n_near=40, n_deep=700, seed=77)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    used = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    off = (synth.START_JD - used.epochs) * 1440.0
+    grids = [np.arange(0.0, 1440.0), 40000.0 + np.arange(0.0, 2880.0, 2.0), 9000.0 + np.arange(0.0, 720.0),
+             -30000.0 + 3.0 * np.arange(0.0, 500.0), 40000.0 + np.arange(0.0, 300.0), np.arange(-700.0, 800.0, 1.5)]
+    for j, t in enumerate(grids):
+        o = off + (1000.0 if j == 4 else 0.0)
+        for layout, olay in ((native.SAT_MAJOR, orc.SAT_MAJOR), (native.TIME_MAJOR, orc.TIME_MAJOR)):
+            fresh = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+            shape = (used.n, len(t), 3) if layout == native.SAT_MAJOR else (len(t), used.n, 3)
+            res = []
+            for dev in (used, fresh):
+                pos, vel = np.empty(shape), np.empty(shape)
+                err = np.zeros((used.n, len(t)), dtype=np.uint8)
+                dev.propagate_host(t, o, pos=pos, vel=vel, err=err, layout=layout)
+                res.append((pos, vel, err))
+            fresh.close()
+            assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]), (j, layout)
+            e0, p0, v0 = cat.propagate(t, o, layout=olay)
+            assert np.array_equal(res[0][2], e0)
+            assert np.abs(res[0][0] - p0).max() < TOL_R and np.abs(res[0][1] - v0).max() < TOL_V, (j, layout)
