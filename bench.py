@@ -264,13 +264,14 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
         return e0.elapsed_time(e1) / steps
 
     def case(key, workload, kernel, dev, pairs, n_times, *, layout, vel=True, f32=False, mode=0, steps=50, warm=20,
-             cold=False, rows=16, ref_jd=0.0, arith32="mixed", stride_align=0, grid="uniform"):
+             cold=False, rows=16, ref_jd=0.0, arith32="mixed", stride_align=0, grid="uniform", gen_ts=0):
         if key in skip:
             return
         ent = {"key": key, "workload": workload, "kernel": kernel}
         try:
             n = dev.n
             dev.set_f32_arithmetic(arith32)
+            dev.set_tile_kernel(gen_ts or 16)   # (tile height of the generic tile kernel: 16, or 12 as an experiment)
             times = np.arange(n_times, dtype=np.float64)
             offs = (synth.START_JD - dev.epochs) * 1440.0
             if grid == "jdfr":
@@ -359,7 +360,9 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
     case("config2_sat_major_jdfr", "config 2, satellite-major, on the (jd, fr) grid of the reference's API call",
          "k_rows_fast<pos+vel,DELTA> + redo", dev2, pairs2, 1440, layout=SM, grid="jdfr")
     case("config2_time_major_irregular", "config 2, TIME-major, irregular grid (one-minute steps with +-20 s jitter)",
-         "generic time-major kernel", dev2, pairs2, 1440, layout=TM, grid="irregular", steps=20, warm=5)
+         "k_tiles (generic step, 16-row tiles)", dev2, pairs2, 1440, layout=TM, grid="irregular", steps=20, warm=5)
+    case("config2_time_major_irregular_ts12", "config 2, TIME-major, irregular grid, 12-row tiles (experiment: 135 VGPRs, no scratch, 3 waves/SIMD)",
+         "k_tiles<TS=12>", dev2, pairs2, 1440, layout=TM, grid="irregular", steps=20, warm=5, gen_ts=12)
     case("config2_sat_major_irregular", "config 2, satellite-major, irregular grid (one-minute steps with +-20 s jitter)",
          "k_rows (generic, lane = time)", dev2, pairs2, 1440, layout=SM, grid="irregular", steps=20, warm=5)
     case("config2_ecef_time_major", "config 2, ECEF time-major (the default of the reference's high-level propagate(), "
