@@ -19,7 +19,7 @@ OUTPUT_MODES = {"teme": OUT_TEME, "ecef": OUT_ECEF, "geodetic": OUT_GEODETIC}
 
 AZ_ERR_HIP = -200
 # azh_last_path bits (include/astroz_hip.h)
-PATH_ROWS_FAST, PATH_TILES_FAST, PATH_ROWS_GENERIC, PATH_LANE_SAT, PATH_DEEP_ROWS, PATH_QUASI_UNIFORM, PATH_TILES_GENERIC = 1, 2, 4, 8, 16, 32, 64
+PATH_ROWS_FAST, PATH_TILES_FAST, PATH_ROWS_GENERIC, PATH_LANE_SAT, PATH_DEEP_ROWS, PATH_QUASI_UNIFORM = 1, 2, 4, 8, 16, 32
 
 # every symbol include/astroz_hip.h declares (tests check the library exports all of them)
 EXPORTS = [

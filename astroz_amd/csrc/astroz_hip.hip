@@ -180,7 +180,6 @@ struct azh_constellation {
     unsigned off_rowmap = 0;   // d_list + off_rowmap: per catalog row, kind << 30 | slot (AZ_ROW_*: k_tiles_fast)
     DevBuf<double> d_deep_tmp; // time-major output: the deep-space rows' compact satellite-major scratch (k_deep_transpose)
     bool tile_kernel = true; // time-major output through the tile kernels (azh_set_tile_kernel)
-    unsigned gen_tile_sats = 16; // satellites per tile of the generic tile kernel (k_tiles): 16 or 12 (azh_set_tile_kernel(c, 12))
     unsigned off_circ = 0, n_circ = 0; // d_list + off_circ: near-earth members in catalog order, [n_circ of eccentricity class 0 | the rest]
     bool timed = false;
     bool timing = true; // record the ev_t0/ev_t1 pair around every launch set (azh_set_timing)
@@ -526,7 +525,7 @@ FastShape fast_shape_tiles(const PropArgs &a, unsigned n_rows)
     FastShape f;
     unsigned tile = std::min(rows_tile(std::max((n_rows + 15u) / 16u, 1u) * 16u, a.n_times, a.tile_forced), fast_window_cap(a.uniform_step));
     if (a.mode != AZ_OUT_TEME) tile = std::min(tile, (unsigned)AZ_TILE_SEG_MAX); // the Greenwich-angle table of a time segment is staged in LDS
-    if (a.delta) tile = std::min(tile, (unsigned)AZ_DELTA_SEG);                  // ... and the deviations of a quasi-uniform grid
+    if (a.delta) tile = std::min(tile, (unsigned)AZ_DELTA_SEG);  // ... and the deviations of a quasi-uniform grid
     f.tile_c = f.tile_e = tile;
     f.kind = 2;
     return f;
@@ -862,12 +861,12 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     unsigned path = 0;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
     if (d_err) HIP_TRY(hipMemsetAsync(d_err + row_lo * (size_t)n_times, 0, (row_hi - row_lo) * (size_t)n_times, st));
-    // time-major output: the near-earth members take a 16-satellite tile kernel -- the branch-free one on a (quasi-)uniform grid
-    // without a mask (k_tiles_fast), the generic one on any other grid and with masks (k_tiles)
-    const bool tiles_any = c->n_sgp4 > 0 && c->tile_kernel && layout == AZ_LAYOUT_TIME_MAJOR && !f32 && n_times >= 64 &&
-                           (size_t)stride * 64 * 24 < 0xf0000000ull; // (32-bit byte offsets inside a block of 64 time rows)
-    const bool tiles_fast = tiles_any && a.inc != nullptr && a.mask == nullptr;
-    const bool tiles = tiles_any;
+    // time-major output on a (quasi-)uniform grid: the near-earth members take the 16-satellite tile kernel.  (Irregular grids
+    // and masked launches stay on the lane = satellite kernel: a generic-step tile kernel was built and measured in round 4 --
+    // 0.40 ms against k_propagate's 0.35 on an irregular grid, 0.65 against 0.44 with a mask -- see profiles/r04_experiments.txt.)
+    const bool tiles = c->n_sgp4 > 0 && c->tile_kernel && a.inc != nullptr && layout == AZ_LAYOUT_TIME_MAJOR && !f32 &&
+                       a.mask == nullptr && n_times >= 64 &&
+                       (size_t)stride * 64 * 24 < 0xf0000000ull; // (k_tiles_fast: 32-bit byte offsets inside a block of 64 time rows)
     const bool fork = c->n_sdp4 > 0;
     if (fork) {
         // deep-space rows on their own stream, concurrent with the near-earth launch
@@ -916,7 +915,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         if (tiles && fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
         if (tiles) a.list = c->d_list.p + c->off_cat; // plain catalog order; the redo items index this list
         FastShape shape;
-        const bool fast = a.inc != nullptr && (tiles_fast || (!tiles && use_rows(a, layout, false)));
+        const bool fast = a.inc != nullptr && (tiles || use_rows(a, layout, false));
         if (fast) {
             // uniform grid: every near-earth member -> the branch-free kernels (near-circular or eccentric Kepler form by
             // class), windows prepared and validated once per staged grid by the plan; what the plan rejects and what the
@@ -929,28 +928,9 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
             shape = tiles ? fast_shape_tiles(a, (unsigned)c->n) : fast_shape_rows(a, c->n_sgp4, c->n_circ);
             if (int32_t rc = ensure_plan(c, a, shape, st); rc != AZ_OK) return rc;
         }
-        if (a.n_list > 0 && tiles_fast) {
+        if (a.n_list > 0 && tiles) {
             launch_tiles(a, d_vel != nullptr, st, shape);
             path |= AZH_PATH_TILES_FAST;
-        } else if (a.n_list > 0 && tiles) {
-            // any grid / masks: the generic step in the same tile structure
-            a.rowmap = c->d_list.p + c->off_rowmap;
-            a.n_rows = (unsigned)c->n;
-            const unsigned ts = c->gen_tile_sats;
-            a.tile = std::min(rows_tile(((unsigned)c->n + ts - 1u) / ts * 16u, n_times, c->tile_sgp4), (unsigned)AZ_TILES_TSEG);
-            dim3 grid((((unsigned)c->n + ts - 1u) / ts + 7u) / 8u * 8u, (n_times + a.tile - 1) / a.tile);
-            const bool vel = d_vel != nullptr, fr = a.mode != AZ_OUT_TEME;
-#define AZ_LAUNCH_TILES(V, F)                                                                                   \
-    do {                                                                                                        \
-        if (ts == 12u) hipLaunchKernelGGL((k_tiles<V, F, 12u>), grid, dim3(768), 0, st, a);                       \
-        else hipLaunchKernelGGL((k_tiles<V, F, 16u>), grid, dim3(1024), 0, st, a);                                \
-    } while (0)
-            if (fr && vel) AZ_LAUNCH_TILES(true, true);
-            else if (fr) AZ_LAUNCH_TILES(false, true);
-            else if (vel) AZ_LAUNCH_TILES(true, false);
-            else AZ_LAUNCH_TILES(false, false);
-#undef AZ_LAUNCH_TILES
-            path |= AZH_PATH_TILES_GENERIC;
         } else if (a.n_list > 0) {
             path |= launch_propagate(a, layout, d_vel != nullptr, false, st, EccSide{c->s_ecc, c->ev_fork2, c->ev_join2}, fast ? &shape : nullptr);
         }
@@ -1382,7 +1362,6 @@ int32_t azh_set_tile_kernel(azh_constellation *c, int32_t enabled)
 {
     if (!c) return AZ_ERR_NULL_POINTER;
     c->tile_kernel = enabled != 0;
-    if (enabled == 12 || enabled == 16) c->gen_tile_sats = (unsigned)enabled; // (tuning: tile height of the generic tile kernel)
     return AZ_OK;
 }
 

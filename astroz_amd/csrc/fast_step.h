@@ -208,8 +208,8 @@ AZ_DEVICE void az_fast_rec_store(const double *__restrict__ el, size_t n_pad, si
     for (int j = FR_USED; j < FR_NUM; ++j) rec[j] = 0.0;
 }
 // the wave-uniform part of a FastKBcast from the record (scalar loads)
-template <class K>
-AZ_DEVICE void az_fast_rec_hot(const double *__restrict__ rec, K &k)
+template <class K, class P = const double *__restrict__>
+AZ_DEVICE void az_fast_rec_hot(P rec, K &k)
 {
 #define X(n) k.n##_ = rec[FR_##n];
     AZ_FASTK_HOT_REC(X)

@@ -1216,141 +1216,6 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
     }
 }
 
-// TIME-MAJOR output on ANY grid, with satellite masks: the tile structure of k_tiles_fast (16 consecutive catalog rows per
-// workgroup, one wave per row, lane = time, 64-step iterations transposed through two alternating LDS tile buffers and
-// flushed as 384-byte runs) around the GENERIC step az_sgp4_step (tier votes, any time grid; the time values of the
-// workgroup's segment are staged in LDS once, so the loop holds no vector-memory load).  It replaces the lane = satellite
-// kernel (k_propagate: 257-282 VGPRs, one wave per SIMD, 0.37 ms on config 2) for irregular grids and masked launches --
-// the reference's driver takes any grid at one speed (src/Constellation.zig L387-434).  Deep-space rows are copied through
-// from the compact scratch array k_rows_deep filled just before, failed members are zeros, masked members are left
-// untouched (a tile with a masked member leaves as 8-byte pieces at per-satellite columns).
-#define AZ_TILES_TSEG 1024 /* grid points per time segment (their time values, and the Greenwich angles, sit in LDS) */
-template <bool VEL, bool FRAME, unsigned TS = AZ_TILE_SATS> // TS: satellites (= waves) per tile, 16 or 12 (3 waves/SIMD: 168 VGPRs)
-__global__ void __launch_bounds__(TS * 64, 1) k_tiles(PropArgs p)
-{
-    constexpr unsigned PITCH = TS * 3u + 1u;   // doubles per staged time row (odd: conflict-free ds_write_b64 per half-wave)
-    constexpr unsigned PPR = TS * 24u / 16u;   // sixteen-byte pieces per time row and array
-    constexpr unsigned NT = TS * 64u;          // threads
-    constexpr unsigned NA = VEL ? 2u : 1u;
-    constexpr unsigned COLD = (C_NUM_MAX + 2);
-    __shared__ __attribute__((aligned(16))) double cold_all[TS * COLD];
-    __shared__ __attribute__((aligned(16))) double tile[2 * NA * 64 * PITCH];
-    __shared__ double tl[AZ_TILES_TSEG];
-    __shared__ double gst[FRAME ? 2 * AZ_TILES_TSEG : 2];
-    const unsigned lane = threadIdx.x & 63u, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned tile_id = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3); // XCD-aware, see k_tiles_fast
-    const unsigned s_first = tile_id * TS;
-    if (s_first >= p.n_rows) return; // padding workgroup (uniform over the workgroup)
-    const unsigned n_valid = min(TS, p.n_rows - s_first);
-    const bool have = w < n_valid;
-    const unsigned s = s_first + (have ? w : 0u);
-    const unsigned fl = p.flags[s];
-    const unsigned rm = p.rowmap[s], kind = rm >> 30, slot = rm & 0x3fffffffu;
-    const unsigned t_lo = blockIdx.y * p.tile, t_hi = min(t_lo + p.tile, p.n_times);
-    const bool wanted = have && s >= p.row_lo && s < p.row_hi && (p.mask == nullptr || p.mask[s] != 0);
-    // a full tile whose 16 members are all wanted leaves as 16-byte pieces (384-byte runs)
-    const bool contig = __syncthreads_and(wanted ? 1 : 0) != 0 && n_valid == TS;
-    const bool compute = wanted && kind == AZ_ROW_NEAR, copy = wanted && kind == AZ_ROW_COPY, zero = wanted && kind == AZ_ROW_ZERO;
-    for (unsigned j = threadIdx.x; j < t_hi - t_lo; j += NT) {
-        tl[j] = p.times[t_lo + j];
-        if (FRAME) {
-            gst[2 * j] = p.sin_g[t_lo + j];
-            gst[2 * j + 1] = p.cos_g[t_lo + j];
-        }
-    }
-    const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
-    const RotK rk = az_rotk();
-    Sgp4Lane e;
-    const ColdBroadcast cold{cold_all + w * COLD};
-    Sgp4Carry c;
-    if (compute) {
-        az_load_sgp4(p.el, p.n_pad, s, fl, e, cold);
-        e.mdot = az_uniform(e.mdot); e.argpdot = az_uniform(e.argpdot); e.nodedot = az_uniform(e.nodedot);
-        e.xnodcf = az_uniform(e.xnodcf); e.aycof = az_uniform(e.aycof); e.xlcof = az_uniform(e.xlcof);
-        e.sinio = az_uniform(e.sinio); e.cosio = az_uniform(e.cosio); e.k_mrt = az_uniform(e.k_mrt);
-        e.k_c2u = az_uniform(e.k_c2u); e.k_su = az_uniform(e.k_su); e.k_node = az_uniform(e.k_node);
-        e.k_inc = az_uniform(e.k_inc); e.x1mth2 = az_uniform(e.x1mth2); e.k_rv = az_uniform(e.k_rv);
-    }
-    c.t_prev = 0.0;
-    c.sW = c.sO = c.sA = 0.0;
-    c.cW = c.cO = c.cA = 1.0;
-    // (the generic increments of az_sgp4_step: a lane's steps are 64 grid points apart -- dA is radians -- and on an irregular
-    // grid no increment repeats, so the cached-increment form of k_rows buys nothing here and costs ten registers)
-    __syncthreads(); // tl / gst / cold tables
-    // This thread's share of a tile flush: threads 0..32 PPR - 1 each move the sixteen-byte piece (row, col) and the piece (row + 32,
-    // col) of every array -- PPR pieces per time row, consecutive lanes = consecutive pieces of a run -- from ONE LDS
-    // offset and ONE output offset plus constants (a quarter of the workgroup idles during the flush; the stores, not the
-    // threads, pace it).  [k_tiles_fast keeps three (offset, offset) pairs per thread: six registers more.]
-    const unsigned f_rowi = threadIdx.x / PPR, f_col = threadIdx.x - f_rowi * PPR;
-    const bool f_on = threadIdx.x < 32u * PPR;
-    const unsigned f_lds = (f_rowi * PITCH + f_col * 2u) * 8u;
-    const unsigned f_out = (unsigned)(((size_t)f_rowi * p.stride_sats + s_first) * 24u + f_col * 16u);
-    const size_t f_half = (size_t)32 * p.stride_sats * 24u; // bytes between time rows r and r + 32 (uniform)
-    const bool stream_out = ((p.stride_sats * 24u) & 127u) == 0 && ((reinterpret_cast<size_t>(p.pos) | (VEL ? reinterpret_cast<size_t>(p.vel) : 0)) & 127u) == 0;
-    unsigned kiter = 0;
-#pragma unroll 1
-    for (unsigned base = t_lo; base < t_hi; base += 64, ++kiter) {
-        const unsigned i = base + lane;
-        const unsigned jj = min(i, t_hi - 1) - t_lo;
-        double r[3], v[3];
-        if (compute) {
-            const double t = tl[jj] + off;
-            const bool first = ((base - t_lo) & (64u * 64u - 1u)) == 0; // full re-seed of the carried pairs every 4,096 grid points
-            az_sgp4_step<VEL, ColdBroadcast, false>(e, cold, p.el, p.n_pad, s, p.g, rk, t, first, c, r, v);
-            if (FRAME) {
-                const double sg = gst[2 * jj], cg = gst[2 * jj + 1];
-                az_to_ecef(r, sg, cg);
-                if (VEL) az_to_ecef(v, sg, cg);
-                if (p.mode == 2) az_ecef_to_geodetic(r);
-            }
-        } else if (copy) {
-            const size_t at = ((size_t)slot * p.n_times + min(i, t_hi - 1)) * 3; // the frame is already the output's
-            r[0] = p.tmp_pos[at]; r[1] = p.tmp_pos[at + 1]; r[2] = p.tmp_pos[at + 2];
-            if (VEL) { v[0] = p.tmp_vel[at]; v[1] = p.tmp_vel[at + 1]; v[2] = p.tmp_vel[at + 2]; }
-        } else {
-            r[0] = r[1] = r[2] = 0.0;
-            v[0] = v[1] = v[2] = 0.0;
-        }
-        double *buf = tile + (kiter & 1u) * (NA * 64 * PITCH);
-        if (wanted) {
-            double *q = buf + lane * PITCH + w * 3;
-            q[0] = r[0]; q[1] = r[1]; q[2] = r[2];
-            if (VEL) {
-                q += 64 * PITCH;
-                q[0] = v[0]; q[1] = v[1]; q[2] = v[2];
-            }
-        }
-        __syncthreads();
-        const size_t gbase = (size_t)base * p.stride_sats * 3; // uniform
-        const bool full = base + 64 <= t_hi;
-        if (contig) {
-            const char *bufc = reinterpret_cast<const char *>(buf) + f_lds;
-            char *pos_b = reinterpret_cast<char *>(p.pos + gbase) + f_out, *vel_b = VEL ? reinterpret_cast<char *>(p.vel + gbase) + f_out : nullptr;
-            if (f_on) {
-#pragma unroll
-                for (unsigned h = 0; h < 2; ++h) {
-                    if (!full && base + f_rowi + 32u * h >= t_hi) continue;
-#pragma unroll
-                    for (unsigned arr = 0; arr < NA; ++arr) {
-                        const az_d2s val = *reinterpret_cast<const az_d2s *>(bufc + (arr * (64u * PITCH) + h * (32u * PITCH)) * 8u);
-                        az_d2s *g = reinterpret_cast<az_d2s *>((arr ? vel_b : pos_b) + h * f_half);
-                        if (stream_out) __builtin_nontemporal_store(val, g);
-                        else *g = val;
-                    }
-                }
-            }
-        } else {
-            // the last tile of the catalog / a tile a row window or a mask cuts through: 8-byte pieces at per-satellite columns
-            for (unsigned q = threadIdx.x; q < NA * 64u * TS * 3u; q += NT) {
-                const unsigned arr = q / (64u * TS * 3u), pe = q - arr * (64u * TS * 3u), row = pe / (TS * 3u), d = pe - row * (TS * 3u), j = d / 3u;
-                const unsigned sj = s_first + j;
-                if (j >= n_valid || sj < p.row_lo || sj >= p.row_hi || base + row >= t_hi || (p.mask != nullptr && p.mask[sj] == 0)) continue;
-                ((arr ? p.vel : p.pos) + gbase + ((size_t)row * p.stride_sats + s_first) * 3)[d] = buf[arr * (64u * PITCH) + row * PITCH + d];
-            }
-        }
-    }
-}
-
 // Staging of the packed kernel, DS instructions written by hand.  Component j of a lane's two grid points sits in
 // one register pair while the row wants (x y z)(x y z): ds_write2_b32 puts the two halves three floats apart without
 // a register move (the compiler pairs NEIGHBOURING floats into 64-bit writes instead: twelve v_mov per iteration).
@@ -1513,7 +1378,11 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
 {
     typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
     const unsigned lane = threadIdx.x;
-    __shared__ __attribute__((aligned(16))) double rows_lds[AZ_ROWS_TLDS + C_NUM_MAX + 2];
+    // (+ 8: the epoch angles az_sgp4_step re-reads when it re-seeds / rebuilds its carried pairs, laid out like one column of
+    // the element table -- from LDS, not from global memory: on an irregular grid that is EVERY step, and a vector load in
+    // this loop waits, through vmcnt, for every output store issued before it)
+    __shared__ __attribute__((aligned(16))) double rows_lds[AZ_ROWS_TLDS + C_NUM_MAX + 2 + 8];
+    static_assert(F_nodeo < 8 && F_argpo < 8 && F_mo < 8, "the epoch angles sit in the first eight rows of the element table");
     constexpr bool redo = REDO; // a separate instantiation: the item loop costs the whole-list form ~100 spilled SGPRs
     const unsigned n_items = redo ? *p.redo_count : 1u;
 #pragma unroll 1
@@ -1562,6 +1431,9 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
     e.sinio = az_uniform(e.sinio); e.cosio = az_uniform(e.cosio); e.k_mrt = az_uniform(e.k_mrt);
     e.k_c2u = az_uniform(e.k_c2u); e.k_su = az_uniform(e.k_su); e.k_node = az_uniform(e.k_node);
     e.k_inc = az_uniform(e.k_inc); e.x1mth2 = az_uniform(e.x1mth2); e.k_rv = az_uniform(e.k_rv);
+    double *seed_lds = rows_lds + AZ_ROWS_TLDS + C_NUM_MAX + 2;
+    if (lane < 8) seed_lds[lane] = p.el[(size_t)lane * p.n_pad + s];
+    az_wave_lds_fence();
     Sgp4Carry c;
     c.t_prev = 0.0;
     c.sW = c.sO = c.sA = 0.0;
@@ -1592,7 +1464,7 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
         r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
         (void)first;
 #else
-        az_sgp4_step<VEL, ColdT, true>(e, cold, p.el, p.n_pad, s, p.g, rk, t, first, c, r, v);
+        az_sgp4_step<VEL, ColdT, true>(e, cold, seed_lds, 1, 0, p.g, rk, t, first, c, r, v);
 #endif
         if (SINK == AZ_SINK_SCREEN) {
             // distances are frame-independent (ECEF is a rotation of TEME about z), so the screen

@@ -264,14 +264,13 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
         return e0.elapsed_time(e1) / steps
 
     def case(key, workload, kernel, dev, pairs, n_times, *, layout, vel=True, f32=False, mode=0, steps=50, warm=20,
-             cold=False, rows=16, ref_jd=0.0, arith32="mixed", stride_align=0, grid="uniform", gen_ts=0):
+             cold=False, rows=16, ref_jd=0.0, arith32="mixed", stride_align=0, grid="uniform"):
         if key in skip:
             return
         ent = {"key": key, "workload": workload, "kernel": kernel}
         try:
             n = dev.n
             dev.set_f32_arithmetic(arith32)
-            dev.set_tile_kernel(gen_ts or 16)   # (tile height of the generic tile kernel: 16, or 12 as an experiment)
             times = np.arange(n_times, dtype=np.float64)
             offs = (synth.START_JD - dev.epochs) * 1440.0
             if grid == "jdfr":
@@ -297,7 +296,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             pp, vp = pos.data_ptr(), (v.data_ptr() if vel else None)
             dev.propagate_device(times, offs, pp, vp, mode=mode, reference_jd=ref_jd, layout=layout, stride=(stride if layout == _native.TIME_MAJOR else 0), stream=sptr, f32=f32)
             torch.cuda.synchronize()
-            ent["path"] = dev.last_path()  # azh_last_path: 1 k_rows_fast, 2 k_tiles_fast, 4 k_rows, 8 k_propagate, 16 k_rows_deep, 32 quasi-uniform form, 64 k_tiles
+            ent["path"] = dev.last_path()  # azh_last_path: 1 k_rows_fast, 2 k_tiles_fast, 4 k_rows, 8 k_propagate, 16 k_rows_deep, 32 quasi-uniform form
             ms = timed(lambda: dev.propagate_device_cached(pp, vp, layout=layout, stride=(stride if layout == _native.TIME_MAJOR else 0), stream=sptr, f32=f32), warm, steps)
             props = n * n_times
             nbytes = props * (BYTES_OUT_PV if vel else BYTES_OUT_P) * (0.5 if f32 else 1.0) + n_times * 8 + n * ELEM_BYTES_PER_SAT
@@ -360,9 +359,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
     case("config2_sat_major_jdfr", "config 2, satellite-major, on the (jd, fr) grid of the reference's API call",
          "k_rows_fast<pos+vel,DELTA> + redo", dev2, pairs2, 1440, layout=SM, grid="jdfr")
     case("config2_time_major_irregular", "config 2, TIME-major, irregular grid (one-minute steps with +-20 s jitter)",
-         "k_tiles (generic step, 16-row tiles)", dev2, pairs2, 1440, layout=TM, grid="irregular", steps=20, warm=5)
-    case("config2_time_major_irregular_ts12", "config 2, TIME-major, irregular grid, 12-row tiles (experiment: 135 VGPRs, no scratch, 3 waves/SIMD)",
-         "k_tiles<TS=12>", dev2, pairs2, 1440, layout=TM, grid="irregular", steps=20, warm=5, gen_ts=12)
+         "k_propagate<time-major> (lane = satellite, generic step)", dev2, pairs2, 1440, layout=TM, grid="irregular", steps=20, warm=5)
     case("config2_sat_major_irregular", "config 2, satellite-major, irregular grid (one-minute steps with +-20 s jitter)",
          "k_rows (generic, lane = time)", dev2, pairs2, 1440, layout=SM, grid="irregular", steps=20, warm=5)
     case("config2_ecef_time_major", "config 2, ECEF time-major (the default of the reference's high-level propagate(), "

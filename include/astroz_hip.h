@@ -358,7 +358,6 @@ double azh_last_kernel_ms(azh_constellation *c);
 #define AZH_PATH_LANE_SAT 8u      /* k_propagate: lane = satellite (short grids; time-major with masks / fp32 / irregular grids) */
 #define AZH_PATH_DEEP_ROWS 16u    /* k_rows_deep: lane = time deep-space rows */
 #define AZH_PATH_QUASI_UNIFORM 32u /* the staged grid is quasi-uniform: the fast kernels ran in their DELTA form */
-#define AZH_PATH_TILES_GENERIC 64u /* k_tiles: lane = time, any grid / masks / fp32, 16-row time-major tiles */
 uint32_t azh_last_path(const azh_constellation *c);
 
 #ifdef __cplusplus

@@ -4,7 +4,7 @@
    L300-302, src/Constellation.zig L266-269), uniform only to ~4e-7 min after the rounding of jd + fr -- run the
    branch-free kernels (k_rows_fast / k_tiles_fast in their DELTA form), proven through azh_last_path, with parity against
    the oracle AT THE ROUNDED TIMES on every row of BASELINE configs 2 and 3, both layouts.
-2. Irregular grids, masks and fp32 outputs in the time-major layout run the generic tile kernel (k_tiles).
+2. The resonance node cache of the deep-space seeding is invisible in the results.
 """
 import os
 
@@ -89,7 +89,7 @@ def test_jdfr_grids_full_size_all_rows_take_the_fast_kernels(native, orc, synth,
     dev.synchronize()
     path = dev.last_path()
     assert path & native.PATH_TILES_FAST and path & native.PATH_QUASI_UNIFORM, path
-    assert not path & (native.PATH_LANE_SAT | native.PATH_TILES_GENERIC), path
+    assert not path & native.PATH_LANE_SAT, path
     dr = float(np.abs(ptm.cpu().numpy().transpose(1, 0, 2) - p0).max())
     dv = float(np.abs(vtm.cpu().numpy().transpose(1, 0, 2) - v0).max())
     assert dr < TOL_R and dv < TOL_V, (dr, dv)
@@ -219,77 +219,3 @@ def test_resonance_node_cache_is_invisible(native, orc, synth):
             e0, p0, v0 = cat.propagate(t, o, layout=olay)
             assert np.array_equal(res[0][2], e0)
             assert np.abs(res[0][0] - p0).max() < TOL_R and np.abs(res[0][1] - v0).max() < TOL_V, (j, layout)
-
-
-@pytest.mark.parametrize("ts", [16, 12])
-def test_generic_tile_kernel_irregular_grids_masks_frames(native, orc, synth, ts):
-    """k_tiles: time-major output on irregular grids and with satellite masks (what used to run the lane = satellite
-    kernel), mixed catalog (deep-space rows copied through, failed members zero), ragged sizes, padded strides, row
-    windows, ECEF / geodetic, positions only -- against the oracle, and azh_last_path names the kernel."""
-    import torch
-    pairs = synth.synth_catalog(n_near=1203, n_deep=131, seed=52)
-    # a member whose initialisation fails (perigee below the surface: 17.8 rev/day; checksums are not verified, Tle.zig)
-    for k in (7, 640):
-        l1, l2 = pairs[k]
-        pairs[k] = (l1, l2[:52] + "17.80000000" + l2[63:])
-    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
-    cat = orc.Catalog.from_pairs(pairs, 1)
-    dev.set_tile_kernel(ts)
-    rng = np.random.default_rng(ts)
-    n_times = 333
-    times = np.sort(np.arange(n_times, dtype=np.float64) * 2.0 + rng.uniform(-0.9, 0.9, n_times)) - 77.0
-    off = (synth.START_JD - dev.epochs) * 1440.0
-    stride = dev.n + 5
-    mask = (rng.uniform(size=dev.n) > 0.15).astype(np.uint8)
-    for m in (None, mask):
-        for mode, omode in ((native.OUT_TEME, orc.TEME), (native.OUT_ECEF, orc.ECEF), (native.OUT_GEODETIC, orc.GEODETIC)):
-            for vel in (True, False):
-                pos = torch.full((n_times, stride, 3), float("nan"), dtype=torch.float64, device="cuda")
-                v = torch.full_like(pos, float("nan")) if vel else None
-                err = torch.zeros((dev.n, n_times), dtype=torch.uint8, device="cuda")
-                torch.cuda.synchronize()
-                dev.propagate_device(times, off, pos.data_ptr(), v.data_ptr() if vel else None, mode=mode, reference_jd=synth.START_JD,
-                                     mask=m, layout=native.TIME_MAJOR, stride=stride, d_err=err.data_ptr())
-                dev.synchronize()
-                path = dev.last_path()
-                assert path & native.PATH_TILES_GENERIC and not path & (native.PATH_LANE_SAT | native.PATH_TILES_FAST), path
-                e0, p0, v0 = cat.propagate(times, off, layout=orc.TIME_MAJOR, velocities=vel, mode=omode, reference_jd=synth.START_JD)
-                got = pos.cpu().numpy()
-                keep = np.ones(dev.n, bool) if m is None else m.astype(bool)
-                assert np.isnan(got[:, dev.n:]).all()                      # the padding columns are never written
-                assert np.isnan(got[:, :dev.n][:, ~keep]).all()            # masked members are left untouched
-                # members whose initialisation failed (the reference refuses such a catalog, shared.zig L78-82; the oracle does
-                # not propagate them): zero rows, the init error at every time
-                failed = cat.init_rc != 0
-                assert failed.sum() == 2
-                assert (got[:, :dev.n][:, keep & failed] == 0.0).all()
-                assert (err.cpu().numpy()[keep & failed] == 6).all()
-                keep = keep & ~failed
-                dq = np.abs(got[:, :dev.n][:, keep] - p0[:, keep])
-                if mode == native.OUT_GEODETIC:
-                    dq[..., 1] = np.minimum(dq[..., 1], 2 * np.pi - dq[..., 1])
-                assert dq.max() < TOL_R, (m is None, mode, vel, dq.max())
-                if vel:
-                    assert np.abs(v.cpu().numpy()[:, :dev.n][:, keep] - v0[:, keep]).max() < TOL_V
-                assert np.array_equal(err.cpu().numpy()[keep], e0[keep])
-    # row windows that cut through tiles == one full launch
-    full = torch.full((n_times, dev.n, 3), float("nan"), dtype=torch.float64, device="cuda")
-    part = torch.full_like(full, float("nan"))
-    torch.cuda.synchronize()
-    dev.propagate_device(times, off, full.data_ptr(), None, layout=native.TIME_MAJOR)
-    for lo, hi in ((0, 5), (5, 100), (100, dev.n // 2 + 3), (dev.n // 2 + 3, 10**6)):
-        dev.propagate_device_window(lo, hi, part.data_ptr(), None, layout=native.TIME_MAJOR)
-    dev.synchronize()
-    assert torch.equal(full, part)
-    # a uniform grid with a mask also takes the generic tiles; without the mask the branch-free ones -- same answers
-    tu = np.arange(0.0, 256.0)
-    a = torch.full((256, dev.n, 3), float("nan"), dtype=torch.float64, device="cuda")
-    b = torch.full_like(a, float("nan"))
-    torch.cuda.synchronize()
-    dev.propagate_device(tu, off, a.data_ptr(), None, layout=native.TIME_MAJOR)
-    dev.synchronize()
-    assert dev.last_path() & native.PATH_TILES_FAST
-    dev.propagate_device(tu, off, b.data_ptr(), None, layout=native.TIME_MAJOR, mask=np.ones(dev.n, np.uint8))
-    dev.synchronize()
-    assert dev.last_path() & native.PATH_TILES_GENERIC
-    assert float((a - b).abs().max()) < 2e-7

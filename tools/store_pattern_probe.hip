@@ -60,6 +60,16 @@ int main()
         {"time-major: 90 tiles of 16 steps", 211, 90, 16, 1536, 4, 1536, row, false},
         // what a 16-satellite x 64-time transposed tile would write: 384-B runs, one per time row
         {"time-major: 842 groups of 16 sats (384-B runs), 23 tiles", 842, 23, 64, 384, 4, 384, row, false},
+        // tile flushes of other heights: 32 satellites (768-B runs), 8 (192-B), 12 (288-B); 16 with rows padded to whole lines
+        {"time-major: 421 groups of 32 sats (768-B runs), 23 tiles", 421, 23, 64, 768, 4, 768, row, false},
+        {"time-major: 421 groups of 32 sats (768-B runs), nt", 421, 23, 64, 768, 4, 768, row, true},
+        {"time-major: 1685 groups of 8 sats (192-B runs)", 1685, 23, 64, 192, 4, 192, row, false},
+        {"time-major: 1123 groups of 12 sats (288-B runs)", 1123, 23, 64, 288, 4, 288, row, false},
+        {"time-major: 16 sats, rows padded to 128 B, plain", 843, 23, 64, 384, 4, 384, (row + 127) / 128 * 128, false},
+        {"time-major: 16 sats, rows padded to 128 B, nt", 843, 23, 64, 384, 4, 384, (row + 127) / 128 * 128, true},
+        {"time-major: 16 sats (384-B runs), nt", 842, 23, 64, 384, 4, 384, row, true},
+        {"time-major: 16 sats (384-B runs), 16 waves per workgroup", 842, 23, 64, 384, 16, 384, row, false},
+        {"time-major: 32 sats, rows padded to 128 B, nt", 421, 23, 64, 768, 4, 768, (row + 127) / 128 * 128, true},
         // a 1024-lane workgroup of 16 lane = satellite waves: same bursts, 24 KB of a row per workgroup
         {"time-major: pitch = row, 16 waves per workgroup", 211, 23, 64, 1536, 16, 1536, row, false},
     };
