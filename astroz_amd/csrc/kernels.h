@@ -1132,7 +1132,11 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
     for (unsigned m = 0; m < 3; ++m) {
         const unsigned q = 1024u * m + threadIdx.x, arr = q / 1536u, pq = q - arr * 1536u, row = pq / 24u, col = pq - row * 24u;
         f_lds[m] = arr < NA ? (arr * (64u * AZ_TILE_PITCH) + row * AZ_TILE_PITCH + col * 2u) * 8u : 0xffffffffu;
+#if defined(AZ_TILE_ABLATE) && AZ_TILE_ABLATE == 5
+        f_out[m] = (unsigned)(((size_t)row * p.stride_sats + (s_first & 511u)) * 24u + col * 16u);
+#else
         f_out[m] = (unsigned)(((size_t)row * p.stride_sats + s_first) * 24u + col * 16u);
+#endif
         f_row |= (row | (arr << 7)) << (8u * m);
     }
     // time rows that start on a 128-byte boundary (a padded out_stride_sats: 16 satellites = 384 bytes): every 384-byte run
@@ -1190,7 +1194,11 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
             }
         }
         __syncthreads();
+#if defined(AZ_TILE_ABLATE) && AZ_TILE_ABLATE == 5 /* tuning experiment: every flush lands in the same 64 time rows (L2-resident) */
+        const size_t gbase = 0;
+#else
         const size_t gbase = (size_t)base * p.stride_sats * 3; // uniform
+#endif
         const bool full = base + 64 <= t_hi;
         if (contig) {
             const char *bufc = reinterpret_cast<const char *>(buf);
