@@ -210,26 +210,31 @@ class SatrecArray:
         v = v_tm.transpose(1, 0, 2) if velocities else np.zeros((n_sats, n_times, 3), dtype=np.float64)
         return e, r, v
 
-    def sgp4_device(self, jd, fr, *, velocities=True, stream=None):
+    def sgp4_device(self, jd, fr, *, velocities=True, stream=None, padded=False):
         """Same computation, results left resident in HBM: returns torch tensors on the GPU
-        (e (n_sats,n_times) uint8, r_tm, v_tm (n_times, n_sats, 3) float64: views of arrays whose time rows are padded to
-        16 satellites).  Asynchronous with
-        respect to the host; ordered on the constellation's stream (or `stream`)."""
+        (e (n_sats, n_times) uint8, r_tm, v_tm (n_times, n_sats, 3) float64, dense and contiguous).  Asynchronous with respect
+        to the host; ordered on the constellation's stream (or `stream`).
+
+        padded=True: the time rows of the underlying arrays are padded to a multiple of 16 satellites (384 bytes = three whole
+        128-byte lines: every run of the time-major tile kernel then starts on a line boundary and leaves as streaming stores,
+        about 8 % faster); r_tm / v_tm are then NON-contiguous (n_times, n_sats, 3) views of
+        (n_times, stride, 3) arrays whose padding columns are zero -- do not hand their data_ptr() to code that assumes a
+        dense layout."""
         import torch
 
         times, offsets = self._grid(jd, fr)
         n_times, n_sats = len(times), self._num_sats
         dev = torch.device("cuda", self._device)  # the device the element table lives on
-        # time rows padded to a multiple of 16 satellites (384 bytes = three whole 128-byte lines): every run of the
-        # time-major tile kernel then starts on a line boundary and leaves as streaming stores (DESIGN.md 4, k_tiles_fast:
-        # 0.27 instead of 0.29 ms for config 2); the caller sees (n_times, n_sats, 3) views of the padded arrays
-        stride = (n_sats + 15) // 16 * 16
-        r_tm = torch.empty((n_times, stride, 3), dtype=torch.float64, device=dev)
-        v_tm = torch.empty((n_times, stride, 3), dtype=torch.float64, device=dev) if velocities else None
+        stride = (n_sats + 15) // 16 * 16 if padded else n_sats
+        alloc = torch.zeros if stride != n_sats else torch.empty
+        r_tm = alloc((n_times, stride, 3), dtype=torch.float64, device=dev)
+        v_tm = alloc((n_times, stride, 3), dtype=torch.float64, device=dev) if velocities else None
         e = torch.empty((n_sats, n_times), dtype=torch.uint8, device=dev)
         torch.cuda.current_stream(dev).synchronize()  # allocations visible before a foreign stream writes
         self._dev.propagate_device(times, offsets, r_tm.data_ptr(), None if v_tm is None else v_tm.data_ptr(),
                                    layout=_native.TIME_MAJOR, stride=stride, d_err=e.data_ptr(), stream=stream)
+        if stride == n_sats:
+            return e, r_tm, v_tm
         return e, r_tm[:, :n_sats], (None if v_tm is None else v_tm[:, :n_sats])
 
     def synchronize(self):

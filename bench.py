@@ -351,7 +351,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
     case("config2_time_major", "config 2, TIME-major output (the reference benchmark's physical layout, api.py L304-314), fp64 TEME pos+vel",
          "k_tiles_fast<pos+vel> + redo", dev2, pairs2, 1440, layout=TM)
     case("config2_time_major_aligned", "config 2, TIME-major output with the time rows padded to a multiple of 16 satellites (out_stride_sats = "
-         "13,488: every 384-byte tile run on whole cache lines; what SatrecArray.sgp4_device allocates), fp64 TEME pos+vel",
+         "13,488: every 384-byte tile run on whole cache lines; what SatrecArray.sgp4_device(padded=True) allocates), fp64 TEME pos+vel",
          "k_tiles_fast<pos+vel> (streaming flush) + redo", dev2, pairs2, 1440, layout=TM, stride_align=16)
     case("config2_time_major_jdfr", "config 2, TIME-major, on the grid the reference's own API call produces: SatrecArray.sgp4(jd, fr), "
          "times = ((jd + fr) - reference_jd) * 1440 (quasi-uniform: first-order correction of every point to its rounded time)",

@@ -163,6 +163,12 @@ def test_satrec_array_jdfr_runs_the_tile_kernel(native, orc, synth):
     assert path & native.PATH_TILES_FAST and path & native.PATH_QUASI_UNIFORM, path
     assert np.abs(r_tm.cpu().numpy().transpose(1, 0, 2) - p0).max() < TOL_R
     assert np.abs(v_tm.cpu().numpy().transpose(1, 0, 2) - v0).max() < TOL_V
+    assert r_tm.is_contiguous() and v_tm.is_contiguous() and tuple(r_tm.shape) == (n, 1000, 3)   # dense by default
+    e, r_pad, v_pad = arr.sgp4_device(jd, fr, padded=True)    # opt-in: time rows padded to 16 satellites, zero padding
+    arr.synchronize()
+    assert not r_pad.is_contiguous() and r_pad.stride(0) == 1008 * 3
+    assert bool((r_pad == r_tm).all()) and bool((v_pad == v_tm).all())
+    assert float(r_pad._base[:, 1000:].abs().max()) == 0.0 if r_pad._base is not None else True
 
 
 def test_jdfr_grid_fp32_and_screen(native, orc, synth):
