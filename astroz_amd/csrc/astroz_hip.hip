@@ -155,6 +155,11 @@ struct azh_constellation {
     DevBuf<float> d_delta;
     double delta_max = 0.0;
     std::vector<float> h_delta; // (source of the asynchronous upload)
+    // ... or, WIDE form (jitter of seconds about a uniform grid, |delta| <= AZ_DELTA_WIDE_MAX): fp64 deviations from a fitted grid
+    DevBuf<double> d_delta64;
+    std::vector<double> h_delta64;
+    bool delta_wide = false;
+    double grid_t0 = 0.0;       // origin of the ideal grid (times[0] unless the grid is a fit)
     unsigned last_path = 0;     // AZH_PATH_* bits of the most recent launch set (azh_last_path)
     DevBuf<double> d_tgt, d_part_d2, d_out_d; // fused screen: target track, partial minima, results
     DevBuf<unsigned> d_part_t, d_out_t;
@@ -213,6 +218,7 @@ void destroy(azh_constellation *c)
     c->d_inc.release();
     c->d_fast_rec.release();
     c->d_delta.release();
+    c->d_delta64.release();
     for (auto &pl : c->plan) { pl.win.release(); pl.flag.release(); pl.redo.release(); }
     c->d_tgt.release();
     c->d_part_d2.release();
@@ -510,11 +516,11 @@ FastShape fast_shape_rows(const PropArgs &a, unsigned n_sgp4, unsigned n_circ)
         f.tile_c = std::min(f.tile_c, (unsigned)AZ_FRAME_SEG);
         f.tile_e = std::min(f.tile_e, (unsigned)AZ_FRAME_SEG);
     }
-    if (a.delta) { // quasi-uniform grid: a wave stages its segment's deviations in LDS
+    if (a.delta || a.delta64) { // quasi-uniform grid: a wave stages its segment's deviations in LDS
         f.tile_c = std::min(f.tile_c, (unsigned)AZ_DELTA_SEG);
         f.tile_e = std::min(f.tile_e, (unsigned)AZ_DELTA_SEG);
     }
-    f.packed32 = a.f32 && a.mode == AZ_OUT_TEME && a.arith32 != 2 && cap >= 128u;
+    f.packed32 = a.f32 && a.mode == AZ_OUT_TEME && a.arith32 != 2 && cap >= 128u && a.delta64 == nullptr; // (the wide form: fp64 kernels)
     f.mixed32 = f.packed32 && a.arith32 == 0;
     if (f.packed32) f.tile_c = std::max(128u, f.tile_c / 128u * 128u);
     f.kind = f.packed32 ? 1 : 0;
@@ -525,7 +531,7 @@ FastShape fast_shape_tiles(const PropArgs &a, unsigned n_rows)
     FastShape f;
     unsigned tile = std::min(rows_tile(std::max((n_rows + 15u) / 16u, 1u) * 16u, a.n_times, a.tile_forced), fast_window_cap(a.uniform_step));
     if (a.mode != AZ_OUT_TEME) tile = std::min(tile, (unsigned)AZ_TILE_SEG_MAX); // the Greenwich-angle table of a time segment is staged in LDS
-    if (a.delta) tile = std::min(tile, (unsigned)AZ_DELTA_SEG);  // ... and the deviations of a quasi-uniform grid
+    if (a.delta || a.delta64) tile = std::min(tile, (unsigned)AZ_DELTA_SEG); // ... and the deviations of a quasi-uniform grid
     f.tile_c = f.tile_e = tile;
     f.kind = 2;
     return f;
@@ -535,8 +541,9 @@ FastShape fast_shape_tiles(const PropArgs &a, unsigned n_rows)
 template <bool VEL, int FRAME, int SINK, bool ECC>
 void launch_rows_fast(const PropArgs &a, dim3 grid, hipStream_t st)
 {
-    if (a.delta) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, SINK, ECC, true>), grid, dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, SINK, ECC, false>), grid, dim3(64), 0, st, a);
+    if (a.delta64) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, SINK, ECC, 2>), grid, dim3(64), 0, st, a);
+    else if (a.delta) hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, SINK, ECC, 1>), grid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_rows_fast<VEL, FRAME, SINK, ECC, 0>), grid, dim3(64), 0, st, a);
 }
 template <bool VEL, bool MIXED>
 void launch_rows_fast32(const PropArgs &a, dim3 grid, hipStream_t st)
@@ -547,8 +554,9 @@ void launch_rows_fast32(const PropArgs &a, dim3 grid, hipStream_t st)
 template <bool VEL, int FRAME>
 void launch_tiles_fast(const PropArgs &a, dim3 grid, hipStream_t st)
 {
-    if (a.delta) hipLaunchKernelGGL((k_tiles_fast<VEL, FRAME, true>), grid, dim3(1024), 0, st, a);
-    else hipLaunchKernelGGL((k_tiles_fast<VEL, FRAME, false>), grid, dim3(1024), 0, st, a);
+    if (a.delta64) hipLaunchKernelGGL((k_tiles_fast<VEL, FRAME, 2>), grid, dim3(1024), 0, st, a);
+    else if (a.delta) hipLaunchKernelGGL((k_tiles_fast<VEL, FRAME, 1>), grid, dim3(1024), 0, st, a);
+    else hipLaunchKernelGGL((k_tiles_fast<VEL, FRAME, 0>), grid, dim3(1024), 0, st, a);
 }
 
 template <bool VEL, int FRAME> // FRAME: 0 TEME, 1 ECEF, 2 geodetic (the generic kernels take frame / no frame and p.mode)
@@ -709,12 +717,14 @@ int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, 
     // (fast_step.h) then advances its carried angles by per-satellite constant rotations
     c->uniform_step = 0.0;
     c->delta_max = 0.0;
+    c->delta_wide = false;
+    c->grid_t0 = n_times ? times[0] : 0.0;
     if (n_times >= 2) {
         // ... or QUASI-uniform: within AZ_DELTA_MAX minutes of such a grid.  That is what the reference's own API hands over,
         // times = ((jd + fr) - reference_jd) * 1440 (api.py L300-302, Constellation.zig L266-269): jd + fr at 2.46e6 days is
         // quantised to 2^-31 day = 6.7e-7 min.  The fast kernels then run along the ideal grid and correct every point to its
-        // actual time to first order in the deviation (fast_step.h, DELTA).
-        const double t0 = times[0], step = (times[n_times - 1] - t0) / (double)(n_times - 1);
+        // actual time to first order in the deviation (fast_step.h, DELTA = 1).
+        double t0 = times[0], step = (times[n_times - 1] - t0) / (double)(n_times - 1);
         double tmax = std::max(std::fabs(t0), std::fabs(times[n_times - 1]));
         const double tol = 4.0 * 2.220446049250313e-16 * std::max(tmax, std::fabs(step));
         bool uni = std::isfinite(step) && step != 0.0;
@@ -731,6 +741,38 @@ int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, 
             // (pageable source, like `times` itself: the runtime has read it when the call returns)
             HIP_TRY(hipMemcpyAsync(c->d_delta.p, c->h_delta.data(), sizeof(float) * c->h_delta.size(), hipMemcpyHostToDevice, st));
             c->delta_max = dmax * (1.0 + 1e-6) + 1e-12;
+        }
+        if (!uni && n_times >= 64) {
+            // ... or uniform up to a JITTER of seconds (time stamps of a periodic process): least-squares line through the
+            // points, deviations up to AZ_DELTA_WIDE_MAX minutes, staged as fp64 (fast_step.h, DELTA = 2)
+            const double nn = (double)n_times, im = 0.5 * (nn - 1.0);
+            double tm = 0.0;
+            for (size_t i = 0; i < n_times; ++i) tm += times[i];
+            tm /= nn;
+            double sxy = 0.0, sxx = 0.0;
+            for (size_t i = 0; i < n_times; ++i) {
+                sxy += ((double)i - im) * (times[i] - tm);
+                sxx += ((double)i - im) * ((double)i - im);
+            }
+            step = sxy / sxx;
+            t0 = tm - step * im;
+            bool ok = std::isfinite(step) && std::isfinite(t0) && step != 0.0;
+            dmax = 0.0;
+            for (size_t i = 0; ok && i < n_times; ++i) {
+                dmax = std::max(dmax, std::fabs(times[i] - std::fma((double)i, step, t0)));
+                ok = dmax <= AZ_DELTA_WIDE_MAX;
+            }
+            // (a jitter as large as the step itself is not "a uniform grid with jitter": such grids stay with the generic kernels)
+            if (ok && dmax <= 0.5 * std::fabs(step)) {
+                c->h_delta64.assign(n_times + AZ_DELTA_SEG, 0.0);
+                for (size_t i = 0; i < n_times; ++i) c->h_delta64[i] = times[i] - std::fma((double)i, step, t0);
+                if (c->d_delta64.ensure(c->h_delta64.size()) != AZ_OK) return AZ_ERR_HIP;
+                HIP_TRY(hipMemcpyAsync(c->d_delta64.p, c->h_delta64.data(), sizeof(double) * c->h_delta64.size(), hipMemcpyHostToDevice, st));
+                c->delta_max = dmax * (1.0 + 1e-6) + 1e-12;
+                c->delta_wide = true;
+                c->grid_t0 = t0;
+                uni = true;
+            }
         }
         if (uni) {
             if (c->d_inc.ensure((size_t)2 * AZ_INC_NUM * c->n_pad) != AZ_OK) return AZ_ERR_HIP;
@@ -799,7 +841,8 @@ int32_t ensure_plan(azh_constellation *c, PropArgs &a, const FastShape &shape, h
         q.el = a.el; q.flags = a.flags; q.n_pad = a.n_pad; q.list = a.list; q.n_list = n_list; q.n_circ = a.n_circ;
         q.n_times = a.n_times; q.tile_c = shape.tile_c; q.tile_e = shape.tile_e; q.by_flags = shape.kind == 2 ? 1u : 0u;
         q.times = a.times; q.offsets = a.offsets; q.inc = a.inc; q.step = a.uniform_step; q.dt_mult = shape.kind == 1 ? 128.0 : 64.0;
-        q.delta_max = a.delta ? a.delta_max : 0.0;
+        q.delta_max = (a.delta || a.delta64) ? a.delta_max : 0.0;
+        q.grid_t0 = a.grid_t0;
         q.f32_mixed = shape.mixed32 ? 1u : 0u;
         q.win = pl.win.p; q.flag = pl.flag.p;
         q.redo_static = pl.redo.p + 2; q.redo_c0 = pl.redo.p; q.redo_c1 = pl.redo.p + 1; q.redo_items = pl.redo.p + 4;
@@ -853,8 +896,11 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     a.uniform_step = c->fast_path ? c->uniform_step : 0.0;
     a.inc = (a.uniform_step != 0.0) ? c->d_inc.p : nullptr;
     a.fast_rec = (a.uniform_step != 0.0) ? c->d_fast_rec.p : nullptr;
-    a.delta = (a.uniform_step != 0.0 && c->delta_max > 0.0) ? c->d_delta.p : nullptr;
+    a.delta = (a.uniform_step != 0.0 && c->delta_max > 0.0 && !c->delta_wide) ? c->d_delta.p : nullptr;
+    a.delta64 = (a.uniform_step != 0.0 && c->delta_max > 0.0 && c->delta_wide) ? c->d_delta64.p : nullptr;
+    a.grid_t0 = c->grid_t0;
     a.delta_max = c->delta_max;
+    a.grid_exact_uniform = (c->uniform_step != 0.0 && c->delta_max == 0.0) ? 1 : 0;
     a.row_lo = (unsigned)row_lo;
     a.row_hi = (unsigned)row_hi;
 
@@ -934,7 +980,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         } else if (a.n_list > 0) {
             path |= launch_propagate(a, layout, d_vel != nullptr, false, st, EccSide{c->s_ecc, c->ev_fork2, c->ev_join2}, fast ? &shape : nullptr);
         }
-        if (a.delta && (path & (AZH_PATH_TILES_FAST | AZH_PATH_ROWS_FAST))) path |= AZH_PATH_QUASI_UNIFORM;
+        if ((a.delta || a.delta64) && (path & (AZH_PATH_TILES_FAST | AZH_PATH_ROWS_FAST))) path |= AZH_PATH_QUASI_UNIFORM;
         HIP_TRY(hipGetLastError());
     }
     if (c->n_bad > 0) {
@@ -1476,8 +1522,11 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
         a.uniform_step = c->fast_path ? c->uniform_step : 0.0;
         a.inc = (a.uniform_step != 0.0) ? c->d_inc.p : nullptr;
         a.fast_rec = (a.uniform_step != 0.0) ? c->d_fast_rec.p : nullptr;
-        a.delta = (a.uniform_step != 0.0 && c->delta_max > 0.0) ? c->d_delta.p : nullptr;
+        a.delta = (a.uniform_step != 0.0 && c->delta_max > 0.0 && !c->delta_wide) ? c->d_delta.p : nullptr;
+        a.delta64 = (a.uniform_step != 0.0 && c->delta_max > 0.0 && c->delta_wide) ? c->d_delta64.p : nullptr;
+        a.grid_t0 = c->grid_t0;
         a.delta_max = c->delta_max;
+        a.grid_exact_uniform = (c->uniform_step != 0.0 && c->delta_max == 0.0) ? 1 : 0;
         a.row_lo = 0;
         a.row_hi = 0xffffffffu;
         a.screen_target = c->d_tgt.p;
@@ -1537,7 +1586,7 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
                     HIP_TRY(hipEventRecord(c->ev_join2, se));
                     HIP_TRY(hipStreamWaitEvent(st, c->ev_join2, 0));
                 }
-                c->last_path = AZH_PATH_ROWS_FAST | (near.delta ? AZH_PATH_QUASI_UNIFORM : 0u);
+                c->last_path = AZH_PATH_ROWS_FAST | ((near.delta || near.delta64) ? AZH_PATH_QUASI_UNIFORM : 0u);
             } else {
                 c->last_path = launch_propagate(near, AZ_LAYOUT_SAT_MAJOR, false, false, st);
             }

@@ -49,7 +49,13 @@ enum FastColdX {
 #undef X
     FCX_NUM
 };
-#define AZ_DELTA_MAX 4.0e-6 /* minutes: largest deviation from the ideal grid the fast kernels take */
+#define AZ_DELTA_MAX 4.0e-6 /* minutes: largest deviation from the ideal grid of the TIGHT form (DELTA = 1: fp32 deviations) */
+// DELTA = 2, the WIDE form: grids that are uniform up to a jitter of seconds (time stamps of a periodic process): |delta_i| <=
+// AZ_DELTA_WIDE_MAX.  The deviations are staged as fp64 (a 0.3-min value in fp32 is off by 2e-8 min = 1e-9 rad of mean anomaly);
+// U is corrected exactly as before (it is linear in t apart from the drag terms, which see the actual t); the M pair by a
+// second-order rotation in the near-circular form and by the 1/16-rad polynomial in the eccentric form; the W pair to first
+// order (argpdot delta < 3e-5).
+#define AZ_DELTA_WIDE_MAX 0.5
 #define AZ_DELTA_SEG 768    /* grid points per time segment whose deviations a wave / tile stages in LDS (fp32) */
 // everything in registers (lane = satellite kernels, host emulation)
 struct FastK {
@@ -443,9 +449,9 @@ AZ_DEVICE bool az_fast_window_ok(const FastK &k, const AzGrav &g, double t_a, do
 // one near-earth propagation on a uniform grid, inside a window az_fast_window_ok accepted.  Returns true when
 // the eccentric form's Newton iteration left its assumptions for this lane (ECC = true only; the caller must then
 // discard r/v and use az_sgp4_step); the near-circular form always returns false.
-// DELTA: the grid is quasi-uniform; t is the ACTUAL time of this point and dl = t - (its place on the ideal grid the carried
-// pairs advance along), |dl| <= AZ_DELTA_MAX.
-template <bool VEL, bool ECC = false, bool DELTA = false, class K = FastK, class RC = RotCoefLit>
+// DELTA (0 none, 1 tight, 2 wide): the grid is quasi-uniform; t is the ACTUAL time of this point and dl = t - (its place on the
+// ideal grid the carried pairs advance along), |dl| <= AZ_DELTA_MAX (tight) / AZ_DELTA_WIDE_MAX (wide).
+template <bool VEL, bool ECC = false, int DELTA = 0, class K = FastK, class RC = RotCoefLit>
 AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, double t, FastCarry &st, double r[3],
                                   double v[3], double dl = 0.0)
 {
@@ -454,13 +460,25 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, doub
     az_pair_advance<K::SCALAR>(st.sW, st.cW, k.sdW(), k.cdW());
     az_pair_advance<K::SCALAR>(st.sU, st.cU, k.sdU(), k.cdU());
     double sA = st.sA, cA = st.cA, sW = st.sW, cW = st.cW;
-    if constexpr (DELTA && ECC) {
-        // M and W at the actual time, first order in dl.  (The near-circular form does without: both pairs only enter
-        // scaled by em < 0.004 -- argpdot dl em < 1e-12 rad -- and through th, whose product with em is bounded by the drag
-        // coefficients alone: d(th) em < 1e-13.)
+    if constexpr ((DELTA == 1 && ECC) || DELTA == 2) {
+        // M and W at the actual time.  Tight form: first order in dl, eccentric members only (the near-circular form does
+        // without: both pairs only enter scaled by em < 0.004 -- argpdot dl em < 1e-12 rad -- and through th, whose product
+        // with em is bounded by the drag coefficients alone: d(th) em < 1e-13).  Wide form: every member; M of an eccentric
+        // member by the 1/16-rad polynomial (|mdot dl| <= 0.0375).
         const double a = k.mdot() * dl, b = k.argpdot() * dl;
-        sA = fma(st.cA, a, st.sA); cA = fma(-st.sA, a, st.cA);
-        sW = fma(st.cW, b, st.sW); cW = fma(-st.sW, b, st.cW);
+        if constexpr (DELTA == 2 && ECC) {
+            double pa, qa;
+            az_pq_16th(a, rk, pa, qa);
+            az_rot_apply2(sA, cA, pa, qa);
+        } else if constexpr (DELTA == 2) {
+            // second order: cos M feeds th = delomg + delm, which turns the eccentricity vector -- for a low, high-drag member
+            // th reaches 1e-2 rad, and a^2 / 2 = 7e-4 of it times em is a micrometre-per-second error; a^4 / 24 is not
+            az_rotate_tiny2(sA, cA, a, rk);
+        } else {
+            sA = fma(st.cA, a, st.sA); cA = fma(-st.sA, a, st.cA);
+        }
+        if constexpr (DELTA == 2 && ECC) az_rotate_tiny2(sW, cW, b, rk); // (b^2 / 2 = 5e-10 times em = 0.25 would be decimetres)
+        else { sW = fma(st.cW, b, st.sW); cW = fma(-st.sW, b, st.cW); }
     }
     const double t2 = t * t;
 

@@ -81,10 +81,15 @@ struct PropArgs {
     // uniform grids: times[i] = times[0] + i * uniform_step (0 = not uniform), and the per-satellite
     // rotation increments k_prep_inc prepared for it (fast_step.h); null = generic path only
     double uniform_step;
+    int grid_exact_uniform; // the staged grid is exactly uniform (whether or not the fast path is switched on): k_rows caches a lane's increments
     // quasi-uniform grid (what jd + fr arithmetic produces): times[i] = times[0] + i uniform_step + delta[i], |delta| <= delta_max
     // (fast_step.h, DELTA); null = exactly uniform
     const float *delta;
     double delta_max;
+    // ... or the WIDE form (jitter of seconds, |delta| <= AZ_DELTA_WIDE_MAX): deviations as fp64; the ideal grid is a fit, its
+    // origin grid_t0 (= times[0] on exact and tight grids) replaces times[0] in the fast kernels and the plan
+    const double *delta64;
+    double grid_t0;
     const double *inc;
     const double *fast_rec; // [n_pad][FR_NUM]: per-satellite record of the lane = time fast kernels (k_prep_rec, fast_step.h)
     // row window: only satellites with row_lo <= table index < row_hi are produced by this launch (chunked
@@ -414,7 +419,7 @@ __global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (
 #if AZ_PROP_FAST
     // Optimistic straight-line loop (fast_step.h): uniform grid, all 64 orbits near-circular, every small
     // angle inside its usual tier; one vote per step, the generic loop takes over on a violation.
-    if (!DEEP && p.inc != nullptr && p.uniform_step != 0.0 && p.delta == nullptr && !az_any(AZ_FLAG_ECLASS(fl) != 0)) {
+    if (!DEEP && p.inc != nullptr && p.uniform_step != 0.0 && p.delta == nullptr && p.delta64 == nullptr && !az_any(AZ_FLAG_ECLASS(fl) != 0)) {
         FastKCol k;
         bool window_ok;
         {
@@ -630,7 +635,7 @@ struct PlanArgs {
     unsigned n_list, n_circ, n_times, tile_c, tile_e, by_flags;
     unsigned f32_mixed; // near-circular slots go to the mixed-precision fp32 step: its extra bound (az_fast32p_window_ok)
     const double *times, *offsets, *inc;
-    double step, dt_mult, delta_max;
+    double step, dt_mult, delta_max, grid_t0;
     double *win;
     unsigned char *flag;
     unsigned *redo_static, *redo_c0, *redo_c1, *redo_items;
@@ -648,7 +653,7 @@ __global__ void __launch_bounds__(256) k_plan_windows(PlanArgs a)
     const unsigned t_lo = seg * tile;
     if (t_lo >= a.n_times) return;
     const unsigned t_hi = min(t_lo + tile, a.n_times);
-    const double t_first = a.times[0] + (a.offsets ? a.offsets[s] : 0.0);
+    const double t_first = a.grid_t0 + (a.offsets ? a.offsets[s] : 0.0);
     const double w_a = fma((double)t_lo, a.step, t_first), w_b = fma((double)(t_hi - 1), a.step, t_first);
     FastK k0, k1;
     az_load_fast(a.el, a.n_pad, s, fl, a.inc, 0, k0);
@@ -915,8 +920,8 @@ __device__ __forceinline__ void az_rows_store(bool staged, bool full, bool live,
 #define AZ_FRAME_SEG 256
 // DELTA: quasi-uniform grid (fast_step.h): the segment's deviations delta_i, staged in LDS as fp32 before the loop (|delta| <=
 // 4e-6 min: an fp32 delta is good to 2.4e-13 min, the rounding of t itself), ride on the time value and on the small rotation of U.
-template <bool VEL, int FRAME, int SINK, bool ECC, bool DELTA = false>
-__global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES : (FRAME == 1 ? 5 : AZ_ROWSF_WAVES))) k_rows_fast(PropArgs p)
+template <bool VEL, int FRAME, int SINK, bool ECC, int DELTA = 0> // DELTA: 0 exact grid, 1 tight (fp32 deviations), 2 wide (fp64)
+__global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES : (FRAME == 1 || DELTA == 2 ? 5 : AZ_ROWSF_WAVES))) k_rows_fast(PropArgs p)
 {
     typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
     const unsigned lane = threadIdx.x;
@@ -944,7 +949,7 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
                             (((reinterpret_cast<size_t>(prow) | (VEL ? reinterpret_cast<size_t>(vrow) : 0)) & 15u) == 0);
         FastKBcast k;
         {
-            const double w_a = fma((double)t_lo, p.uniform_step, p.times[0] + off), w_b = fma((double)(t_hi - 1), p.uniform_step, p.times[0] + off);
+            const double w_a = fma((double)t_lo, p.uniform_step, p.grid_t0 + off), w_b = fma((double)(t_hi - 1), p.uniform_step, p.grid_t0 + off);
             // window constants and the verdict of the validation bounds: prepared once per staged grid (k_plan_windows); a
             // rejected window is already on the redo list
             window_ok = az_plan_window(p, blockIdx.y, row + p.redo_slot0, w_a, w_b, k);
@@ -953,14 +958,16 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
             az_wave_lds_fence();
             if (DELTA && k.tc_ != 0.0 && lane == 0) cold_lds[FCX_udot] = fma(2.0 * rec[FC_nl2], k.tc_, rec[FCX_udot]); // rate of U about tc
         }
-        __shared__ float dl_lds[DELTA ? AZ_DELTA_SEG : 1]; // (the host keeps DELTA segments at AZ_DELTA_SEG points)
+        typedef typename std::conditional<DELTA == 2, double, float>::type dl_t;
+        __shared__ dl_t dl_lds[DELTA ? AZ_DELTA_SEG : 1]; // (the host keeps DELTA segments at AZ_DELTA_SEG points)
         if (DELTA) {
+            const dl_t *src = DELTA == 2 ? reinterpret_cast<const dl_t *>(p.delta64) : reinterpret_cast<const dl_t *>(p.delta);
 #pragma unroll
-            for (unsigned j = lane; j < AZ_DELTA_SEG; j += 64) dl_lds[j] = p.delta[t_lo + j]; // (the table is zero-padded by one segment)
+            for (unsigned j = lane; j < AZ_DELTA_SEG; j += 64) dl_lds[j] = src[t_lo + j]; // (the table is zero-padded by one segment)
         }
         az_wave_lds_fence();
         const double step = p.uniform_step;
-        const double t_first = p.times[0] + off; // tsince of grid point 0; grid point i is t_first + i*step
+        const double t_first = p.grid_t0 + off; // tsince of grid point 0; grid point i is t_first + i*step
         FastCarry fc;
         // seed one increment (64 grid steps) BEFORE this lane's first grid point
         az_seed_fast_rec(rec, rec[FC_nl2], fma((double)(t_lo + lane) - 64.0, step, t_first), k.tc_, fc,
@@ -1059,7 +1066,7 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
 #define AZ_TILE_SATS 16
 #define AZ_TILE_SEG_MAX 1024 /* longest time segment of an ECEF launch (its Greenwich-angle table sits in LDS) */
 #define AZ_TILE_PITCH 49 /* doubles per staged time row: 48 + 1 (lane stride 98 dwords: ds_write_b64 conflict-free per half-wave) */
-template <bool VEL, int FRAME = 0, bool DELTA = false> // FRAME: 0 TEME, 1 ECEF, 2 geodetic positions (+ ECEF velocities); DELTA: see k_rows_fast
+template <bool VEL, int FRAME = 0, int DELTA = 0> // FRAME: 0 TEME, 1 ECEF, 2 geodetic positions (+ ECEF velocities); DELTA: see k_rows_fast
 __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
 {
     constexpr unsigned NA = VEL ? 2u : 1u;
@@ -1101,10 +1108,12 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
     }
     const bool ecc = AZ_FLAG_ECLASS(fl) != 0; // wave-uniform
     const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
-    const double step = p.uniform_step, t_first = p.times[0] + off;
-    __shared__ float dl_lds[DELTA ? AZ_DELTA_SEG : 1]; // the segment's deviations from the ideal grid, one table per tile
+    const double step = p.uniform_step, t_first = p.grid_t0 + off;
+    typedef typename std::conditional<DELTA == 2, double, float>::type dl_t;
+    __shared__ dl_t dl_lds[DELTA ? AZ_DELTA_SEG : 1]; // the segment's deviations from the ideal grid, one table per tile
     if (DELTA) {
-        if (threadIdx.x < AZ_DELTA_SEG) dl_lds[threadIdx.x] = p.delta[t_lo + threadIdx.x]; // (zero-padded by one segment)
+        const dl_t *src = DELTA == 2 ? reinterpret_cast<const dl_t *>(p.delta64) : reinterpret_cast<const dl_t *>(p.delta);
+        if (threadIdx.x < AZ_DELTA_SEG) dl_lds[threadIdx.x] = src[t_lo + threadIdx.x]; // (zero-padded by one segment)
         if (!ECEF) __syncthreads();
     }
     if (ECEF) __syncthreads(); // (gst above, and dl_lds)
@@ -1279,7 +1288,7 @@ __global__ void __launch_bounds__(64, MIXED ? AZ_ROWSF32P_WAVES : AZ_ROWSF32_WAV
         const bool staged = AZ_ROWS_LDS_STORE &&
                             (((reinterpret_cast<size_t>(prow) | (VEL ? reinterpret_cast<size_t>(vrow) : 0)) & 15u) == 0);
         const double step = p.uniform_step;
-        const double t_first = p.times[0] + off;
+        const double t_first = p.grid_t0 + off;
         __shared__ float once_lds[F32_NUM];
         FastK32Bcast k;
         FastCarry32 fc;
@@ -1472,7 +1481,7 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
         r[0] = t; r[1] = t + 1.0; r[2] = t + 2.0; v[0] = t + 3.0; v[1] = t + 4.0; v[2] = t + 5.0;
         (void)first;
 #else
-        az_sgp4_step<VEL, ColdT, true>(e, cold, seed_lds, 1, 0, p.g, rk, t, first, c, r, v);
+        az_sgp4_step<VEL, ColdT, true>(e, cold, seed_lds, 1, 0, p.g, rk, t, first, c, r, v, p.grid_exact_uniform != 0);
 #endif
         if (SINK == AZ_SINK_SCREEN) {
             // distances are frame-independent (ECEF is a rotation of TEME about z), so the screen
@@ -1568,7 +1577,7 @@ __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
         }
     }
     const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
-    const bool uniform = p.uniform_step != 0.0 && p.delta == nullptr; // (a quasi-uniform grid: the time table, like any other grid)
+    const bool uniform = p.uniform_step != 0.0 && p.delta == nullptr && p.delta64 == nullptr; // (a quasi-uniform grid: the time table, like any other grid)
     const double step = p.uniform_step, t_first = uniform ? p.times[0] + off : 0.0;
     const RotK rk = az_rotk();
     const size_t out_row = p.rows_compact ? row : s;

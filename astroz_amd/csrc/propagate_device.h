@@ -249,9 +249,11 @@ AZ_DEVICE double az_kepler_posvel(const AzGrav &g, double am, double ra, double 
 //                   mean anomaly moves by radians between them and is simply re-evaluated, the J2
 //                   angles still move by < 2^-7 rad and keep their carried pairs.
 template <bool VEL, class Cold, bool STRIDE64 = false>
+// cache_inc (STRIDE64 only, wave-uniform): the grid is uniform, so a lane's increments repeat and are worth caching; false on
+// irregular grids, where every step would rebuild the cache for nothing (a full sincos of mdot dt: a seventh of the step).
 AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const Cold &cold, const double *__restrict__ el, size_t n_pad,
                             size_t sat, const AzGrav &g, const RotK &rk, double t, bool first, Sgp4Carry &st,
-                            double r[3], double v[3])
+                            double r[3], double v[3], bool cache_inc = true)
 {
 #define CL(k) cold(k)
     const double t2 = t * t;
@@ -269,7 +271,11 @@ AZ_DEVICE void az_sgp4_step(const Sgp4Lane &e, const Cold &cold, const double *_
             az_sincos(fma(e.mdot, t, mo), st.sA, st.cA);
         } else if (STRIDE64) {
             az_rotate_le_small(st.sO, st.cO, dO, rk);
-            if (az_any(dt != st.dt_c || fabs(dW) > AZ_ROT_SMALL)) {
+            if (!cache_inc) {
+                // irregular grid: nothing repeats -- rotate W by its own increment, re-evaluate M (radians between a lane's steps)
+                az_rotate(st.sW, st.cW, dW, rk);
+                az_sincos(fma(e.mdot, t, el[(size_t)F_mo * n_pad + sat]), st.sA, st.cA);
+            } else if (az_any(dt != st.dt_c || fabs(dW) > AZ_ROT_SMALL)) {
                 // (re)build the cached increments; also the path of any non-uniform grid
                 st.dt_c = (fabs(dW) > AZ_ROT_SMALL) ? -1.0e300 : dt;
                 az_sincos(dA, st.sdA, st.cdA);

@@ -284,10 +284,14 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
                 offs = (rjd - dev.epochs) * 1440.0
                 st_ = (times[-1] - times[0]) / (n_times - 1)
                 ent["grid"] = {"kind": "jd+fr (api.py L300-302)", "max_dev_from_uniform_min": float(np.abs(times - (times[0] + np.arange(n_times) * st_)).max())}
-            elif grid == "irregular":
-                # one-minute grid with +-20 s of jitter per point (sorted): no fast path applies
+            elif grid == "jitter":
+                # one-minute grid with +-20 s of jitter per point: "uniform with jitter" (fast_step.h, the wide DELTA form)
                 times = times + np.random.default_rng(7).uniform(-1.0 / 3.0, 1.0 / 3.0, n_times)
                 ent["grid"] = {"kind": "one-minute steps + uniform(-20 s, 20 s) jitter"}
+            elif grid == "random":
+                # sorted random times over the same day: no uniform structure at all, the generic kernels
+                times = np.sort(np.random.default_rng(7).uniform(0.0, float(n_times), n_times))
+                ent["grid"] = {"kind": "sorted uniform-random times over the span"}
             stride = (n + stride_align - 1) // stride_align * stride_align if (stride_align and layout == _native.TIME_MAJOR) else n
             shape = (n_times, stride, 3) if layout == _native.TIME_MAJOR else (n, n_times, 3)
             odt = torch.float32 if f32 else torch.float64
@@ -358,10 +362,14 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
          "k_tiles_fast<pos+vel,DELTA> + redo", dev2, pairs2, 1440, layout=TM, grid="jdfr")
     case("config2_sat_major_jdfr", "config 2, satellite-major, on the (jd, fr) grid of the reference's API call",
          "k_rows_fast<pos+vel,DELTA> + redo", dev2, pairs2, 1440, layout=SM, grid="jdfr")
-    case("config2_time_major_irregular", "config 2, TIME-major, irregular grid (one-minute steps with +-20 s jitter)",
-         "k_propagate<time-major> (lane = satellite, generic step)", dev2, pairs2, 1440, layout=TM, grid="irregular", steps=20, warm=5)
-    case("config2_sat_major_irregular", "config 2, satellite-major, irregular grid (one-minute steps with +-20 s jitter)",
-         "k_rows (generic, lane = time)", dev2, pairs2, 1440, layout=SM, grid="irregular", steps=20, warm=5)
+    case("config2_time_major_irregular", "config 2, TIME-major, one-minute steps with +-20 s jitter (VERDICT r03's irregular grid: uniform with jitter, "
+         "the wide quasi-uniform form)", "k_tiles_fast<pos+vel,DELTA=2> + redo", dev2, pairs2, 1440, layout=TM, grid="jitter", steps=20, warm=5)
+    case("config2_sat_major_irregular", "config 2, satellite-major, one-minute steps with +-20 s jitter",
+         "k_rows_fast<pos+vel,DELTA=2> + redo", dev2, pairs2, 1440, layout=SM, grid="jitter", steps=20, warm=5)
+    case("config2_time_major_random", "config 2, TIME-major, sorted random times (no uniform structure: the generic kernels)",
+         "k_propagate<time-major> (lane = satellite, generic step)", dev2, pairs2, 1440, layout=TM, grid="random", steps=20, warm=5)
+    case("config2_sat_major_random", "config 2, satellite-major, sorted random times",
+         "k_rows (generic, lane = time)", dev2, pairs2, 1440, layout=SM, grid="random", steps=20, warm=5)
     case("config2_ecef_time_major", "config 2, ECEF time-major (the default of the reference's high-level propagate(), "
          "Constellation.zig L489-506), fp64 pos+vel", "k_tiles_fast<pos+vel,ECEF> + redo", dev2, pairs2, 1440, layout=TM, mode=1, ref_jd=ref_jd)
     case("config2_ecef_sat_major", "config 2, ECEF satellite-major, fp64 pos+vel", "k_rows_fast<pos+vel,FRAME> + redo",

@@ -95,7 +95,7 @@ static void emul_fast_run(const double* fields, unsigned flags, const double* gr
 // eccentric form, follows a rejected step of its segment (the kernel hands the rest of the segment to the generic path).
 // delta (may be null): quasi-uniform grid, point i sits at t_first + i step + delta[i] (fast_step.h, DELTA); dmax >= max |delta|
 static void emul_rows_fast_impl(const double* fields, unsigned flags, const double* grav6, double t_first, double step, int n_times, int tile,
-                                int ecc, double* out6, int* bad_out, const float* delta, double dmax)
+                                int ecc, double* out6, int* bad_out, const float* delta, double dmax, const double* delta64 = nullptr)
 {
     AzGrav g{grav6[0], grav6[1], grav6[2], grav6[3], grav6[4], grav6[5], 0.5 * grav6[1]};
     double inc[2 * AZ_INC_NUM];
@@ -119,11 +119,16 @@ static void emul_rows_fast_impl(const double* fields, unsigned flags, const doub
                 double r[3], v[3];
                 double t = fma((double)i, step, t_first);
                 bool bad;
-                if (delta) {
+                if (delta64) { // the WIDE form: fp64 deviations of seconds
+                    const double dl = i < n_times ? delta64[i] : 0.0;
+                    t += dl;
+                    bad = ecc ? az_sgp4_fast_step<true, true, 2>(k, g, RotCoefLit(), t, st, r, v, dl)
+                              : az_sgp4_fast_step<true, false, 2>(k, g, RotCoefLit(), t, st, r, v, dl);
+                } else if (delta) {
                     const double dl = i < n_times ? (double)delta[i] : 0.0;
                     t += dl;
-                    bad = ecc ? az_sgp4_fast_step<true, true, true>(k, g, RotCoefLit(), t, st, r, v, dl)
-                              : az_sgp4_fast_step<true, false, true>(k, g, RotCoefLit(), t, st, r, v, dl);
+                    bad = ecc ? az_sgp4_fast_step<true, true, 1>(k, g, RotCoefLit(), t, st, r, v, dl)
+                              : az_sgp4_fast_step<true, false, 1>(k, g, RotCoefLit(), t, st, r, v, dl);
                 } else {
                     bad = ecc ? az_sgp4_fast_step<true, true>(k, g, RotCoefLit(), t, st, r, v)
                               : az_sgp4_fast_step<true, false>(k, g, RotCoefLit(), t, st, r, v);
@@ -146,6 +151,12 @@ void emul_rows_fast_delta(const double* fields, unsigned flags, const double* gr
                           int ecc, const float* delta, double dmax, double* out6, int* bad_out)
 {
     emul_rows_fast_impl(fields, flags, grav6, t_first, step, n_times, tile, ecc, out6, bad_out, delta, dmax);
+}
+
+void emul_rows_fast_wide(const double* fields, unsigned flags, const double* grav6, double t_first, double step, int n_times, int tile,
+                         int ecc, const double* delta64, double dmax, double* out6, int* bad_out)
+{
+    emul_rows_fast_impl(fields, flags, grav6, t_first, step, n_times, tile, ecc, out6, bad_out, nullptr, dmax, delta64);
 }
 
 void emul_propagate_fast(const double* fields, unsigned flags, const double* grav6, double ts0, double dt, int n,

@@ -133,9 +133,9 @@ def test_jdfr_grid_matches_the_generic_path_and_ecef(native, orc, synth):
     assert dev.last_path() & native.PATH_QUASI_UNIFORM
     _, p0, _ = cat.propagate(tb, off, velocities=False)
     assert np.abs(pos - p0).max() < TOL_R
-    # a grid with 20-second jitter is not quasi-uniform: generic kernels, same answers
+    # random times are not a uniform grid in any sense: generic kernels, same answers
     rng = np.random.default_rng(4)
-    tj = times + rng.uniform(-1 / 3, 1 / 3, n)
+    tj = np.sort(times[0] + rng.uniform(0.0, 700.0, n))
     pos, vel = np.empty((dev.n, n, 3)), np.empty((dev.n, n, 3))
     dev.propagate_host(tj, off, pos=pos, vel=vel, layout=native.SAT_MAJOR)
     assert not dev.last_path() & (native.PATH_ROWS_FAST | native.PATH_QUASI_UNIFORM)
@@ -225,3 +225,89 @@ def test_resonance_node_cache_is_invisible(native, orc, synth):
             e0, p0, v0 = cat.propagate(t, o, layout=olay)
             assert np.array_equal(res[0][2], e0)
             assert np.abs(res[0][0] - p0).max() < TOL_R and np.abs(res[0][1] - v0).max() < TOL_V, (j, layout)
+
+
+@pytest.mark.parametrize("n_deep", [0, 1522])
+def test_jittered_grids_full_size_take_the_fast_kernels(native, orc, synth, n_deep):
+    """A one-minute grid whose points are off by up to +-20 s (time stamps of a periodic process) is 'uniform with jitter': the
+    fast kernels run along the least-squares grid and rotate every point to its actual time (fast_step.h, DELTA = 2).
+    BASELINE configs 2 and 3 at full size, every row vs the oracle at the actual times, both layouts."""
+    import torch
+    pairs = synth.synth_catalog(n_near=13478, n_deep=n_deep)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    n = 1440
+    times = np.arange(n, dtype=np.float64) + np.random.default_rng(7).uniform(-1.0 / 3.0, 1.0 / 3.0, n)
+    off = (synth.START_JD - dev.epochs) * 1440.0
+    e0, p0, v0 = cat.propagate(times, off, layout=orc.SAT_MAJOR, threads=16)
+    pos = torch.empty((dev.n, n, 3), dtype=torch.float64, device="cuda")
+    vel = torch.empty_like(pos)
+    err = torch.empty((dev.n, n), dtype=torch.uint8, device="cuda")
+    dev.propagate_device(times, off, pos.data_ptr(), vel.data_ptr(), layout=native.SAT_MAJOR, d_err=err.data_ptr())
+    dev.synchronize()
+    path = dev.last_path()
+    assert path & native.PATH_ROWS_FAST and path & native.PATH_QUASI_UNIFORM and not path & native.PATH_ROWS_GENERIC, path
+    assert np.array_equal(err.cpu().numpy(), e0)
+    dr = float(np.abs(pos.cpu().numpy() - p0).max())
+    dv = float(np.abs(vel.cpu().numpy() - v0).max())
+    assert dr < TOL_R and dv < TOL_V, (dr, dv)
+    del pos, vel
+    ptm = torch.empty((n, dev.n, 3), dtype=torch.float64, device="cuda")
+    vtm = torch.empty_like(ptm)
+    dev.propagate_device_cached(ptm.data_ptr(), vtm.data_ptr(), layout=native.TIME_MAJOR)
+    dev.synchronize()
+    path = dev.last_path()
+    assert path & native.PATH_TILES_FAST and path & native.PATH_QUASI_UNIFORM and not path & native.PATH_LANE_SAT, path
+    dr = float(np.abs(ptm.cpu().numpy().transpose(1, 0, 2) - p0).max())
+    dv = float(np.abs(vtm.cpu().numpy().transpose(1, 0, 2) - v0).max())
+    assert dr < TOL_R and dv < TOL_V, (dr, dv)
+
+
+def test_jittered_grid_variants_and_limits(native, orc, synth):
+    """The wide form with ECEF / geodetic output, fp32 outputs, the fused screen, a coarse grid with large jitter; and what is
+    NOT uniform-with-jitter (jitter above 30 s, or as large as the step, or random times) stays with the generic kernels."""
+    import torch
+    pairs = synth.synth_catalog(n_near=800, n_deep=60, seed=91)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    off = (synth.START_JD - dev.epochs) * 1440.0
+    rng = np.random.default_rng(3)
+    n = 900
+    tj = -300.0 + 2.0 * np.arange(n) + rng.uniform(-0.45, 0.45, n)          # two-minute steps, +-27 s
+    for layout, olay in ((native.SAT_MAJOR, orc.SAT_MAJOR), (native.TIME_MAJOR, orc.TIME_MAJOR)):
+        for mode, omode in ((native.OUT_TEME, orc.TEME), (native.OUT_ECEF, orc.ECEF), (native.OUT_GEODETIC, orc.GEODETIC)):
+            shape = (dev.n, n, 3) if layout == native.SAT_MAJOR else (n, dev.n, 3)
+            pos, vel = np.empty(shape), np.empty(shape)
+            dev.propagate_host(tj, off, pos=pos, vel=vel, mode=mode, reference_jd=synth.START_JD, layout=layout)
+            path = dev.last_path()
+            assert path & native.PATH_QUASI_UNIFORM and path & (native.PATH_ROWS_FAST | native.PATH_TILES_FAST), (layout, mode, path)
+            _, p0, v0 = cat.propagate(tj, off, layout=olay, mode=omode, reference_jd=synth.START_JD)
+            dq = np.abs(pos - p0)
+            if mode == native.OUT_GEODETIC:
+                dq[..., 1] = np.minimum(dq[..., 1], 2 * np.pi - dq[..., 1])
+            assert dq.max() < TOL_R and np.abs(vel - v0).max() < TOL_V, (layout, mode, dq.max())
+    # fp32 outputs: the wide form runs the fp64 kernels with rounded stores (half an fp32 ulp), in every arithmetic mode
+    _, p0, v0 = cat.propagate(tj, off)
+    p32 = torch.empty((dev.n, n, 3), dtype=torch.float32, device="cuda")
+    v32 = torch.empty_like(p32)
+    dev.propagate_device(tj, off, p32.data_ptr(), v32.data_ptr(), layout=native.SAT_MAJOR, f32=True)
+    dev.synchronize()
+    assert dev.last_path() & native.PATH_QUASI_UNIFORM
+    assert np.abs(p32.cpu().numpy().astype(np.float64) - p0).max() < 4.95e-4 + 2.5e-3  # (deep-space rows reach 42,000 km: half an ulp is 2 m there)
+    near = ~cat.is_deep
+    assert np.abs(p32.cpu().numpy().astype(np.float64)[near] - p0[near]).max() < 4.95e-4
+    assert np.abs(v32.cpu().numpy().astype(np.float64)[near] - v0[near]).max() < 4.85e-7
+    # fused screen
+    d, t = dev.screen_target(tj, 3, 3000.0, off)
+    assert dev.last_path() & native.PATH_QUASI_UNIFORM
+    d0, t0 = cat.screen_target(tj, 3, 3000.0, off)
+    assert np.array_equal(t, t0) and np.abs(d - d0).max() < TOL_R
+    # not uniform-with-jitter: generic kernels, same gate
+    for bad_grid in (2.0 * np.arange(n) + rng.uniform(-0.7, 0.7, n),                       # jitter above half a minute
+                     0.5 * np.arange(n) + rng.uniform(-0.3, 0.3, n),                       # jitter larger than half the step
+                     np.sort(rng.uniform(0.0, 1440.0, n))):                                # random times
+        pos, vel = np.empty((dev.n, n, 3)), np.empty((dev.n, n, 3))
+        dev.propagate_host(bad_grid, off, pos=pos, vel=vel, layout=native.SAT_MAJOR)
+        assert not dev.last_path() & (native.PATH_QUASI_UNIFORM | native.PATH_ROWS_FAST), dev.last_path()
+        _, p0, v0 = cat.propagate(bad_grid, off)
+        assert np.abs(pos - p0).max() < TOL_R and np.abs(vel - v0).max() < TOL_V

@@ -125,3 +125,48 @@ def test_emulated_mixed_fp32_step_on_a_jd_fr_grid(emul, orc):
         worst_v = max(worst_v, np.abs(out[ok, 3:] - v0[i][ok]).max())
     assert used > 30
     assert worst_r < 6e-4 and worst_v < 6e-7, (worst_r, worst_v)
+
+
+def test_emulated_fast_step_on_a_jittered_grid(emul, orc):
+    """The WIDE form (fast_step.h, DELTA = 2): a one-minute grid whose points are off by up to +-20 s (time stamps of a periodic
+    process).  Least-squares ideal grid, fp64 deviations, M rotated to first order (near-circular) / by the 1/16-rad
+    polynomial (eccentric), W to first order, U exactly -- against the oracle at the actual times, at the fp64 gate."""
+    from astroz_amd import synth
+    E = emul
+    E.emul_rows_fast_wide.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    pairs = synth.synth_catalog(150, 0, seed=31)
+    tles = [orc.parse_lines(a, b) for a, b in pairs]
+    cat = orc.Catalog(tles, 1)
+    g = _grav6(1)
+    nf = E.emul_num_fields()
+    n = 1440
+    rng = np.random.default_rng(12)
+    times = np.arange(n, dtype=np.float64) + rng.uniform(-1.0 / 3.0, 1.0 / 3.0, n)
+    off = (synth.START_JD - cat.epoch_jd) * 1440.0
+    idx = np.arange(n, dtype=np.float64)
+    step, t0 = np.polyfit(idx, times, 1)            # the least-squares line stage_inputs fits
+    delta = times - (idx * step + t0)
+    dmax = float(np.abs(delta).max())
+    assert 0.2 < dmax < 0.5
+    _, p0, v0 = cat.propagate(times, off)
+    worst_r = worst_v = 0.0
+    accepted = n_ecc = 0
+    for i, t in enumerate(tles):
+        raw = np.array([t.epoch_jd, t.mm_revday, t.ecc, t.incl_deg, t.raan_deg, t.argp_deg, t.ma_deg, t.bstar])
+        fields = np.zeros(nf)
+        flags = E.emul_init(raw.ctypes.data, g.ctypes.data, fields.ctypes.data)
+        ecc = 1 if t.ecc > 0.003 else 0
+        n_ecc += ecc
+        out = np.zeros((n, 6))
+        bad = np.zeros(n, dtype=np.int32)
+        E.emul_rows_fast_wide(fields.ctypes.data, flags, g.ctypes.data, t0 + off[i], step, n, 768, ecc, delta.ctypes.data, dmax,
+                              out.ctypes.data, bad.ctypes.data)
+        ok = bad == 0
+        accepted += int(ok.sum())
+        if ok.any():
+            worst_r = max(worst_r, np.abs(out[ok, :3] - p0[i][ok]).max())
+            worst_v = max(worst_v, np.abs(out[ok, 3:] - v0[i][ok]).max())
+    assert n_ecc >= 5
+    assert accepted > 0.85 * n * len(tles), accepted
+    assert worst_r < 1e-6 and worst_v < 1e-9, (worst_r, worst_v)
