@@ -82,6 +82,10 @@ def parse_args():
                     help="disable the branch-free uniform-grid step (A/B against the generic tier-voting loop)")
     ap.add_argument("--no-tile-kernel", action="store_true",
                     help="time-major layout: the lane = satellite kernel instead of the 16-satellite tile kernel")
+    ap.add_argument("--grid", choices=["uniform", "jdfr", "jitter", "random"], default="uniform",
+                    help="time grid of the main workload: exactly uniform one-minute steps (the headline); the (jd, fr) grid of the "
+                         "reference's SatrecArray.sgp4 call (uniform to ~4e-7 min); one-minute steps with +-20 s jitter; sorted random "
+                         "times (profiling runs: which kernels a grid takes)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default run only: skip the `secondary` block (the other configurations of BASELINE.json, each a "
                          "few steps, timed after the headline region)")
@@ -624,6 +628,16 @@ def main():
     dev.set_f32_arithmetic("packed" if a.f32_arith else ("fp64" if a.f32_fp64 else "mixed"))
     n_local = dev.n
     offsets = (synth.START_JD - dev.epochs) * 1440.0
+    if a.grid == "jdfr":       # api.py L300-302 on examples/python_sgp4.py's (jd, fr)
+        jd_ = np.full(n_times, synth.START_JD)
+        fr_ = 0.32853009 + np.arange(n_times) / 1440.0
+        rjd_ = jd_[0] + fr_[0]
+        times = ((jd_ + fr_) - rjd_) * 1440.0
+        offsets = (rjd_ - dev.epochs) * 1440.0
+    elif a.grid == "jitter":
+        times = times + np.random.default_rng(7).uniform(-1.0 / 3.0, 1.0 / 3.0, n_times)
+    elif a.grid == "random":
+        times = np.sort(np.random.default_rng(7).uniform(0.0, float(n_times), n_times))
     layout = _native.TIME_MAJOR if a.layout == "time" else _native.SAT_MAJOR
     stride = 0
     if layout == _native.TIME_MAJOR and a.stride_align > 0:
@@ -824,7 +838,8 @@ def main():
         # (the fingerprint was written on the GPU box by tools/profile_run.py when the counters were collected; a file
         # measured on other sources is not reported)
         if (pm.get("csrc_sha16") == csrc_fingerprint() and world == 1 and layout == _native.SAT_MAJOR and vel_on and
-                a.sats == 13478 and n_times == 1440 and not a.deep and not a.f32_out and not a.no_fast_path and mode == 0):
+                a.sats == 13478 and n_times == 1440 and not a.deep and not a.f32_out and not a.no_fast_path and mode == 0 and
+                a.grid == "uniform"):
             pm = pm.get("step", pm)     # tools/profile_run.py keeps the step totals under "step"
             traffic = pm["hbm_bytes_per_launch"]
             if pm.get("valu_wave_insts_per_launch"):
@@ -880,7 +895,7 @@ def main():
         "scaling": "n/a" if world == 1 else a.scaling, "vs_baseline": None,
         "dtype": "f64" if "fp64 arithmetic" == arith else "f32 (+f64 phase/radius chains)", "data": "synthetic",
         "config": {
-            "workload": wl, "n_sats_total": n_total, "n_sats_per_gpu": n_local, "n_times": n_times, "gather": bool(gather),
+            "workload": wl + ("" if a.grid == "uniform" else " [time grid: %s]" % a.grid), "launch_path": dev.last_path(), "n_sats_total": n_total, "n_sats_per_gpu": n_local, "n_times": n_times, "gather": bool(gather),
             "precondition_ms": a.precondition_ms, "precondition_steps": n_pre,
             **({"t_kernel_ms": kernel_only_ms, "t_allgather_ms": max(elapsed / a.steps * 1e3 - kernel_only_ms, 0.0),
                 "t_total_ms": elapsed / a.steps * 1e3, "rccl_ranks": world, "chunks": plan.n_chunks,
