@@ -488,7 +488,10 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, doub
     const double tempa = fma(-t, fma(t, fma(t, fma(t, k.d4(), k.d3()), k.d2()), k.cc1()), 1.0);
     // no_unkozai * templ without the part carried by U: kappa (t - tc)^2 + t^3 (nl3 + t (nl4 + t nl5))
     const double dtc = t - k.tc();
-    const double nl = fma(k.nl2() * dtc, dtc, t2 * (t * fma(t, fma(t, k.nl5(), k.nl4()), k.nl3())));
+    double nl = fma(k.nl2() * dtc, dtc, t2 * (t * fma(t, fma(t, k.nl5(), k.nl4()), k.nl3())));
+    // U at the actual time: udot dl joins the angle of the small rotation U takes further down -- added HERE, where dl is still
+    // at hand (kept live down to that rotation it costs the tile kernel, which runs at its register limit, two VGPRs)
+    if constexpr (DELTA != 0) nl = fma(k.udot(), dl, nl);
     bool bad = false;
     double p, q;
     if (ECC) az_pq_16th(th, rk, p, q);
@@ -511,8 +514,7 @@ AZ_DEVICE bool az_sgp4_fast_step(const K &k, const AzGrav &g, const RC &rk, doub
     // u0 = U + (rest of no*templ) + temp*xlcof*axnl: |.| <= 1/8, sin to d^7 and cos to d^8 (d^9/9! < 2.1e-14)
     double s = st.sU, c = st.cU;
     {
-        double eps = fma(temp * k.xlcof(), axnl, nl);
-        if constexpr (DELTA) eps = fma(k.udot(), dl, eps); // U at the actual time
+        const double eps = fma(temp * k.xlcof(), axnl, nl);
         az_pq_16th(eps, rk, p, q);
         az_rot_apply2(s, c, p, q);
     }

@@ -197,7 +197,8 @@ AZ_DEVICE void az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, Fas
     const az_f2 th = az_fma2(k.xmcof(), dm * dm * dm, az_fma2(k.omgcof(), t, -k.xd()));
     // 1 - tempa = t (cc1 + t (d2 + t (d3 + t d4))) is small (1e-3 after a week): fp32 is plenty for it
     const az_f2 dev = t * az_fma2(t, az_fma2(t, az_fma2(k.d4(), t, k.d3()), k.d2()), k.cc1());
-    const az_f2 nl = az_fma2(k.nl2() * dtc, dtc, t2 * (t * az_fma2(t, az_fma2(k.nl5(), t, k.nl4()), k.nl3())));
+    az_f2 nl = az_fma2(k.nl2() * dtc, dtc, t2 * (t * az_fma2(t, az_fma2(k.nl5(), t, k.nl4()), k.nl3())));
+    if constexpr (DELTA) nl = az_fma2(k.udot(), dl, nl); // U at the actual time (fast_step.h): rides on the rotation by eps below
     // M + th and W - th: both pairs only enter through eccentricity-scaled terms (x 0.004), |th| <= 1/16:
     // sin th = th - th^3/6 (error 8e-9), cos th = 1 - th^2/2 (error 6e-7 x 0.004), one polynomial for both
     const az_f2 th2 = th * th;
@@ -224,8 +225,7 @@ AZ_DEVICE void az_sgp4_fast_step_f32(const K &k, const AzGrav &g, double ta, Fas
     az_f2 s = az_cvt2(st.sU, fma(st.sU, k.c1U, st.cU * k.s1U));
     az_f2 c = az_cvt2(st.cU, fma(st.cU, k.c1U, -(st.sU * k.s1U)));
     {
-        az_f2 eps = az_fma2(k.xlcof() * temp, axnl, nl);
-        if constexpr (DELTA) eps = az_fma2(k.udot(), dl, eps);
+        const az_f2 eps = az_fma2(k.xlcof() * temp, axnl, nl);
         az_rot32_med(s, c, eps);
     }
 
@@ -355,7 +355,8 @@ AZ_DEVICE void az_sgp4_fast_step_f32p(const K &k, const AzGrav &g, double ta, Fa
     const az_f2 dm = az_fma2(k.eta(), st.cA, 1.0f);
     const az_f2 th = az_fma2(k.xmcof(), dm * dm * dm, az_fma2(k.omgcof(), t, -k.xd()));
     const az_f2 dev = t * az_fma2(t, az_fma2(t, az_fma2(k.d4(), t, k.d3()), k.d2()), k.cc1());
-    const az_f2 nl = az_fma2(k.nl2() * dtc, dtc, t2 * (t * az_fma2(t, az_fma2(k.nl5(), t, k.nl4()), k.nl3())));
+    az_f2 nl = az_fma2(k.nl2() * dtc, dtc, t2 * (t * az_fma2(t, az_fma2(k.nl5(), t, k.nl4()), k.nl3())));
+    if constexpr (DELTA) nl = az_fma2(k.udot(), dl, nl); // U at the actual time: rides on the rotation by eps below
     const az_f2 th2 = th * th;
     const az_f2 pth = az_fma2((-1.0f / 6.0f) * th2, th, th);
     const az_f2 qth = -0.5f * th2;
@@ -384,8 +385,7 @@ AZ_DEVICE void az_sgp4_fast_step_f32p(const K &k, const AzGrav &g, double ta, Fa
     const double sU_a = st.sU, cU_a = st.cU;
     const double sU_b = fma(st.sU, k.c1U, st.cU * k.s1U), cU_b = fma(st.cU, k.c1U, -(st.sU * k.s1U));
     az_f2 s = az_cvt2(sU_a, sU_b), c = az_cvt2(cU_a, cU_b);
-    az_f2 eps = az_fma2(k.xlcof() * temp, axnl, nl);
-    if constexpr (DELTA) eps = az_fma2(k.udot(), dl, eps);
+    const az_f2 eps = az_fma2(k.xlcof() * temp, axnl, nl);
     az_rot32_med(s, c, eps);
     // Kepler, near-circular: Newton step from E0 = u, then the chord step with the same reciprocal (first order)
     const az_f2 el2 = az_fma2(axnl, axnl, aynl * aynl);

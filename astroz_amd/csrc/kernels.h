@@ -88,7 +88,8 @@ struct PropArgs {
     double delta_max;
     // ... or the WIDE form (jitter of seconds, |delta| <= AZ_DELTA_WIDE_MAX): deviations as fp64; the ideal grid is a fit, its
     // origin grid_t0 (= times[0] on exact and tight grids) replaces times[0] in the fast kernels and the plan
-    const double *delta64;
+    const double *delta64; // (also set on tight grids: k_tiles_fast stages fp64 deviations in both forms)
+    int delta_wide;        // the wide form applies
     double grid_t0;
     const double *inc;
     const double *fast_rec; // [n_pad][FR_NUM]: per-satellite record of the lane = time fast kernels (k_prep_rec, fast_step.h)
@@ -1109,10 +1110,11 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
     const bool ecc = AZ_FLAG_ECLASS(fl) != 0; // wave-uniform
     const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
     const double step = p.uniform_step, t_first = p.grid_t0 + off;
-    typedef typename std::conditional<DELTA == 2, double, float>::type dl_t;
+    // (fp64 deviations: the host launches the wide instantiation of this kernel for both quasi-uniform forms)
+    typedef double dl_t;
     __shared__ dl_t dl_lds[DELTA ? AZ_DELTA_SEG : 1]; // the segment's deviations from the ideal grid, one table per tile
     if (DELTA) {
-        const dl_t *src = DELTA == 2 ? reinterpret_cast<const dl_t *>(p.delta64) : reinterpret_cast<const dl_t *>(p.delta);
+        const dl_t *src = p.delta64;
         if (threadIdx.x < AZ_DELTA_SEG) dl_lds[threadIdx.x] = src[t_lo + threadIdx.x]; // (zero-padded by one segment)
         if (!ECEF) __syncthreads();
     }
