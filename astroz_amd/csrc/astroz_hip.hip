@@ -1174,13 +1174,18 @@ int32_t run_one_satellite(azh_constellation *c, size_t sat, const double *tsince
             }
         }
     } else {
+        // long time series: through the pinned staging slots, like the constellation's host-returning calls (copy_back_staged)
+        void *const dst[3] = {interleaved ? (void *)out6 : (void *)pos, interleaved ? nullptr : (void *)vel, interleaved ? nullptr : (void *)err};
+        const void *const src[3] = {interleaved ? (const void *)c->d_one_o.p : (const void *)d_p, d_v, c->d_one_e.p};
+        const size_t len[3] = {sizeof(double) * (interleaved ? 6 : 3) * n, (!interleaved && vel) ? sizeof(double) * 3 * n : 0,
+                               (!interleaved && err) ? n : 0};
+        const unsigned thr = host_copy_threads();
         bool ok = true;
-        if (interleaved) {
-            ok = hip_ok(hipMemcpyAsync(out6, c->d_one_o.p, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, st), "D2H");
+        if (thr > 0 && len[0] + len[1] + len[2] >= (size_t(8) << 20)) {
+            ok = copy_back_staged(c->stager, dst, src, len, 3, st, thr) == AZ_OK;
         } else {
-            ok = hip_ok(hipMemcpyAsync(pos, d_p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st), "D2H");
-            if (ok && vel) ok = hip_ok(hipMemcpyAsync(vel, d_v, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, st), "D2H");
-            if (ok && err) ok = hip_ok(hipMemcpyAsync(err, c->d_one_e.p, n, hipMemcpyDeviceToHost, st), "D2H");
+            for (int k = 0; k < 3 && ok; ++k)
+                if (len[k]) ok = hip_ok(hipMemcpyAsync(dst[k], src[k], len[k], hipMemcpyDeviceToHost, st), "D2H");
         }
         if (!ok || !hip_ok(hipStreamSynchronize(st), "sync")) rc = AZ_ERR_HIP;
     }

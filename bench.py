@@ -489,7 +489,17 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             ent["parity"] = {"points": int(len(pick)),
                              "max_abs_dr_km": float(np.abs(po[torch.as_tensor(pick, device=cuda)].cpu().numpy() - p0[0]).max()),
                              "max_abs_dv_kms": float(np.abs(ve[torch.as_tensor(pick, device=cuda)].cpu().numpy() - v0[0]).max())}
-            del ts, po, ve
+            # the same series through HOST pointers (Satrec.sgp4_array / sgp4_propagate_batch: tsince in, e / r / v numpy out)
+            th = np.linspace(0.0, 14400.0, n)
+            hw = []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                eh, rh, vh = dev2.propagate_one(0, th)
+                hw.append((time.perf_counter() - t0) * 1e3)
+                del eh, rh, vh
+            ent["host_pointers"] = {"ms_per_call": sorted(hw[1:])[len(hw[1:]) // 2], "calls_ms": hw,
+                                    "value": n / (sorted(hw[1:])[len(hw[1:]) // 2] / 1e3), "unit": "propagations/s (80 MB in, 490 MB out over PCIe, fresh arrays)"}
+            del ts, po, ve, th
         except Exception as exc:
             ent["failed"] = repr(exc)
         res.append(ent)
