@@ -311,3 +311,58 @@ def test_jittered_grid_variants_and_limits(native, orc, synth):
         assert not dev.last_path() & (native.PATH_QUASI_UNIFORM | native.PATH_ROWS_FAST), dev.last_path()
         _, p0, v0 = cat.propagate(bad_grid, off)
         assert np.abs(pos - p0).max() < TOL_R and np.abs(vel - v0).max() < TOL_V
+
+
+def test_api_hygiene_round4(native, orc, synth):
+    """the boolean azh_set_f32_arithmetic keeps its original meaning next to azh_set_f32_mode; azh_group_* take the
+    length of epoch_offsets; host copy threads are a switch, not a semantic."""
+    import ctypes as C
+    import torch
+    pairs = synth.synth_catalog(n_near=300, n_deep=20, seed=5)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    times = np.arange(0.0, 256.0)
+    off = (synth.START_JD - dev.epochs) * 1440.0
+
+    def f32(mode):
+        dev.set_f32_arithmetic(mode)
+        p = torch.empty((dev.n, 256, 3), dtype=torch.float32, device="cuda")
+        v = torch.empty_like(p)
+        dev.propagate_device(times, off, p.data_ptr(), v.data_ptr(), layout=native.SAT_MAJOR, f32=True)
+        dev.synchronize()
+        return p.cpu().numpy(), v.cpu().numpy()
+    a, b = f32(False), f32("fp64")        # False = fp64 arithmetic rounded once at the store: bit-identical to mode 2
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    a, b = f32(True), f32("packed")
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    a, b = f32(0), f32("mixed")
+    assert np.array_equal(a[0], b[0])
+    dev.set_f32_arithmetic("mixed")
+    # host copy threads: same bytes either way
+    big = native.DeviceConstellation.from_tle_lines(synth.synth_catalog(n_near=3000, n_deep=0, seed=6), 1, 0)
+    tb = np.arange(0.0, 700.0)
+    ob = (synth.START_JD - big.epochs) * 1440.0
+    res = []
+    for thr in (0, 3, -1):
+        native.set_host_copy_threads(thr)
+        pos, vel = np.empty((700, big.n, 3)), np.empty((700, big.n, 3))
+        err = np.zeros((big.n, 700), dtype=np.uint8)
+        big.propagate_host(tb, ob, pos=pos, vel=vel, err=err)
+        res.append((pos, vel, err))
+    native.set_host_copy_threads(-1)
+    for r in res[1:]:
+        assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
+    # azh_group_*: a short epoch_offsets array is an error code, not an out-of-bounds read
+    text = synth.pairs_to_text(pairs)
+    grp = native.DeviceGroup(text, [0], native.WGS72, n_chunks=2)
+    L = native.lib()
+    t = np.arange(0.0, 64.0)
+    short = np.zeros(grp.n - 1)
+    pos = np.empty((grp.n, 64, 3))
+    rc = L.azh_group_propagate_host(grp._h, t.ctypes.data, 64, short.ctypes.data, len(short), pos.ctypes.data, None, 0, 0.0, None)
+    assert rc == -20   # AZ_ERR_VALUE
+    full = (synth.START_JD - grp.epochs) * 1440.0
+    rc = L.azh_group_propagate_host(grp._h, t.ctypes.data, 64, full.ctypes.data, len(full), pos.ctypes.data, None, 0, 0.0, None)
+    assert rc == 0
+    _, p0, _ = orc.Catalog.from_pairs(pairs, 1).propagate(t, full, velocities=False)
+    assert np.abs(pos - p0).max() < TOL_R
+    grp.close()

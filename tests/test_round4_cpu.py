@@ -170,3 +170,41 @@ def test_emulated_fast_step_on_a_jittered_grid(emul, orc):
     assert n_ecc >= 5
     assert accepted > 0.85 * n * len(tles), accepted
     assert worst_r < 1e-6 and worst_v < 1e-9, (worst_r, worst_v)
+
+
+def test_source_resolution_round4():
+    """CelesTrak group aliases of the reference's loader (bindings/python/astroz/__init__.py L131-136), the explicit
+    'celestrak:' prefix, and the conflicts the advisor flagged (source + norad_id; a mistyped file name is not a group)."""
+    import astroz_amd as az
+    for short, group in (("all", "active"), ("iss", "stations"), ("gps", "gps-ops"), ("glonass", "glo-ops"), ("Starlink", "starlink")):
+        assert az.celestrak_url(group=short).endswith("GROUP=%s&FORMAT=tle" % group)
+    seen = []
+    fetch = lambda url: seen.append(url) or "1 x\n2 y\n"
+    az._as_text("celestrak:iss", fetch=fetch)
+    az._as_text("gps", fetch=fetch)
+    assert seen[0].endswith("GROUP=stations&FORMAT=tle") and seen[1].endswith("GROUP=gps-ops&FORMAT=tle")
+    with pytest.raises(ValueError):
+        az._as_text("starlink", norad_id=25544, fetch=fetch)          # either a source or a catalog number
+    with pytest.raises(ValueError):
+        az._as_text("celestrak:", fetch=fetch)
+    with pytest.raises((FileNotFoundError, ValueError)):
+        az._as_text("catalog.tle", fetch=fetch)                       # a file name that does not exist is not a group name
+    assert len(seen) == 2
+
+
+def test_orbital_scalars_report_a_missing_device():
+    """The four closed-form scalars run on the device like every floating-point path: without one the Python wrappers raise
+    NativeError (not ValueError, not NaN); with one they return the reference's values (src/calculations.zig L83-125)."""
+    import astroz_amd as az
+    from astroz_amd import _native
+    if _native.device_count() == 0:
+        for call in (lambda: az.orbital_velocity(az.EARTH_MU, 7000.0), lambda: az.orbital_period(az.EARTH_MU, 7000.0),
+                     lambda: az.escape_velocity(az.EARTH_MU, 7000.0), lambda: az.hohmann_transfer(az.EARTH_MU, 7000.0, 42164.0)):
+            with pytest.raises(_native.NativeError):
+                call()
+    else:
+        assert abs(az.orbital_velocity(az.EARTH_MU, 7000.0) - (az.EARTH_MU / 7000.0) ** 0.5) < 1e-12
+    with pytest.raises(ValueError):
+        az.orbital_velocity(az.EARTH_MU, -1.0)                        # argument errors stay ValueError either way
+    with pytest.raises(ValueError):
+        az.hohmann_transfer(az.EARTH_MU, 7000.0, 7000.5)
