@@ -89,6 +89,9 @@ def _as_text(source, norad_id=None, fetch=None, allow_network=False):
         return source
     one_line = "\n" not in source and len(source) < 4096
     if one_line and source.lower().startswith(("http://", "https://")):
+        if source.lower().startswith("http://"):
+            import warnings
+            warnings.warn("element sets fetched over plain http are not authenticated: prefer https", stacklevel=3)
         return _download(source, fetch, allow_network)
     if one_line and os.path.isfile(source):
         with open(source, "r", encoding="utf-8") as fh:

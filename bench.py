@@ -410,7 +410,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             _native.set_host_copy_threads(-1)
             ms = sorted(ws)[len(ws) // 2]
             out_bytes = r_.nbytes + v_.nbytes + e_.nbytes
-            ent.update({"ms_per_step": ms, "value": n2 * 1440 / (ms / 1e3), "unit": "propagations/s (host arrays, PCIe-inclusive)",
+            ent.update({"ms_per_step": ms, "min_ms": min(ws), "value": n2 * 1440 / (ms / 1e3), "unit": "propagations/s (host arrays, PCIe-inclusive)",
                         "n_sats": n2, "n_times": 1440, "calls_ms": ws, "d2h_GB_per_s_of_wall": out_bytes / (ms / 1e3) / 1e9,
                         "path": arr._dev.last_path(),
                         "direct_pageable_copy_ms": sorted(ws0)[len(ws0) // 2],
@@ -563,6 +563,9 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             dev5.close()
         except Exception as exc:
             res.append({"key": "config5_share", "failed": repr(exc)})
+    # the entries for the reference's own call shapes go LAST (a record that keeps only the tail of this line keeps them)
+    last = ["config2_time_major", "config2_sat_major_jdfr", "config2_time_major_jdfr", "api_host"]
+    res.sort(key=lambda e: last.index(e["key"]) if e.get("key") in last else -1)
     return res
 
 
