@@ -366,3 +366,51 @@ def test_api_hygiene_round4(native, orc, synth):
     _, p0, _ = orc.Catalog.from_pairs(pairs, 1).propagate(t, full, velocities=False)
     assert np.abs(pos - p0).max() < TOL_R
     grp.close()
+
+
+def test_quasi_uniform_forms_ragged_long_and_windowed(native, orc, synth):
+    """The quasi-uniform forms away from the benchmark shape: ragged grid lengths (not a multiple of 64; shorter than a
+    segment), a 10,000-step (jd, fr) grid a week long (seven-day windows: the plan's bounds, the redo pass), two-minute and
+    backwards steps, row windows (the chunked multi-GPU launches) on a (jd, fr) grid, padded time-major strides."""
+    import torch
+    pairs = synth.synth_catalog(n_near=400, n_deep=30, seed=23)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+
+    def check(jd, fr, tol_r=TOL_R, tol_v=TOL_V, want_fast=True):
+        times, off, _ = api_times(jd, fr, dev.epochs)
+        n = len(times)
+        e0, p0, v0 = cat.propagate(times, off, threads=8)
+        for layout in (native.SAT_MAJOR, native.TIME_MAJOR):
+            shape = (dev.n, n, 3) if layout == native.SAT_MAJOR else (n, dev.n, 3)
+            pos, vel = np.empty(shape), np.empty(shape)
+            err = np.zeros((dev.n, n), dtype=np.uint8)
+            dev.propagate_host(times, off, pos=pos, vel=vel, err=err, layout=layout)
+            if want_fast and n >= 64:
+                assert dev.last_path() & native.PATH_QUASI_UNIFORM, (n, layout, dev.last_path())
+            if layout == native.TIME_MAJOR:
+                pos, vel = pos.transpose(1, 0, 2), vel.transpose(1, 0, 2)
+            assert np.array_equal(err, e0)
+            assert np.abs(pos - p0).max() < tol_r and np.abs(vel - v0).max() < tol_v, (n, layout, np.abs(pos - p0).max())
+
+    day = synth.START_JD
+    for n in (65, 100, 777, 1441):
+        check(np.full(n, day), 0.1234567 + np.arange(n) / 1440.0)
+    check(np.full(10000, day - 2.0), 0.5 + np.arange(10000) / 1440.0)                      # a week, one-minute steps
+    check(np.full(900, day), 0.75 + np.arange(900) / 720.0)                               # two-minute steps across midnight
+    check(np.full(900, day + 1.0), 0.4 - np.arange(900) / 1440.0)                         # backwards
+    check(day + np.floor(np.arange(3000) / 1440.0), (np.arange(3000) % 1440) / 1440.0)    # jd steps by whole days, fr wraps
+    # row windows on a (jd, fr) grid == one launch, bit for bit, both layouts
+    n = 500
+    times, off, _ = api_times(np.full(n, day), 0.3 + np.arange(n) / 1440.0, dev.epochs)
+    for layout, shape in ((native.SAT_MAJOR, (dev.n, n, 3)), (native.TIME_MAJOR, (n, dev.n + 3, 3))):
+        stride = dev.n + 3 if layout == native.TIME_MAJOR else 0
+        full = torch.full(shape, float("nan"), dtype=torch.float64, device="cuda")
+        part = torch.full_like(full, float("nan"))
+        torch.cuda.synchronize()
+        dev.propagate_device(times, off, full.data_ptr(), None, layout=layout, stride=stride)
+        for lo, hi in ((0, 7), (7, 130), (130, 131), (131, 10**6)):
+            dev.propagate_device_window(lo, hi, part.data_ptr(), None, layout=layout, stride=stride)
+        dev.synchronize()
+        assert dev.last_path() & native.PATH_QUASI_UNIFORM
+        assert torch.equal(torch.nan_to_num(full, nan=-1.0), torch.nan_to_num(part, nan=-1.0))
