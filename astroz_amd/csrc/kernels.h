@@ -884,6 +884,17 @@ __device__ __forceinline__ void az_flush_stage(const T *stage, const AzRowSink &
         }
     }
 }
+// The row a workgroup of the lane = time row kernels takes (grid: x = rows rounded up to a multiple of 8, y = time segments).
+// Workgroup b runs on XCD b % 8, and gridDim.x is a multiple of 8: the low three bits of blockIdx.x ARE the XCD.  The rows are
+// dealt out in eight contiguous ranges, one per XCD (k_rows).  With a handful of rows and a long time series that alone would
+// leave most XCDs idle -- one satellite x 10^7 times ran on ONE of the eight (0.54 ms; 0.30 ms through k_one_satellite) -- so
+// there the ranges rotate with the time segment: segment y of range j runs on XCD (j - y) mod 8.
+__device__ __forceinline__ unsigned az_xcd_row()
+{
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned range = per_xcd <= 8u ? ((blockIdx.x + blockIdx.y) & 7u) : (blockIdx.x & 7u);
+    return range * per_xcd + (blockIdx.x >> 3);
+}
 // one wave's work on a row segment, shared by the two row kernels: where a finished iteration goes
 template <bool VEL, class out_t>
 __device__ __forceinline__ void az_rows_store(bool staged, bool full, bool live, unsigned lane, out_t *stage, out_t *prow,
@@ -926,8 +937,7 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
 {
     typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
     const unsigned lane = threadIdx.x;
-    const unsigned per_xcd = gridDim.x >> 3; // XCD-aware row assignment, see k_rows
-    const unsigned row = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const unsigned row = az_xcd_row(); // XCD-aware row assignment, see k_rows
     if (row >= p.n_list) return;
     const unsigned s = p.list[row]; // wave-uniform
     if (SINK != AZ_SINK_SCREEN && ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi)) return;
@@ -1081,7 +1091,7 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
     double *cold_lds = cold_all + w * AZ_FAST_TABLE;
     // XCD-aware tile assignment (workgroup b runs on XCD b % 8; gridDim.x is a multiple of 8): every XCD takes a contiguous
     // range of tiles, so the cache lines that two neighbouring tiles share at the ends of their 384-byte runs meet in ONE L2
-    const unsigned tile_id = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const unsigned tile_id = az_xcd_row(); // (a handful of tiles: rotated over the XCDs with the time segment, like the rows)
     // A tile is 16 consecutive CATALOG rows, whatever they are: a near-earth member is computed here; a deep-space member was
     // computed by k_rows_deep into the compact scratch array just before and is copied through (a coalesced 1.5-KB read per
     // wave and iteration); a member whose initialisation failed is zeros.  So every tile is a run of consecutive rows and
@@ -1273,8 +1283,7 @@ template <bool VEL, bool MIXED = false, bool DELTA = false> // MIXED: az_sgp4_fa
 __global__ void __launch_bounds__(64, MIXED ? AZ_ROWSF32P_WAVES : AZ_ROWSF32_WAVES) k_rows_fast32(PropArgs p)
 {
     const unsigned lane = threadIdx.x;
-    const unsigned per_xcd = gridDim.x >> 3; // XCD-aware row assignment, see k_rows
-    const unsigned row = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const unsigned row = az_xcd_row(); // XCD-aware row assignment, see k_rows
     if (row >= p.n_list) return;
     const unsigned s = p.list[row];
     const unsigned fl = p.flags[s];
@@ -1418,8 +1427,7 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
         // XCD-aware row assignment: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the
         // rows are dealt out in eight contiguous ranges -- every XCD then reads one eighth of the SoA
         // element table (8 satellites share each 64-B line) instead of all of it
-        const unsigned per_xcd = gridDim.x >> 3; // gridDim.x is a multiple of 8
-        row = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+        row = az_xcd_row(); // (gridDim.x is a multiple of 8)
         if (row >= p.n_list) return;
         // blockIdx.y: time segment of p.tile grid points (a multiple of 64) -- splits long rows so that
         // the grid has enough waves to fill the chip several times over
@@ -1548,8 +1556,7 @@ __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
     typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
     constexpr unsigned TL = 512;
     const unsigned lane = threadIdx.x;
-    const unsigned per_xcd = gridDim.x >> 3; // XCD-aware row assignment, see k_rows
-    const unsigned row = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const unsigned row = az_xcd_row(); // XCD-aware row assignment, see k_rows
     if (row >= p.n_list) return;
     const unsigned s = p.list[row];
     const unsigned fl = p.flags[s];

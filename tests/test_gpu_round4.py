@@ -414,3 +414,35 @@ def test_quasi_uniform_forms_ragged_long_and_windowed(native, orc, synth):
         dev.synchronize()
         assert dev.last_path() & native.PATH_QUASI_UNIFORM
         assert torch.equal(torch.nan_to_num(full, nan=-1.0), torch.nan_to_num(part, nan=-1.0))
+
+
+@pytest.mark.parametrize("n_near,n_deep", [(1, 0), (5, 2), (40, 3), (64, 0)])
+def test_few_rows_long_series_rotate_over_the_xcds(native, orc, synth, n_near, n_deep):
+    """A handful of satellites x a long time series: the lane = time kernels deal their rows out in eight ranges, one per XCD,
+    and with at most 64 rows rotate the ranges by time segment (kernels.h az_xcd_row: one satellite x 10^7 times otherwise
+    runs on one XCD of eight).  Every (row, segment) pair must still be computed exactly once: all rows x 40,000 steps
+    against the oracle, both layouts, exact and (jd, fr) grids, every output element written."""
+    pairs = synth.synth_catalog(n_near=n_near, n_deep=n_deep, seed=31)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    n = 40_000
+    day = synth.START_JD
+    grids = [(np.arange(n) * 0.25, (day - dev.epochs) * 1440.0)]
+    t_, o_, _ = api_times(np.full(n, day), 0.25 + np.arange(n) / 5760.0, dev.epochs)
+    grids.append((t_, o_))
+    pick = np.unique(np.concatenate([np.arange(0, n, 997), np.arange(0, 200), np.arange(n - 200, n), np.arange(639, n, 640)[:50],
+                                     np.arange(640, n, 640)[:50]]))
+    for times, off in grids:
+        e0, p0, v0 = cat.propagate(times[pick], off, threads=8)
+        for layout in (native.SAT_MAJOR, native.TIME_MAJOR):
+            shape = (dev.n, n, 3) if layout == native.SAT_MAJOR else (n, dev.n, 3)
+            pos, vel = np.full(shape, np.nan), np.full(shape, np.nan)
+            err = np.zeros((dev.n, n), dtype=np.uint8)
+            dev.propagate_host(times, off, pos=pos, vel=vel, err=err, layout=layout)
+            assert dev.last_path() & (native.PATH_ROWS_FAST | native.PATH_TILES_FAST), dev.last_path()
+            assert not np.isnan(pos).any() and not np.isnan(vel).any(), (layout, "an output element was left unwritten")
+            if layout == native.TIME_MAJOR:
+                pos, vel = pos.transpose(1, 0, 2), vel.transpose(1, 0, 2)
+            assert np.array_equal(err[:, pick], e0)
+            assert np.abs(pos[:, pick] - p0).max() < TOL_R and np.abs(vel[:, pick] - v0).max() < TOL_V, (
+                layout, np.abs(pos[:, pick] - p0).max(), np.abs(vel[:, pick] - v0).max())
