@@ -1007,9 +1007,17 @@ def main():
                                              skip=tuple(k for k in a.secondary_skip.split(",") if k))
         except Exception as exc:   # never takes the headline down
             out["secondary"] = [{"failed": repr(exc)}]
-    print(json.dumps(out))
     if world > 1 or a.force_sharded:
         dist.destroy_process_group()
+    # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio, which (redirected to a file or
+    # a pipe) sits in the C buffer until the process ends -- flush it first
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
