@@ -756,34 +756,36 @@ AZ_DEVICE void az_to_ecef(double p[3], double sg, double cg)
     p[1] = y;
 }
 
-// ECEF -> (lat rad, lon rad, alt km), WGS84: the reference's fixed-point iteration lat <- atan2(z + e2 N(lat) sin lat, rho)
-// (src/WorldCoordinateSystem.zig L98-121: <= 10 trips, exit once the latitude moves by less than 1e-12), carried on the
-// (sin,cos) PAIR of the latitude -- (sin,cos) of atan2(Z, rho) is (Z, rho) / hypot(Z, rho): no atan2 and no sin inside the
-// loop -- for a fixed six trips (the map contracts by e2 = 0.0067 per trip: 3e-3 -> 3e-16, inside the reference's own exit
-// tolerance), then ONE polynomial atan2 each for the latitude and the longitude.  ~230 instructions and no branch instead
-// of libm's atan2 / sin / cos a dozen times over (~2,000).
+// ECEF -> (lat rad, lon rad, alt km), WGS84.  The reference iterates lat <- atan2(z + e2 N(lat) sin lat, rho) to a fixed point
+// (src/WorldCoordinateSystem.zig L98-121: <= 10 trips, exit once the latitude moves by less than 1e-12; the map contracts by
+// e2 = 0.0067 per trip).  The same latitude comes out of Bowring's form on the PARAMETRIC latitude beta, tan beta = (1 - f)
+// tan lat:  tan lat = (z + e'2 b sin^3 beta) / (rho - e2 a cos^3 beta), which converges cubically -- from beta0 =
+// atan2(z, (1 - f) rho) the formula alone is good to 8e-9 rad, after ONE refinement of beta to 2e-16 at every altitude from
+// 150 to 80,000 km (checked against long-double arithmetic) -- and is carried on (sin,cos) pairs: (sin,cos) of atan2(Y, X) is
+// (Y, X) / hypot(Y, X), so there is no trigonometric call before the ONE polynomial atan2 each for latitude and longitude.
+// Three reciprocal square roots and ~25 multiply-adds in place of round 3's six fixed-point trips (twelve rsqrt): ~130
+// instructions instead of ~230.  Altitude as the reference forms it: rho / cos(lat) - N.
 AZ_DEVICE void az_ecef_to_geodetic(double p[3])
 {
     const double f = 1.0 / 298.257223563;
     const double e2 = 2.0 * f - f * f;
     const double a = 6378.137;
+    const double omf = 1.0 - f;
+    const double ep2b = e2 / (1.0 - e2) * (a * omf), e2a = e2 * a; // e'^2 b, e^2 a
     const double x = p[0], y = p[1], z = p[2];
     const double rho2 = fma(x, x, y * y);
     const double rho = rho2 * az_rsqrt(fmax(rho2, 1.0e-300));
-    // lat0 = atan2(z, rho (1 - e2))
-    double Z = z, R = rho * (1.0 - e2);
-    double ih = az_rsqrt(fmax(fma(Z, Z, R * R), 1.0e-300));
-    double s = Z * ih, c;
-    double N = a;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        N = a * az_rsqrt(fma(-e2 * s, s, 1.0));
-        Z = fma(e2 * N, s, z);
-        ih = az_rsqrt(fmax(fma(Z, Z, rho2), 1.0e-300));
-        s = Z * ih;
-    }
-    c = rho * ih;
-    N = a * az_rsqrt(fma(-e2 * s, s, 1.0));
+    double sb = z, cb = omf * rho;                                      // beta0
+    double ih = az_rsqrt(fmax(fma(sb, sb, cb * cb), 1.0e-300));
+    sb *= ih; cb *= ih;
+    double num = fma(ep2b * sb * sb, sb, z), den = fma(-e2a * cb * cb, cb, rho);
+    sb = omf * num; cb = den;                                           // beta1
+    ih = az_rsqrt(fmax(fma(sb, sb, cb * cb), 1.0e-300));
+    sb *= ih; cb *= ih;
+    num = fma(ep2b * sb * sb, sb, z); den = fma(-e2a * cb * cb, cb, rho);
+    ih = az_rsqrt(fmax(fma(num, num, den * den), 1.0e-300));
+    const double s = num * ih, c = den * ih;                            // (sin,cos) of the latitude
+    const double N = a * az_rsqrt(fma(-e2 * s, s, 1.0));
     p[0] = az_atan2(s, c);
     p[1] = az_atan2(y, x);
     p[2] = rho * az_rcp(fmax(c, 6.123233995736766e-17)) - N; // (cos(pi/2) in fp64, the reference's divisor on the axis)

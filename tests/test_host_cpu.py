@@ -544,8 +544,9 @@ def test_empty_and_malformed_inputs_are_rejected_before_any_device_work():
 
 
 def test_emulated_geodetic_and_atan2(emul, orc):
-    """devmath's polynomial atan2 against libm, and the pair-form ECEF -> geodetic conversion (six fixed trips of the
-    reference's fixed-point iteration, src/WorldCoordinateSystem.zig L98-121) against the oracle's restatement of it."""
+    """devmath's polynomial atan2 against libm, and the pair-form ECEF -> geodetic conversion (Bowring's form on the parametric
+    latitude, one refinement: the fixed point of the reference's iteration, src/WorldCoordinateSystem.zig L98-121) against the
+    oracle's restatement of that iteration."""
     emul.emul_atan2.restype = C.c_double
     emul.emul_atan2.argtypes = [C.c_double, C.c_double]
     rng = np.random.default_rng(12)
@@ -565,7 +566,8 @@ def test_emulated_geodetic_and_atan2(emul, orc):
         v = rng.normal(size=3)
         e = r * v / np.linalg.norm(v)
         if rng.random() < 0.05:
-            e[:2] *= 1e-4          # near the axis
+            e[:2] *= 1e-4          # near the axis, at the same radius (Bowring's form and the reference's iteration agree
+            e *= r / np.linalg.norm(e)   # to rounding from the surface outwards; deep inside the Earth neither means anything)
         q = e.copy()
         emul.emul_geodetic(q.ctypes.data)
         ref = np.zeros(3)
