@@ -797,10 +797,22 @@ def main():
     # config 4, host-returning consumers (the C-host route, azh_group_propagate_host): ONE process, all N devices, every
     # device copies its shard straight into the caller's catalog-ordered host arrays over its own PCIe link -- no collective.
     # The one case where sharding this path pays: the call is PCIe-bound (16.4 ms for 932 MB over one link).  Rank 0 only,
-    # after the timed region, the other ranks idle at the barrier.
+    # after the timed region and after the other ranks have gone.
+    # Every collective is behind us: all ranks leave the process group HERE, together, and ranks != 0 exit -- rank 0 does the rest
+    # (group_host on all devices, oracle parity, the secondary block) alone, with no communicator alive and no peer process
+    # holding a GPU in a barrier kernel.
+    if world > 1 or a.force_sharded:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
     group_host = None
     if sharded:
-        if rank == 0:
+        box = {}
+
+        def _group_host():
             try:
                 text = "\n".join(x + "\n" + y for x, y in allp)
                 devs = list(range(world)) if world > 1 else [local_rank]
@@ -816,19 +828,23 @@ def main():
                     gp, gv = res_[0], res_[1]
                     del res_
                 gms = sorted(ws[1:])[len(ws[1:]) // 2]
-                group_host = {"ms_per_call": gms, "calls_ms": ws, "devices": len(devs), "value": n_total * n_times / (gms / 1e3),
-                              "GB_per_s": (gp.nbytes + (gv.nbytes if gv is not None else 0)) / (gms / 1e3) / 1e9,
-                              "what": "azh_group_propagate_host: one process, N devices, fresh host arrays each call; wall clock"}
+                box["r"] = {"ms_per_call": gms, "calls_ms": ws, "devices": len(devs), "value": n_total * n_times / (gms / 1e3),
+                            "GB_per_s": (gp.nbytes + (gv.nbytes if gv is not None else 0)) / (gms / 1e3) / 1e9,
+                            "what": "azh_group_propagate_host: one process, N devices, fresh host arrays each call; wall clock"}
                 del gp, gv
                 grp.close()
             except Exception as exc:
-                group_host = {"failed": repr(exc)}
-        if world > 1:
-            dist.barrier()
+                box["r"] = {"failed": repr(exc)}
 
-    if rank != 0:
-        dist.destroy_process_group()
-        return
+        # (a watchdog: this is an extra, it must never take the headline line down with it)
+        import threading
+        th = threading.Thread(target=_group_host, daemon=True)
+        th.start()
+        th.join(timeout=120.0)
+        group_host = box.get("r", {"failed": "timed out after 120 s"})
+        group_host_stuck = th.is_alive()
+    else:
+        group_host_stuck = False
 
     props_per_step = n_total * n_times
     value = props_per_step * a.steps / elapsed
@@ -1007,8 +1023,6 @@ def main():
                                              skip=tuple(k for k in a.secondary_skip.split(",") if k))
         except Exception as exc:   # never takes the headline down
             out["secondary"] = [{"failed": repr(exc)}]
-    if world > 1 or a.force_sharded:
-        dist.destroy_process_group()
     # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio, which (redirected to a file or
     # a pipe) sits in the C buffer until the process ends -- flush it first
     try:
@@ -1018,6 +1032,8 @@ def main():
         pass
     sys.stdout.flush()
     print(json.dumps(out), flush=True)
+    if group_host_stuck:
+        os._exit(0)   # (a stuck extra must not keep the process alive)
 
 
 if __name__ == "__main__":
