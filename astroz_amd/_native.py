@@ -31,7 +31,7 @@ EXPORTS = [
     "azh_num_satellites", "azh_num_sgp4", "azh_num_sdp4", "azh_get_epochs", "azh_get_status",
     "azh_get_field", "azh_propagate_host", "azh_propagate_device", "azh_propagate_device_cached", "azh_propagate_device_window",
     "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile", "azh_set_timing", "azh_set_fast_path", "azh_set_tile_kernel", "azh_set_f32_arithmetic", "azh_set_f32_mode",
-    "azh_last_kernel_ms", "azh_last_path", "azh_set_host_copy_threads", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
+    "azh_last_kernel_ms", "azh_last_path", "azh_last_one_stats", "azh_set_host_copy_threads", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
     "azh_screen_target_host", "azh_screen_target_device", "azh_coarse_screen_device", "azh_coarse_screen_host",
     "azh_screen_all_host", "azh_constellation_from_omm_json", "azh_propagate_one_device", "azh_selftest_math",
     "azh_parse_tle_text", "azh_parse_omm_json", "azh_set_parse_threads", "coords_julian_to_gmst",
@@ -194,6 +194,8 @@ def lib():
     L.azh_set_host_copy_threads.restype = None
     L.azh_last_path.argtypes = [vp]
     L.azh_last_path.restype = u32
+    L.azh_last_one_stats.argtypes = [vp, vp, vp]
+    L.azh_last_one_stats.restype = C.c_int32
     L.azh_propagate_device_f32.argtypes = L.azh_propagate_device.argtypes
     L.azh_propagate_device_f32.restype = i32
     L.azh_propagate_device_cached_f32.argtypes = L.azh_propagate_device_cached.argtypes
@@ -454,6 +456,14 @@ class DeviceConstellation:
     def last_path(self):
         """AZH_PATH_* bits (PATH_* below): which kernel families the most recent call launched."""
         return int(lib().azh_last_path(self._h))
+
+    def last_one_stats(self):
+        """The most recent propagate_one / propagate_one_device call: (segments of 1,024 points the branch-free kernel was
+        launched on, segments it handed over to the generic kernel); (0, 0) when the call took the generic kernel throughout.
+        Waits for the call to finish."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        check(lib().azh_last_one_stats(self._h, C.byref(a), C.byref(b)), "azh_last_one_stats")
+        return int(a.value), int(b.value)
 
 
 class DeviceGroup:

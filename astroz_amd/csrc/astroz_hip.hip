@@ -167,6 +167,9 @@ struct azh_constellation {
     // that a scalar call costs one small H2D, one launch, one D2H and one synchronisation -- no allocation
     DevBuf<double> d_one_t, d_one_o;
     DevBuf<unsigned char> d_one_e;
+    DevBuf<unsigned> d_one_items; // k_one_fast -> k_one_satellite hand-over list (count, then segment indices)
+    unsigned one_segments = 0;     // segments of the most recent one-satellite call that k_one_fast was launched on (azh_last_one_stats)
+    hipStream_t one_stream = nullptr;
     void *h_stage = nullptr; // pinned host staging for small calls (kOneStage points)
     HostStager stager;       // pinned staging slots of the host-returning calls (copy_back_staged), allocated on first use
     bool seeds_valid = false; // resonance seeds match the staged times/offsets and tile
@@ -228,6 +231,7 @@ void destroy(azh_constellation *c)
     c->d_one_t.release();
     c->d_one_o.release();
     c->d_one_e.release();
+    c->d_one_items.release();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     c->stager.release();
     c->d_mask.release();
@@ -1131,6 +1135,43 @@ unsigned host_copy_threads()
     return std::min(6u, std::max(1u, std::thread::hardware_concurrency() / 2));
 }
 
+// one satellite x n times, times and outputs in device memory: long series of a near-earth member take k_one_fast (every wave
+// tries the branch-free step on its 1,024 points) with k_one_satellite behind it for what that hands over; short ones, the
+// c_api's interleaved layout and deep-space members take k_one_satellite (one generic step per point) directly
+#ifndef AZ_ONE_FAST
+#define AZ_ONE_FAST 1
+#endif
+int32_t launch_one(azh_constellation *c, size_t sat, const double *d_t, size_t n, double *d_p, double *d_v, unsigned char *d_e,
+                   int interleaved, hipStream_t st)
+{
+    const unsigned f = sat < c->h_flags.size() ? c->h_flags[sat] : ~0u;
+    const bool fast = AZ_ONE_FAST && !interleaved && n >= 8192 && f != ~0u && AZ_FLAG_ERR(f) == 0 && !(f & AZ_FLAG_DEEP);
+    c->one_segments = 0;
+    c->one_stream = st;
+    if (fast) {
+        const unsigned n_seg = (unsigned)((n + AZ_ONE_SEG - 1) / AZ_ONE_SEG);
+        if (c->d_one_items.ensure((size_t)n_seg + 1) != AZ_OK) return AZ_ERR_HIP;
+        c->one_segments = n_seg;
+        HIP_TRY(hipMemsetAsync(c->d_one_items.p, 0, sizeof(unsigned), st));
+        if (d_v)
+            hipLaunchKernelGGL((k_one_fast<true>), dim3(n_seg), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad, (unsigned)sat, d_t,
+                               (unsigned)n, d_p, d_v, d_e, c->g, (const double *)nullptr, c->d_one_items.p);
+        else
+            hipLaunchKernelGGL((k_one_fast<false>), dim3(n_seg), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad, (unsigned)sat, d_t,
+                               (unsigned)n, d_p, d_v, d_e, c->g, (const double *)nullptr, c->d_one_items.p);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL((k_one_satellite<true>), dim3(std::min(4096u, n_seg * (unsigned)(AZ_ONE_SEG / 64))), dim3(64), 0, st, c->d_el,
+                           c->d_flags, c->n_pad, (unsigned)sat, d_t, (unsigned)n, d_p, d_v, d_e, 0, c->g, (const double *)nullptr, 0,
+                           (const unsigned *)c->d_one_items.p);
+    } else {
+        hipLaunchKernelGGL((k_one_satellite<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
+                           (unsigned)sat, d_t, (unsigned)n, d_p, d_v, d_e, interleaved, c->g, (const double *)nullptr, 0,
+                           (const unsigned *)nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    return AZ_OK;
+}
+
 constexpr size_t kOneStage = 1024; // points served through the pinned staging buffer
 
 // one satellite x n times.  interleaved = 1: out6 is n x 6 (x,y,z,vx,vy,vz; c_api batch layout); otherwise
@@ -1154,10 +1195,9 @@ int32_t run_one_satellite(azh_constellation *c, size_t sat, const double *tsince
     } else {
         HIP_TRY(hipMemcpyAsync(c->d_one_t.p, tsince, sizeof(double) * n, hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL(k_one_satellite, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
-                       (unsigned)sat, c->d_one_t.p, (unsigned)n, d_p, interleaved ? (double *)nullptr : d_v,
-                       interleaved ? (unsigned char *)nullptr : c->d_one_e.p, interleaved, c->g, (const double *)nullptr, 0);
-    HIP_TRY(hipGetLastError());
+    if (int32_t lrc = launch_one(c, sat, c->d_one_t.p, n, d_p, interleaved ? (double *)nullptr : d_v,
+                                 interleaved ? (unsigned char *)nullptr : c->d_one_e.p, interleaved, st); lrc != AZ_OK)
+        return lrc;
     int32_t rc = AZ_OK;
     if (staged) {
         if (!hip_ok(hipMemcpyAsync(hs_o, c->d_one_o.p, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, st), "D2H") ||
@@ -1518,7 +1558,7 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
     HIP_TRY(hipGetLastError());
     if (nt > 0) {
         if (c->d_tgt.ensure((size_t)nt * 3) != AZ_OK) return AZ_ERR_HIP;
-        hipLaunchKernelGGL(k_one_satellite, dim3((nt + 63) / 64), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
+        hipLaunchKernelGGL((k_one_satellite<false>), dim3((nt + 63) / 64), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
                            (unsigned)target, c->d_times.p, nt, c->d_tgt.p, (double *)nullptr, (unsigned char *)nullptr, 0,
                            c->g, c->have_offsets ? c->d_offsets.p : (const double *)nullptr, 1);
         HIP_TRY(hipGetLastError());
@@ -1880,6 +1920,20 @@ int32_t azh_synchronize(azh_constellation *c)
 
 uint32_t azh_last_path(const azh_constellation *c) { return c ? c->last_path : 0u; }
 
+int32_t azh_last_one_stats(azh_constellation *c, uint32_t *n_segments, uint32_t *n_handed_over)
+{
+    if (!c || !n_segments || !n_handed_over) return AZ_ERR_NULL_POINTER;
+    *n_segments = c->one_segments;
+    *n_handed_over = 0;
+    if (c->one_segments == 0) return AZ_OK;
+    if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    HIP_TRY(hipStreamSynchronize(c->one_stream));
+    unsigned cnt = 0;
+    HIP_TRY(hipMemcpy(&cnt, c->d_one_items.p, sizeof(unsigned), hipMemcpyDeviceToHost));
+    *n_handed_over = cnt;
+    return AZ_OK;
+}
+
 double azh_last_kernel_ms(azh_constellation *c)
 {
     if (!c || !c->timed) return -1.0;
@@ -1909,9 +1963,7 @@ int32_t azh_propagate_one_device(azh_constellation *c, size_t sat, const double 
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->s_main;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
-    hipLaunchKernelGGL(k_one_satellite, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
-                       (unsigned)sat, d_tsince, (unsigned)n, d_pos, d_vel, d_err, 0, c->g, (const double *)nullptr, 0);
-    HIP_TRY(hipGetLastError());
+    if (int32_t lrc = launch_one(c, sat, d_tsince, n, d_pos, d_vel, d_err, 0, st); lrc != AZ_OK) return lrc;
     if (c->timing) {
         HIP_TRY(hipEventRecord(c->ev_t1, st));
         c->timed = true;

@@ -124,8 +124,9 @@ struct FastCarry {
 // which = 0: dt = 64 grid steps (lane = time kernels), 1: dt = one grid step (lane = satellite kernels)
 enum { AZ_INC_sdA, AZ_INC_cdA, AZ_INC_sdW, AZ_INC_cdW, AZ_INC_NUM };
 
-AZ_DEVICE void az_load_fast(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags,
-                            const double *__restrict__ inc, int which, FastK &k)
+// everything of a FastK but the window constants; (sdA, cdA), (sdW, cdW): the increments of M and W over one lane step
+AZ_DEVICE void az_load_fast_with(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags, double sdA, double cdA,
+                                 double sdW, double cdW, FastK &k)
 {
 #define L(f) el[(size_t)F_##f * n_pad + i]
     const bool ho = !(flags & AZ_FLAG_ISIMP);
@@ -145,13 +146,20 @@ AZ_DEVICE void az_load_fast(const double *__restrict__ el, size_t n_pad, size_t 
     az_j2_factors(L(con41), L(x1mth2), L(x7thm1), k.sinio_, k.cosio_, k.k_mrt_, k.k_c2u_, k.k_su_, k.k_node_,
                   k.k_inc_, k.k_rv_);
     k.x1mth2_ = L(x1mth2);
-    const double *q = inc + (size_t)(AZ_INC_NUM * which) * n_pad + i;
-    k.sdA_ = q[(size_t)AZ_INC_sdA * n_pad]; k.cdA_ = q[(size_t)AZ_INC_cdA * n_pad];
-    k.sdW_ = q[(size_t)AZ_INC_sdW * n_pad]; k.cdW_ = q[(size_t)AZ_INC_cdW * n_pad];
+    k.sdA_ = sdA; k.cdA_ = cdA;
+    k.sdW_ = sdW; k.cdW_ = cdW;
     k.nodedot_ = L(nodedot);
     k.mdot_ = L(mdot); k.argpdot_ = L(argpdot);
     k.udot_ = k.mdot_ + k.argpdot_; // (tc = 0; az_fast_udot once the window's tc is known)
 #undef L
+}
+// ... with the increments k_prep_inc tabulated for the staged grid
+AZ_DEVICE void az_load_fast(const double *__restrict__ el, size_t n_pad, size_t i, unsigned flags,
+                            const double *__restrict__ inc, int which, FastK &k)
+{
+    const double *q = inc + (size_t)(AZ_INC_NUM * which) * n_pad + i;
+    az_load_fast_with(el, n_pad, i, flags, q[(size_t)AZ_INC_sdA * n_pad], q[(size_t)AZ_INC_cdA * n_pad], q[(size_t)AZ_INC_sdW * n_pad],
+                      q[(size_t)AZ_INC_cdW * n_pad], k);
 }
 // rate of the carried phase U about the window centre tc (DELTA: the first-order correction of U)
 AZ_DEVICE void az_fast_udot(FastK &k) { k.udot_ = fma(2.0 * k.nl2_, k.tc_, k.mdot_ + k.argpdot_); }

@@ -572,13 +572,22 @@ __global__ void __launch_bounds__(64) k_deep_seed(const double *el, const unsign
 // one satellite x many times: lane = time, the satellite's constants are wave-uniform.  Every
 // evaluation is a 'first' step (full sincos seeds); deep-space lanes integrate the resonance from
 // epoch themselves, like the reference's sdp4Times8 (src/Sdp4.zig L1105-1128).
+#define AZ_ONE_SEG 1024 /* points per wave of k_one_fast; k_one_satellite's item list counts in these */
+// items (may be null): [0] = number of segments, [1 + k] = segment index -- only the points of the listed AZ_ONE_SEG-point
+// segments are produced (what k_one_fast handed over), by workgroups striding over (segment, 64-point block) pairs
+template <bool ITEMS = false> // (a separate instantiation: the item loop costs the plain form 48 VGPRs)
 __global__ void __launch_bounds__(64) k_one_satellite(const double *el, const unsigned *flags,
                                                             size_t n_pad, unsigned sat, const double *tsince,
                                                             unsigned n, double *pos, double *vel,
                                                             unsigned char *err, int interleaved, AzGrav g,
-                                                            const double *offsets, int nan_on_error)
+                                                            const double *offsets, int nan_on_error, const unsigned *items = nullptr)
 {
-    const unsigned i = blockIdx.x * 64 + threadIdx.x;
+    const unsigned n_work = ITEMS ? items[0] * (AZ_ONE_SEG / 64u) : 1u;
+#pragma unroll 1
+    for (unsigned w = ITEMS ? blockIdx.x : 0u; w < n_work; w += ITEMS ? gridDim.x : 1u) {
+    const unsigned i = ITEMS ? items[1u + w / (AZ_ONE_SEG / 64u)] * AZ_ONE_SEG + (w % (AZ_ONE_SEG / 64u)) * 64u + threadIdx.x
+                             : blockIdx.x * 64 + threadIdx.x;
+    if (ITEMS && i - threadIdx.x >= n) continue; // (the last segment's blocks past the end)
     const double t = tsince[i < n ? i : n - 1] + (offsets ? offsets[sat] : 0.0);
     const unsigned fl = flags[sat];
     double r[3], v[3];
@@ -616,6 +625,7 @@ __global__ void __launch_bounds__(64) k_one_satellite(const double *el, const un
             if (vel) { vel[(size_t)i * 3] = v[0]; vel[(size_t)i * 3 + 1] = v[1]; vel[(size_t)i * 3 + 2] = v[2]; }
         }
         if (err) err[i] = (unsigned char)rc;
+    }
     }
 }
 
@@ -911,6 +921,84 @@ __device__ __forceinline__ void az_rows_store(bool staged, bool full, bool live,
         az_put3_stream(prow + (size_t)(base + lane) * 3, r);
         if (VEL) az_put3_stream(vrow + (size_t)(base + lane) * 3, v);
     }
+}
+
+// ONE SATELLITE x MANY TIMES, the times in device memory (azh_propagate_one_device / _host, sgp4_propagate_batch).
+// Nothing on the host has seen the times, so every wave finds out for itself: it takes AZ_ONE_SEG consecutive points, fits the
+// ideal grid t0 + i step through its first and last time and measures the deviations; if they stay inside the tight
+// quasi-uniform form (fast_step.h, DELTA = 1: what arange, linspace and jd + fr arithmetic produce) and the window passes
+// the fast step's validation bounds, the wave sets the branch-free step up by itself -- the increments of a lane step (two
+// sincos), the window constants (one or two), its seeds (two or three): the work k_prep_inc / k_prep_rec / k_plan_windows do
+// once per staged grid for the constellation kernels, ~600 instructions here against sixteen iterations of ~205 -- and
+// runs it; otherwise (irregular times, a short tail, a window the bounds reject, an eccentric member whose Newton
+// validation fails, deep space) the segment goes onto a list that k_one_satellite, launched behind, works off point by
+// point with the generic step (~600 instructions and full sincos seeds per point: 0.29 ms for 10^7 points).
+// The constants stay where the compiler puts them (uniform values in vector registers: this kernel runs at 3 waves/SIMD).
+template <bool VEL>
+__global__ void __launch_bounds__(64, 3) k_one_fast(const double *el, const unsigned *flags, size_t n_pad, unsigned sat,
+                                                    const double *tsince, unsigned n, double *pos, double *vel, unsigned char *err,
+                                                    AzGrav g, const double *offsets, unsigned *items)
+{
+    const unsigned lane = threadIdx.x, seg = blockIdx.x, lo = seg * AZ_ONE_SEG;
+    const unsigned cnt = min((unsigned)AZ_ONE_SEG, n - lo);
+    const unsigned fl = flags[sat];
+    __shared__ float dl_lds[AZ_ONE_SEG];
+    __shared__ __attribute__((aligned(16))) double rows_stage[2 * 64 * 3];
+    const double off = az_uniform(offsets ? offsets[sat] : 0.0);
+    const bool ecc = AZ_FLAG_ECLASS(fl) != 0; // wave-uniform
+    bool ok = AZ_FLAG_ERR(fl) == 0 && !(fl & AZ_FLAG_DEEP) && cnt >= 128u;
+    double t0 = 0.0, step = 0.0;
+    FastK k;
+    if (ok) {
+        t0 = az_uniform(tsince[lo]) + off;
+        step = ((az_uniform(tsince[lo + cnt - 1]) + off) - t0) / (double)(cnt - 1u);
+        bool far = false;
+#pragma unroll 4
+        for (unsigned j = lane; j < (unsigned)AZ_ONE_SEG; j += 64u) {
+            const unsigned jj = min(j, cnt - 1u);
+            const double d = (tsince[lo + jj] + off) - fma((double)jj, step, t0);
+            dl_lds[j] = (float)d;
+            far |= !(fabs(d) <= AZ_DELTA_MAX); // (NaN: far)
+        }
+        // (the window may not outgrow the window-centred constants either: fast_window_cap on the host side)
+        ok = !az_any(far) && step != 0.0 && fabs(step) * (double)cnt <= 3000.0;
+    }
+    if (ok) {
+#define L(f) el[(size_t)F_##f * n_pad + sat]
+        double sdA, cdA, sdW, cdW;
+        az_sincos(L(mdot) * (64.0 * step), sdA, cdA);
+        az_sincos(L(argpdot) * (64.0 * step), sdW, cdW);
+#undef L
+        az_load_fast_with(el, n_pad, sat, fl, sdA, cdA, sdW, cdW, k);
+        const double w_a = t0, w_b = fma((double)(cnt - 1u), step, t0);
+        az_fast_window(el, n_pad, sat, w_a, w_b, 64.0 * step, k);
+        ok = ecc ? az_fast_window_ok<true>(k, g, w_a, w_b, AZ_DELTA_MAX) : az_fast_window_ok<false>(k, g, w_a, w_b, AZ_DELTA_MAX);
+    }
+    if (ok) {
+        FastCarry fc;
+        az_seed_fast(el, n_pad, sat, fma((double)lane - 64.0, step, t0), k.tc_, fc); // one lane step before the lane's first point
+        double *prow = pos + (size_t)lo * 3, *vrow = VEL ? vel + (size_t)lo * 3 : nullptr;
+        const bool staged = ((reinterpret_cast<size_t>(prow) | (VEL ? reinterpret_cast<size_t>(vrow) : 0)) & 15u) == 0;
+        const AzRowSink sink = az_row_sink(prow, vrow, cnt);
+        az_wave_lds_fence();
+#pragma unroll 1
+        for (unsigned base = 0; base < cnt; base += 64u) {
+            const unsigned i = base + lane;
+            const bool live = i < cnt;
+            const double dl = (double)dl_lds[i]; // (i < AZ_ONE_SEG always; past cnt the entry is the last point's)
+            const double t = fma((double)i, step, t0) + dl;
+            double r[3], v[3];
+            const bool bad = ecc ? az_sgp4_fast_step<VEL, true, 1>(k, g, RotCoefLit(), t, fc, r, v, dl)
+                                 : az_sgp4_fast_step<VEL, false, 1>(k, g, RotCoefLit(), t, fc, r, v, dl);
+            if (az_any(bad && live)) { // (eccentric form only) the generic kernel redoes the whole segment
+                ok = false;
+                break;
+            }
+            az_rows_store<VEL>(staged, base + 64u <= cnt, live, lane, rows_stage, prow, vrow, base, r, v, sink);
+            if (err && live) err[lo + i] = 0;
+        }
+    }
+    if (!ok && lane == 0) items[1u + atomicAdd(items, 1u)] = seg;
 }
 
 // Near-earth rows on a UNIFORM grid: the branch-free step of fast_step.h, one wave per (satellite row, time

@@ -469,7 +469,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             ent["failed"] = repr(exc)
         res.append(ent)
     if "one_satellite" not in skip:
-        ent = {"key": "one_satellite", "kernel": "k_one_satellite",
+        ent = {"key": "one_satellite", "kernel": "k_one_fast (every wave fits its own 1,024 points; k_one_satellite behind it for what it hands over)",
                "workload": "one satellite (ISS-like, near-earth) x 10,000,000 times through azh_propagate_one_device: device-resident "
                            "tsince in, pos+vel out (reference: 30.8 M/s single-thread sgp4_array, README.md L25-33)"}
         try:
@@ -479,6 +479,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             ve = torch.empty((n, 3), dtype=torch.float64, device=cuda)
             ms = timed(lambda: dev2.propagate_one_device(0, ts.data_ptr(), n, po.data_ptr(), ve.data_ptr(), None, sptr), 2, 5)
             nbytes = n * 56.0
+            ent["segments_fast_handed_over"] = list(dev2.last_one_stats())
             ent.update({"ms_per_step": ms, "value": n / (ms / 1e3), "unit": "propagations/s",
                         "roofline": {"bound": "hbm", "achieved": nbytes / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}})

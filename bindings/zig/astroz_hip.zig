@@ -119,6 +119,7 @@ pub extern "c" fn azh_set_fast_path(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_set_tile_kernel(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_set_host_copy_threads(n: i32) void; // host threads behind the pinned staging of host-returning copies (-1 auto, 0 = direct pageable copies)
 pub extern "c" fn azh_last_path(h: ?*const Handle) u32; // AZH_PATH_* bits: which kernel families the last call launched
+pub extern "c" fn azh_last_one_stats(h: ?*Handle, n_segments: ?*u32, n_handed_over: ?*u32) i32; // last one-satellite call: fast segments / handed over
 pub extern "c" fn azh_propagate_one_device(h: ?*Handle, sat_index: usize, d_tsince_min: [*]const f64, n: usize, d_pos: [*]f64,
     d_vel: ?[*]f64, d_err: ?[*]u8, stream: ?*anyopaque) i32;
 pub extern "c" fn azh_selftest_math(x: [*]const f64, n: usize, out6n: [*]f64, device: i32) i32;

@@ -359,6 +359,11 @@ double azh_last_kernel_ms(azh_constellation *c);
 #define AZH_PATH_DEEP_ROWS 16u    /* k_rows_deep: lane = time deep-space rows */
 #define AZH_PATH_QUASI_UNIFORM 32u /* the staged grid is quasi-uniform: the fast kernels ran in their DELTA form */
 uint32_t azh_last_path(const azh_constellation *c);
+/* the most recent one-satellite call of this handle (azh_propagate_one_host / _device; sgp4_propagate / _batch through their
+ * handles): the number of 1,024-point segments the branch-free kernel was launched on (0: the series was short, interleaved,
+ * deep-space or failed -- one generic step per point throughout) and how many of them it handed over to the generic kernel
+ * (irregular times, a window outside the fast step's bounds).  Waits for that call to finish.  Returns an astroz error code. */
+int32_t azh_last_one_stats(azh_constellation *c, uint32_t *n_segments, uint32_t *n_handed_over);
 
 #ifdef __cplusplus
 }

@@ -446,3 +446,69 @@ def test_few_rows_long_series_rotate_over_the_xcds(native, orc, synth, n_near, n
             assert np.array_equal(err[:, pick], e0)
             assert np.abs(pos[:, pick] - p0).max() < TOL_R and np.abs(vel[:, pick] - v0).max() < TOL_V, (
                 layout, np.abs(pos[:, pick] - p0).max(), np.abs(vel[:, pick] - v0).max())
+
+
+def test_one_satellite_long_series_fast_and_handed_over_segments(native, orc, synth):
+    """azh_propagate_one_host / _device on long series (k_one_fast: every wave fits a grid through its own 1,024 points and runs
+    the branch-free step where they are (quasi-)uniform and the window passes the bounds; k_one_satellite works off the rest):
+    uniform, (jd, fr)-rounded, backwards, irregular, half-and-half, ragged tails, windows too long for the fast step, an
+    eccentric and a deep-space member, positions only -- every point against the oracle at the times given."""
+    import torch
+    pairs = synth.synth_catalog(n_near=600, n_deep=8, seed=41)
+    dev_all = native.DeviceConstellation.from_tle_lines(pairs, 1, 0)
+    ecc = dev_all.field("ecco")
+    _, deep, _ = dev_all.status
+    near = np.flatnonzero(~deep)
+    picks = {"leo": int(near[0]), "ecc": int(near[np.argmax(ecc[near])]), "deep": int(np.flatnonzero(deep)[0])}
+    assert ecc[picks["ecc"]] > 0.05
+    rng = np.random.default_rng(5)
+    n = 40_000 + 77                      # (39 whole segments of 1,024 and a tail of 141)
+    day = synth.START_JD
+    jd, fr = np.full(n, day), 0.2 + np.arange(n) / 86400.0
+    grids = {
+        "uniform": 3.0 + np.arange(n) * 0.05,
+        "jdfr": ((jd + fr) - (jd[0] + fr[0])) * 1440.0 + 100.0,
+        "backwards": 2000.0 - np.arange(n) * 0.07,
+        "irregular": np.sort(rng.uniform(0.0, 3000.0, n)),
+        "half": np.concatenate([np.arange(n // 2) * 0.1, np.sort(rng.uniform(3000.0, 4000.0, n - n // 2))]),
+        "long_windows": np.arange(n) * 5.0,            # 5,120 minutes per segment: the fast step's window cap says no
+        "short": np.arange(8200) * 0.5,                # just over the threshold for the fast launch, tail of 8 points
+    }
+    for name, s in picks.items():
+        dev = native.DeviceConstellation.from_tle_lines([pairs[s]], 1, 0)
+        cat = orc.Catalog.from_pairs([pairs[s]], 1)
+        for gname, ts in grids.items():
+            m = len(ts)
+            sel = np.unique(np.concatenate([np.arange(0, m, 211), np.arange(m - 300, m), np.arange(1023, m, 1024), np.arange(1024, m, 1024),
+                                            np.arange(m // 2 - 70, m // 2 + 70)]))
+            e0, p0, v0 = cat.propagate(ts[sel], None, layout=orc.SAT_MAJOR)
+            e, r, v = dev.propagate_one(0, ts)
+            segs, handed = dev.last_one_stats()
+            want_segs = 0 if name == "deep" else (m + 1023) // 1024
+            assert segs == want_segs, (name, gname, segs)
+            if name != "deep":
+                # what took the branch-free kernel: all of a (quasi-)uniform series but a short tail; none of an irregular one
+                if gname in ("uniform", "jdfr", "backwards"):
+                    assert handed == 0, (name, gname, handed)
+                elif gname == "short":
+                    assert handed == 1, (name, gname, handed)        # the 8-point tail
+                elif gname == "irregular":
+                    assert handed == segs, (name, gname, handed)
+                elif gname == "long_windows":
+                    assert handed == segs - 1, (name, gname, handed)  # (the 141-point tail spans 705 minutes: inside the cap)
+                else:
+                    assert segs // 2 - 1 <= handed <= segs // 2 + 2, (name, gname, handed, segs)
+            assert np.array_equal(e[sel], e0[0]), (name, gname)
+            assert not e.any() or name == "deep" or gname == "long_windows", (name, gname)
+            good = e0[0] == 0
+            assert np.abs(r[sel][good] - p0[0][good]).max() < TOL_R and np.abs(v[sel][good] - v0[0][good]).max() < TOL_V, (
+                name, gname, np.abs(r[sel][good] - p0[0][good]).max(), np.abs(v[sel][good] - v0[0][good]).max())
+            # the device-pointer entry, positions only, every element written
+            dts = torch.as_tensor(ts, device="cuda")
+            dp = torch.full((m, 3), float("nan"), dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            dev.propagate_one_device(0, dts.data_ptr(), m, dp.data_ptr(), None, None)
+            dev.synchronize()
+            hp = dp.cpu().numpy()
+            assert not np.isnan(hp).any(), (name, gname)
+            assert np.array_equal(hp, r), (name, gname, "positions-only and pos+vel calls disagree")
