@@ -468,6 +468,33 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
         except Exception as exc:
             ent["failed"] = repr(exc)
         res.append(ent)
+    if "screen_all" not in skip:
+        ent = {"key": "screen_all", "kernel": "k_tiles_fast / k_propagate + the cell-list screen kernels (azh_screen_all_host)",
+               "workload": "config 2 catalog, all-vs-all conjunction screen (SURVEY 8 f3; bindings/python/astroz/__init__.py L535-658, "
+                           "bindings/python/src/conjunction.zig L152-260): every pair closer than 10 km at any of 120 one-minute "
+                           "steps, propagate + spatial hash on the GPU, the positions never leave HBM; host wall clock per call"}
+        try:
+            times = np.arange(120, dtype=np.float64)
+            offs = (synth.START_JD - dev2.epochs) * 1440.0
+            ws = []
+            for _ in range(4):
+                t0 = time.perf_counter()
+                pr, tt = dev2.screen_all(times, 10.0, offs)
+                ws.append((time.perf_counter() - t0) * 1e3)
+            ms = sorted(ws[1:])[len(ws[1:]) // 2]
+            ent.update({"ms_per_step": ms, "calls_ms": ws, "value": dev2.n * len(times) / (ms / 1e3), "unit": "propagations/s screened",
+                        "pairs_found": int(len(tt))})
+            # parity: the same screen by the oracle on the first 24 steps (propagate + its own cell list), as sets of (t, i, j)
+            cat = oracle.Catalog.from_pairs(pairs2, oracle.WGS72)
+            _, rp, _ = cat.propagate(times[:24], offs, layout=oracle.SAT_MAJOR, velocities=False)
+            pr0, tt0 = oracle.coarse_screen(rp, 10.0)
+            keep = np.asarray(tt) < 24
+            got = set(zip(np.asarray(tt)[keep].tolist(), np.asarray(pr)[keep, 0].tolist(), np.asarray(pr)[keep, 1].tolist()))
+            want = set(zip(np.asarray(tt0).tolist(), np.asarray(pr0)[:, 0].tolist(), np.asarray(pr0)[:, 1].tolist()))
+            ent["parity"] = {"steps": 24, "pairs": len(want), "missing": len(want - got), "extra": len(got - want)}
+        except Exception as exc:
+            ent["failed"] = repr(exc)
+        res.append(ent)
     if "one_satellite" not in skip:
         ent = {"key": "one_satellite", "kernel": "k_one_fast (every wave fits its own 1,024 points; k_one_satellite behind it for what it hands over)",
                "workload": "one satellite (ISS-like, near-earth) x 10,000,000 times through azh_propagate_one_device: device-resident "
