@@ -1150,19 +1150,19 @@ int32_t launch_one(azh_constellation *c, size_t sat, const double *d_t, size_t n
     c->one_stream = st;
     if (fast) {
         const unsigned n_seg = (unsigned)((n + AZ_ONE_SEG - 1) / AZ_ONE_SEG);
-        if (c->d_one_items.ensure((size_t)n_seg + 1) != AZ_OK) return AZ_ERR_HIP;
+        const unsigned cap = (n_seg + AZ_ONE_LISTS - 1) / AZ_ONE_LISTS; // capacity of each of the AZ_ONE_LISTS hand-over lists
+        if (c->d_one_items.ensure((size_t)AZ_ONE_HEAD + (size_t)cap * AZ_ONE_LISTS) != AZ_OK) return AZ_ERR_HIP;
         c->one_segments = n_seg;
-        HIP_TRY(hipMemsetAsync(c->d_one_items.p, 0, sizeof(unsigned), st));
+        HIP_TRY(hipMemsetAsync(c->d_one_items.p, 0, sizeof(unsigned) * AZ_ONE_HEAD, st));
         if (d_v)
             hipLaunchKernelGGL((k_one_fast<true>), dim3(n_seg), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad, (unsigned)sat, d_t,
-                               (unsigned)n, d_p, d_v, d_e, c->g, (const double *)nullptr, c->d_one_items.p);
+                               (unsigned)n, d_p, d_v, d_e, c->g, (const double *)nullptr, c->d_one_items.p, cap);
         else
             hipLaunchKernelGGL((k_one_fast<false>), dim3(n_seg), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad, (unsigned)sat, d_t,
-                               (unsigned)n, d_p, d_v, d_e, c->g, (const double *)nullptr, c->d_one_items.p);
+                               (unsigned)n, d_p, d_v, d_e, c->g, (const double *)nullptr, c->d_one_items.p, cap);
         HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL((k_one_satellite<true>), dim3(std::min(4096u, n_seg * (unsigned)(AZ_ONE_SEG / 64))), dim3(64), 0, st, c->d_el,
-                           c->d_flags, c->n_pad, (unsigned)sat, d_t, (unsigned)n, d_p, d_v, d_e, 0, c->g, (const double *)nullptr, 0,
-                           (const unsigned *)c->d_one_items.p);
+        hipLaunchKernelGGL((k_one_satellite<true>), dim3(4096), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad, (unsigned)sat, d_t,
+                           (unsigned)n, d_p, d_v, d_e, 0, c->g, (const double *)nullptr, 0, (const unsigned *)c->d_one_items.p, cap);
     } else {
         hipLaunchKernelGGL((k_one_satellite<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
                            (unsigned)sat, d_t, (unsigned)n, d_p, d_v, d_e, interleaved, c->g, (const double *)nullptr, 0,
@@ -1928,8 +1928,10 @@ int32_t azh_last_one_stats(azh_constellation *c, uint32_t *n_segments, uint32_t 
     if (c->one_segments == 0) return AZ_OK;
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(c->one_stream));
+    std::vector<unsigned> head(AZ_ONE_HEAD);
+    HIP_TRY(hipMemcpy(head.data(), c->d_one_items.p, sizeof(unsigned) * AZ_ONE_HEAD, hipMemcpyDeviceToHost));
     unsigned cnt = 0;
-    HIP_TRY(hipMemcpy(&cnt, c->d_one_items.p, sizeof(unsigned), hipMemcpyDeviceToHost));
+    for (unsigned k = 0; k < AZ_ONE_LISTS; ++k) cnt += head[32u * k];
     *n_handed_over = cnt;
     return AZ_OK;
 }

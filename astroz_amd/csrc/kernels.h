@@ -572,20 +572,29 @@ __global__ void __launch_bounds__(64) k_deep_seed(const double *el, const unsign
 // one satellite x many times: lane = time, the satellite's constants are wave-uniform.  Every
 // evaluation is a 'first' step (full sincos seeds); deep-space lanes integrate the resonance from
 // epoch themselves, like the reference's sdp4Times8 (src/Sdp4.zig L1105-1128).
-#define AZ_ONE_SEG 1024 /* points per wave of k_one_fast; k_one_satellite's item list counts in these */
-// items (may be null): [0] = number of segments, [1 + k] = segment index -- only the points of the listed AZ_ONE_SEG-point
-// segments are produced (what k_one_fast handed over), by workgroups striding over (segment, 64-point block) pairs
-template <bool ITEMS = false> // (a separate instantiation: the item loop costs the plain form 48 VGPRs)
-__global__ void __launch_bounds__(64) k_one_satellite(const double *el, const unsigned *flags,
-                                                            size_t n_pad, unsigned sat, const double *tsince,
+#define AZ_ONE_SEG 1024 /* points per wave of k_one_fast; k_one_satellite's item lists count in these */
+// The hand-over lists of k_one_fast: AZ_ONE_LISTS of them (a segment goes onto list seg mod AZ_ONE_LISTS), each with its own
+// counter on its own 128-byte line -- ten thousand waves pushing onto ONE list head with an atomic each took as long as the
+// arithmetic they had skipped (118 us for an all-irregular series of 10^7 points; spread over 64 heads: 16 us).
+// items[32 k] = length of list k; items[AZ_ONE_HEAD + k cap + j] = its j-th segment index.
+#define AZ_ONE_LISTS 64u
+#define AZ_ONE_HEAD (32u * AZ_ONE_LISTS)
+// items (ITEMS only): only the points of the listed AZ_ONE_SEG-point segments are produced (what k_one_fast handed over);
+// workgroup b works on list b mod AZ_ONE_LISTS, striding over its (segment, 64-point block) pairs; gridDim.x is a multiple
+// of AZ_ONE_LISTS
+template <bool ITEMS = false> // (a separate instantiation: the item loop costs the plain form registers)
+__global__ void __launch_bounds__(64) k_one_satellite(const double *__restrict__ el, const unsigned *__restrict__ flags,
+                                                            size_t n_pad, unsigned sat, const double *__restrict__ tsince,
                                                             unsigned n, double *pos, double *vel,
                                                             unsigned char *err, int interleaved, AzGrav g,
-                                                            const double *offsets, int nan_on_error, const unsigned *items = nullptr)
+                                                            const double *__restrict__ offsets, int nan_on_error,
+                                                            const unsigned *__restrict__ items = nullptr, unsigned list_cap = 0)
 {
-    const unsigned n_work = ITEMS ? items[0] * (AZ_ONE_SEG / 64u) : 1u;
+    const unsigned sub = ITEMS ? (blockIdx.x % AZ_ONE_LISTS) : 0u;
+    const unsigned n_work = ITEMS ? items[32u * sub] * (AZ_ONE_SEG / 64u) : 1u;
 #pragma unroll 1
-    for (unsigned w = ITEMS ? blockIdx.x : 0u; w < n_work; w += ITEMS ? gridDim.x : 1u) {
-    const unsigned i = ITEMS ? items[1u + w / (AZ_ONE_SEG / 64u)] * AZ_ONE_SEG + (w % (AZ_ONE_SEG / 64u)) * 64u + threadIdx.x
+    for (unsigned w = ITEMS ? blockIdx.x / AZ_ONE_LISTS : 0u; w < n_work; w += ITEMS ? gridDim.x / AZ_ONE_LISTS : 1u) {
+    const unsigned i = ITEMS ? items[AZ_ONE_HEAD + sub * list_cap + w / (AZ_ONE_SEG / 64u)] * AZ_ONE_SEG + (w % (AZ_ONE_SEG / 64u)) * 64u + threadIdx.x
                              : blockIdx.x * 64 + threadIdx.x;
     if (ITEMS && i - threadIdx.x >= n) continue; // (the last segment's blocks past the end)
     const double t = tsince[i < n ? i : n - 1] + (offsets ? offsets[sat] : 0.0);
@@ -937,7 +946,7 @@ __device__ __forceinline__ void az_rows_store(bool staged, bool full, bool live,
 template <bool VEL>
 __global__ void __launch_bounds__(64, 3) k_one_fast(const double *el, const unsigned *flags, size_t n_pad, unsigned sat,
                                                     const double *tsince, unsigned n, double *pos, double *vel, unsigned char *err,
-                                                    AzGrav g, const double *offsets, unsigned *items)
+                                                    AzGrav g, const double *offsets, unsigned *items, unsigned list_cap)
 {
     const unsigned lane = threadIdx.x, seg = blockIdx.x, lo = seg * AZ_ONE_SEG;
     const unsigned cnt = min((unsigned)AZ_ONE_SEG, n - lo);
@@ -998,7 +1007,10 @@ __global__ void __launch_bounds__(64, 3) k_one_fast(const double *el, const unsi
             if (err && live) err[lo + i] = 0;
         }
     }
-    if (!ok && lane == 0) items[1u + atomicAdd(items, 1u)] = seg;
+    if (!ok && lane == 0) {
+        const unsigned sub = seg % AZ_ONE_LISTS;
+        items[AZ_ONE_HEAD + sub * list_cap + atomicAdd(items + 32u * sub, 1u)] = seg;
+    }
 }
 
 // Near-earth rows on a UNIFORM grid: the branch-free step of fast_step.h, one wave per (satellite row, time

@@ -507,6 +507,14 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             ms = timed(lambda: dev2.propagate_one_device(0, ts.data_ptr(), n, po.data_ptr(), ve.data_ptr(), None, sptr), 2, 5)
             nbytes = n * 56.0
             ent["segments_fast_handed_over"] = list(dev2.last_one_stats())
+            # the same count of sorted RANDOM times: every segment is handed over to the generic kernel (one full step per point)
+            tr = torch.sort(torch.rand(n, dtype=torch.float64, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3)) * 14400.0).values
+            ms_irr = timed(lambda: dev2.propagate_one_device(0, tr.data_ptr(), n, po.data_ptr(), ve.data_ptr(), None, sptr), 1, 3)
+            ent["irregular_times"] = {"ms_per_step": ms_irr, "value": n / (ms_irr / 1e3), "segments_fast_handed_over": list(dev2.last_one_stats()),
+                                      "frac": nbytes / (ms_irr / 1e3) / 1e9 / HBM_PEAK_GBS}
+            dev2.propagate_one_device(0, ts.data_ptr(), n, po.data_ptr(), ve.data_ptr(), None, sptr)   # (po / ve: the uniform series again, for the parity below)
+            torch.cuda.synchronize()
+            del tr
             ent.update({"ms_per_step": ms, "value": n / (ms / 1e3), "unit": "propagations/s",
                         "roofline": {"bound": "hbm", "achieved": nbytes / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": nbytes / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}})
