@@ -512,3 +512,8 @@ def test_one_satellite_long_series_fast_and_handed_over_segments(native, orc, sy
             hp = dp.cpu().numpy()
             assert not np.isnan(hp).any(), (name, gname)
             assert np.array_equal(hp, r), (name, gname, "positions-only and pos+vel calls disagree")
+            if gname == "uniform":
+                # the same member addressed inside the 608-satellite handle: bit for bit the 1-satellite handle's result
+                e2, r2, v2 = dev_all.propagate_one(s, ts)
+                assert dev_all.last_one_stats() == (segs, handed)
+                assert np.array_equal(e2, e) and np.array_equal(r2, r) and np.array_equal(v2, v), (name, gname)
