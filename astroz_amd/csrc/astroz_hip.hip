@@ -170,7 +170,8 @@ struct azh_constellation {
     DevBuf<unsigned> d_one_items; // k_one_fast -> k_one_satellite hand-over list (count, then segment indices)
     unsigned one_segments = 0;     // segments of the most recent one-satellite call that k_one_fast was launched on (azh_last_one_stats)
     hipStream_t one_stream = nullptr;
-    void *h_stage = nullptr; // pinned host staging for small calls (kOneStage points)
+    void *h_stage = nullptr; // pinned host staging for small one-satellite calls: h_stage_cap points (grows to kOneStage)
+    size_t h_stage_cap = 0;
     HostStager stager;       // pinned staging slots of the host-returning calls (copy_back_staged), allocated on first use
     bool seeds_valid = false; // resonance seeds match the staged times/offsets and tile
     unsigned seeds_tile = 0;
@@ -1136,16 +1137,20 @@ unsigned host_copy_threads()
 }
 
 // one satellite x n times, times and outputs in device memory: long series of a near-earth member take k_one_fast (every wave
-// tries the branch-free step on its 1,024 points) with k_one_satellite behind it for what that hands over; short ones, the
+// tries the branch-free step on its 1,024 points) with k_one_satellite behind it for what that hands over; shorter ones, the
 // c_api's interleaved layout and deep-space members take k_one_satellite (one generic step per point) directly
 #ifndef AZ_ONE_FAST
 #define AZ_ONE_FAST 1
 #endif
+// (a wave of k_one_fast works through its 1,024 points one 64-point iteration after the other: ~40 us whatever the length of
+// the series, and a memset and a second launch come with it -- below about a million points the generic kernel, one point per
+// lane and all of them at once, is done sooner: 10^6 points 32 us against 28)
+constexpr size_t kOneFastMin = size_t(1) << 20;
 int32_t launch_one(azh_constellation *c, size_t sat, const double *d_t, size_t n, double *d_p, double *d_v, unsigned char *d_e,
                    int interleaved, hipStream_t st)
 {
     const unsigned f = sat < c->h_flags.size() ? c->h_flags[sat] : ~0u;
-    const bool fast = AZ_ONE_FAST && !interleaved && n >= 8192 && f != ~0u && AZ_FLAG_ERR(f) == 0 && !(f & AZ_FLAG_DEEP);
+    const bool fast = AZ_ONE_FAST && !interleaved && n >= kOneFastMin && f != ~0u && AZ_FLAG_ERR(f) == 0 && !(f & AZ_FLAG_DEEP);
     c->one_segments = 0;
     c->one_stream = st;
     if (fast) {
@@ -1172,7 +1177,17 @@ int32_t launch_one(azh_constellation *c, size_t sat, const double *d_t, size_t n
     return AZ_OK;
 }
 
-constexpr size_t kOneStage = 1024; // points served through the pinned staging buffer
+// One-satellite calls of up to this many points go through a pinned staging buffer of the handle (it starts at 1,024 points
+// and doubles on demand: a Satrec that only ever asks for one point holds 64 KB).  Pageable copies of a few KB cost ~20 us
+// each: 1,440 points (BASELINE config 1's shape) took 68 us against 26 us for 1,024.
+#ifndef AZ_ONE_ZERO_COPY
+#define AZ_ONE_ZERO_COPY 1
+#endif
+#ifndef AZ_ONE_ZERO_COPY_MAX
+#define AZ_ONE_ZERO_COPY_MAX 16384
+#endif
+constexpr size_t kOneStage = 16384;
+constexpr size_t kOneZeroCopy = AZ_ONE_ZERO_COPY_MAX; // points the kernel exchanges with the pinned buffer directly
 
 // one satellite x n times.  interleaved = 1: out6 is n x 6 (x,y,z,vx,vy,vz; c_api batch layout); otherwise
 // pos (n x 3), vel (n x 3, optional), err (n, optional).
@@ -1184,11 +1199,44 @@ int32_t run_one_satellite(azh_constellation *c, size_t sat, const double *tsince
     hipStream_t st = c->s_main;
     if (c->d_one_t.ensure(n) != AZ_OK || c->d_one_o.ensure(6 * n) != AZ_OK || c->d_one_e.ensure(n) != AZ_OK) return AZ_ERR_HIP;
     const bool staged = n <= kOneStage;
-    if (staged && !c->h_stage) HIP_TRY(hipHostMalloc(&c->h_stage, kOneStage * (7 * sizeof(double) + 8), hipHostMallocDefault));
+    if (staged && c->h_stage_cap < n) {
+        size_t cap = std::max<size_t>(c->h_stage_cap, 1024);
+        while (cap < n) cap *= 2;
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->h_stage = nullptr;
+        c->h_stage_cap = 0;
+        HIP_TRY(hipHostMalloc(&c->h_stage, cap * (7 * sizeof(double) + 8), hipHostMallocDefault));
+        c->h_stage_cap = cap;
+    }
+    const size_t scap = c->h_stage_cap;
     double *hs_t = static_cast<double *>(c->h_stage);
-    double *hs_o = hs_t ? hs_t + kOneStage : nullptr;
-    uint8_t *hs_e = hs_o ? reinterpret_cast<uint8_t *>(hs_o + 6 * kOneStage) : nullptr;
+    double *hs_o = hs_t ? hs_t + scap : nullptr;
+    uint8_t *hs_e = hs_o ? reinterpret_cast<uint8_t *>(hs_o + 6 * scap) : nullptr;
     double *d_p = c->d_one_o.p, *d_v = c->d_one_o.p + 3 * n;
+    // A handful of points: the kernel reads the times from and writes its results into the pinned buffer ITSELF (host memory
+    // the device can address: coherent by default) -- one launch and one synchronize instead of three copy commands around it
+    // (a single point 26 -> 19 us; 1,440 points, BASELINE config 1's shape, 68 -> 21 us = 67 M propagations/s through
+    // Satrec.sgp4_array; 16,000 points 109 -> 74 us).
+    const bool zero_copy = AZ_ONE_ZERO_COPY && staged && n <= kOneZeroCopy;
+    if (zero_copy) {
+        memcpy(hs_t, tsince, sizeof(double) * n);
+        double *dev_t = nullptr;
+        HIP_TRY(hipHostGetDevicePointer((void **)&dev_t, hs_t, 0));
+        double *dev_o = dev_t + (hs_o - hs_t);
+        unsigned char *dev_e = reinterpret_cast<unsigned char *>(dev_t) + (reinterpret_cast<char *>(hs_e) - reinterpret_cast<char *>(hs_t));
+        if (int32_t lrc = launch_one(c, sat, dev_t, n, dev_o, interleaved ? (double *)nullptr : dev_o + 3 * n,
+                                     interleaved ? (unsigned char *)nullptr : dev_e, interleaved, st); lrc != AZ_OK)
+            return lrc;
+        if (!hip_ok(hipStreamSynchronize(st), "sync")) return AZ_ERR_HIP;
+        if (interleaved) {
+            memcpy(out6, hs_o, sizeof(double) * 6 * n);
+        } else {
+            memcpy(pos, hs_o, sizeof(double) * 3 * n);
+            if (vel) memcpy(vel, hs_o + 3 * n, sizeof(double) * 3 * n);
+            if (err) memcpy(err, hs_e, n);
+        }
+        return AZ_OK;
+    }
     if (staged) {
         memcpy(hs_t, tsince, sizeof(double) * n);
         HIP_TRY(hipMemcpyAsync(c->d_one_t.p, hs_t, sizeof(double) * n, hipMemcpyHostToDevice, st));

@@ -462,17 +462,17 @@ def test_one_satellite_long_series_fast_and_handed_over_segments(native, orc, sy
     picks = {"leo": int(near[0]), "ecc": int(near[np.argmax(ecc[near])]), "deep": int(np.flatnonzero(deep)[0])}
     assert ecc[picks["ecc"]] > 0.05
     rng = np.random.default_rng(5)
-    n = 40_000 + 77                      # (39 whole segments of 1,024 and a tail of 141)
+    n = (1 << 20) + 77 + 64              # (just over the fast launch's threshold: 1,024 whole segments of 1,024 and a tail of 141)
     day = synth.START_JD
-    jd, fr = np.full(n, day), 0.2 + np.arange(n) / 86400.0
+    jd, fr = np.full(n, day), 0.2 + np.arange(n) / 864000.0
     grids = {
-        "uniform": 3.0 + np.arange(n) * 0.05,
+        "uniform": 3.0 + np.arange(n) * 0.002,
         "jdfr": ((jd + fr) - (jd[0] + fr[0])) * 1440.0 + 100.0,
-        "backwards": 2000.0 - np.arange(n) * 0.07,
+        "backwards": 2000.0 - np.arange(n) * 0.003,
         "irregular": np.sort(rng.uniform(0.0, 3000.0, n)),
-        "half": np.concatenate([np.arange(n // 2) * 0.1, np.sort(rng.uniform(3000.0, 4000.0, n - n // 2))]),
-        "long_windows": np.arange(n) * 5.0,            # 5,120 minutes per segment: the fast step's window cap says no
-        "short": np.arange(8200) * 0.5,                # just over the threshold for the fast launch, tail of 8 points
+        "half": np.concatenate([np.arange(n // 2) * 0.004, np.sort(rng.uniform(3000.0, 4000.0, n - n // 2))]),
+        "long_windows": (np.arange(n) % 1024) * 5.0,    # every 1,024-point segment spans 5,120 minutes: the window cap says no
+        "short_tail": 5.0 + np.arange((1 << 20) + 8) * 0.001,   # a tail of 8 points
     }
     for name, s in picks.items():
         dev = native.DeviceConstellation.from_tle_lines([pairs[s]], 1, 0)
@@ -490,7 +490,7 @@ def test_one_satellite_long_series_fast_and_handed_over_segments(native, orc, sy
                 # what took the branch-free kernel: all of a (quasi-)uniform series but a short tail; none of an irregular one
                 if gname in ("uniform", "jdfr", "backwards"):
                     assert handed == 0, (name, gname, handed)
-                elif gname == "short":
+                elif gname == "short_tail":
                     assert handed == 1, (name, gname, handed)        # the 8-point tail
                 elif gname == "irregular":
                     assert handed == segs, (name, gname, handed)
