@@ -380,6 +380,45 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
          dev2, pairs2, 1440, layout=SM, mode=1, ref_jd=ref_jd)
     case("config2_geodetic_time_major", "config 2, geodetic (lat, lon [rad], alt km) time-major, positions only",
          "k_propagate<time-major,pos,FRAME> (lane = satellite)", dev2, pairs2, 1440, layout=TM, vel=False, mode=2, ref_jd=ref_jd, steps=10)
+    if "config1" not in skip:
+        ent = {"key": "config1", "kernel": "k_one_satellite (the kernel reads the times from and writes into a pinned buffer itself) / "
+                                            "the constellation kernels on a 1-satellite catalog",
+               "workload": "BASELINE config 1: the ISS TLE x 1,440 one-minute steps through the Python API mirror (examples/python_sgp4.py "
+                           "L31-33): Satrec.sgp4_array(jd, fr), SatrecArray([sat]).sgp4(jd, fr) and 1,440 scalar Satrec.sgp4 calls; host "
+                           "wall clock per call, host arrays in and out (reference: 30.8 M/s single-thread sgp4_array, README.md L25-33)"}
+        try:
+            from astroz_amd.api import Satrec, SatrecArray, WGS72
+            l1 = "1 25544U 98067A   24127.82853009  .00015698  00000+0  27310-3 0  9995"
+            l2 = "2 25544  51.6393 160.4574 0003580 140.6673 205.7250 15.50957674452123"
+            sat = Satrec.twoline2rv(l1, l2, WGS72)
+            jd = np.full(1440, sat.jdsatepoch)
+            fr = sat.jdsatepochF + np.arange(1440) / 1440.0
+
+            def wall(fn, k):
+                for _ in range(max(3, k // 10)):
+                    fn()
+                t0 = time.perf_counter()
+                for _ in range(k):
+                    fn()
+                return (time.perf_counter() - t0) / k * 1e6
+            us_arr = wall(lambda: sat.sgp4_array(jd, fr), 300)
+            sa = SatrecArray([sat], device=cuda.index or 0)
+            us_sa = wall(lambda: sa.sgp4(jd, fr), 200)
+            us_one = wall(lambda: sat.sgp4(jd[0], fr[7]), 500)
+            e_, r_, v_ = sat.sgp4_array(jd, fr)
+            e2, r2, v2 = sa.sgp4(jd, fr)
+            cat = oracle.Catalog.from_pairs([(l1, l2)], oracle.WGS72)
+            ts = ((jd + fr) - (sat.jdsatepoch + sat.jdsatepochF)) * 1440.0
+            _, p0, v0 = cat.propagate(ts, None, layout=oracle.SAT_MAJOR)
+            ent.update({"ms_per_step": us_arr / 1e3, "value": 1440 / (us_arr / 1e6), "unit": "propagations/s (Satrec.sgp4_array, host arrays)",
+                        "sgp4_array_us": us_arr, "satrec_array_sgp4_us": us_sa, "scalar_sgp4_us": us_one,
+                        "parity": {"max_abs_dr_km": float(max(np.abs(r_ - p0[0]).max(), np.abs(r2[0] - p0[0]).max())),
+                                   "max_abs_dv_kms": float(max(np.abs(v_ - v0[0]).max(), np.abs(v2[0] - v0[0]).max())),
+                                   "err_nonzero": int(np.count_nonzero(e_) + np.count_nonzero(e2))}})
+            del sa
+        except Exception as exc:
+            ent["failed"] = repr(exc)
+        res.append(ent)
     if "api_host" not in skip:
         ent = {"key": "api_host", "kernel": "k_tiles_fast<pos+vel,DELTA> + redo, then device -> host over PCIe",
                "workload": "the reference's flagship Python call, host arrays out: SatrecArray.sgp4(jd, fr) -> (e, r, v) numpy, %d x 1,440, "
