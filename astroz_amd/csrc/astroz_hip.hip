@@ -172,6 +172,8 @@ struct azh_constellation {
     hipStream_t one_stream = nullptr;
     void *h_stage = nullptr; // pinned host staging for small one-satellite calls: h_stage_cap points (grows to kOneStage)
     size_t h_stage_cap = 0;
+    void *h_small = nullptr; // pinned host buffer the kernels of a SMALL host-returning constellation call write into directly
+    size_t h_small_cap = 0;
     HostStager stager;       // pinned staging slots of the host-returning calls (copy_back_staged), allocated on first use
     bool seeds_valid = false; // resonance seeds match the staged times/offsets and tile
     unsigned seeds_tile = 0;
@@ -234,6 +236,7 @@ void destroy(azh_constellation *c)
     c->d_one_e.release();
     c->d_one_items.release();
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_small) (void)hipHostFree(c->h_small);
     c->stager.release();
     c->d_mask.release();
     c->d_host_pos.release();
@@ -1187,6 +1190,7 @@ int32_t launch_one(azh_constellation *c, size_t sat, const double *d_t, size_t n
 #define AZ_ONE_ZERO_COPY_MAX 16384
 #endif
 constexpr size_t kOneStage = 16384;
+constexpr size_t kSmallOut = size_t(512) << 10; // bytes of results a host-returning constellation call lets its kernels write to pinned host memory directly
 constexpr size_t kOneZeroCopy = AZ_ONE_ZERO_COPY_MAX; // points the kernel exchanges with the pinned buffer directly
 
 // one satellite x n times.  interleaved = 1: out6 is n x 6 (x,y,z,vx,vy,vz; c_api batch layout); otherwise
@@ -1907,6 +1911,36 @@ int32_t azh_propagate_host(azh_constellation *c, const double *times, size_t n_t
     // device-side result buffers live in the handle and only ever grow: repeated calls (the Python propagate(),
     // SatrecArray.sgp4) do not pay a hipMalloc/hipFree pair of hundreds of megabytes each time
     const size_t words = bytes / sizeof(double);
+    // A few satellites (what Satrec / SatrecArray([sat]) / a c_api client make): the kernels write straight into a pinned host
+    // buffer of the handle (device-addressable, coherent) and one synchronize ends the call -- three pageable device-to-host
+    // copies of a few KB cost ~15 us each.
+    const size_t err_bytes = err ? c->n * n_times : 0, small_total = bytes * (vel ? 2 : 1) + ((err_bytes + 63) & ~size_t(63));
+    if (small_total <= kSmallOut && mask == nullptr && !(layout == AZ_LAYOUT_TIME_MAJOR && stride > c->n)) {
+        if (c->h_small_cap < small_total) {
+            if (c->h_small) (void)hipHostFree(c->h_small);
+            c->h_small = nullptr;
+            c->h_small_cap = 0;
+            size_t cap = 65536;
+            while (cap < small_total) cap *= 2;
+            HIP_TRY(hipHostMalloc(&c->h_small, cap, hipHostMallocDefault));
+            c->h_small_cap = cap;
+        }
+        char *dev = nullptr;
+        HIP_TRY(hipHostGetDevicePointer((void **)&dev, c->h_small, 0));
+        const size_t o_vel = bytes, o_err = bytes * (vel ? 2 : 1);
+        int32_t rc = azh_propagate_device(c, times, n_times, offsets, reinterpret_cast<double *>(dev), vel ? reinterpret_cast<double *>(dev + o_vel) : nullptr,
+                                          mode, reference_jd, mask, layout, stride, err ? reinterpret_cast<uint8_t *>(dev + o_err) : nullptr, nullptr);
+        if (rc == AZ_OK && !hip_ok(hipStreamSynchronize(c->s_main), "sync")) rc = AZ_ERR_HIP;
+        if (rc != AZ_OK) {
+            (void)hipStreamSynchronize(c->s_main);
+            return rc;
+        }
+        const char *h = static_cast<const char *>(c->h_small);
+        memcpy(pos, h, bytes);
+        if (vel) memcpy(vel, h + o_vel, bytes);
+        if (err) memcpy(err, h + o_err, err_bytes);
+        return AZ_OK;
+    }
     if (c->d_host_pos.ensure(words) != AZ_OK || (vel && c->d_host_vel.ensure(words) != AZ_OK) ||
         (err && c->d_host_err.ensure(c->n * n_times) != AZ_OK))
         return AZ_ERR_HIP;
