@@ -312,8 +312,10 @@ int32_t azh_synchronize(azh_constellation *c);
 
 /* one satellite x many times (lane = time): Satrec.sgp4 / sgp4_array
  * (bindings/python/src/satrec.zig L169-201, L256-343) and dispatch.sgp4Times8 / sdp4Times8
- * (src/dispatch.zig L32-44).  tsince in minutes from that satellite's epoch.
- * pos/vel: n x 3 each (host); err: n bytes (optional). */
+ * (src/dispatch.zig L32-44).  tsince in minutes from that satellite's epoch, in any order and spacing.
+ * pos/vel: n x 3 each (host); err: n bytes (optional).  Up to 16,384 points the kernel exchanges the data with a pinned
+ * buffer of the handle itself (one launch, one synchronize: ~20 us a call); from 2^20 points of a near-earth member every
+ * wave checks its own 1,024 times and runs the branch-free step where they are (quasi-)uniform (azh_last_one_stats). */
 int32_t azh_propagate_one_host(azh_constellation *c, size_t sat_index, const double *tsince_min, size_t n,
                                double *pos, double *vel, uint8_t *err);
 
