@@ -1561,7 +1561,7 @@ int32_t azh_set_time_tile(azh_constellation *c, uint32_t sgp4_tile, uint32_t sdp
     return AZ_OK;
 }
 
-int32_t azh_propagate_device(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+static int32_t azh_propagate_device_impl(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
                              double *d_pos, double *d_vel, int32_t mode, double reference_jd, const uint8_t *mask,
                              int32_t layout, size_t stride, uint8_t *d_err, void *stream)
 {
@@ -1573,6 +1573,12 @@ int32_t azh_propagate_device(azh_constellation *c, const double *times, size_t n
     int32_t rc = stage_inputs(c, times, n_times, offsets, mask, mode, reference_jd, st);
     if (rc != AZ_OK) return rc;
     return launch_all(c, d_pos, d_vel, layout, stride, d_err, st);
+}
+int32_t azh_propagate_device(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+                             double *d_pos, double *d_vel, int32_t mode, double reference_jd, const uint8_t *mask,
+                             int32_t layout, size_t stride, uint8_t *d_err, void *stream)
+{
+    return guarded([&]() -> int32_t { return azh_propagate_device_impl(c, times, n_times, offsets, d_pos, d_vel, mode, reference_jd, mask, layout, stride, d_err, stream); });
 }
 
 int32_t azh_propagate_device_cached(azh_constellation *c, double *d_pos, double *d_vel, int32_t layout,
@@ -1748,7 +1754,7 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
     return AZ_OK;
 }
 
-int32_t azh_screen_target_host(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+static int32_t azh_screen_target_host_impl(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
                                size_t target, double threshold_km, double reference_jd, double *min_dist,
                                uint32_t *min_t)
 {
@@ -1762,6 +1768,12 @@ int32_t azh_screen_target_host(azh_constellation *c, const double *times, size_t
     HIP_TRY(hipMemcpyAsync(min_t, c->d_out_t.p, sizeof(uint32_t) * c->n, hipMemcpyDeviceToHost, c->s_main));
     HIP_TRY(hipStreamSynchronize(c->s_main));
     return AZ_OK;
+}
+int32_t azh_screen_target_host(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+                               size_t target, double threshold_km, double reference_jd, double *min_dist,
+                               uint32_t *min_t)
+{
+    return guarded([&]() -> int32_t { return azh_screen_target_host_impl(c, times, n_times, offsets, target, threshold_km, reference_jd, min_dist, min_t); });
 }
 
 // All-vs-all coarse screen of device-resident positions (coarseScreen, bindings/python/src/
@@ -1906,7 +1918,7 @@ int32_t azh_coarse_screen_host(const double *pos, size_t n_sats, size_t n_times,
 
 // screen() without a target (bindings/python/astroz/__init__.py L633-658): propagate every member
 // to TEME on the device (time-major scratch, never copied to the host) and run the coarse screen on it
-int32_t azh_screen_all_host(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+static int32_t azh_screen_all_host_impl(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
                             double threshold_km, uint32_t *out_pairs, uint32_t *out_t, size_t max_results,
                             size_t *n_found)
 {
@@ -1927,8 +1939,14 @@ int32_t azh_screen_all_host(azh_constellation *c, const double *times, size_t n_
     (void)hipFree(d_pos);
     return rc;
 }
+int32_t azh_screen_all_host(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+                            double threshold_km, uint32_t *out_pairs, uint32_t *out_t, size_t max_results,
+                            size_t *n_found)
+{
+    return guarded([&]() -> int32_t { return azh_screen_all_host_impl(c, times, n_times, offsets, threshold_km, out_pairs, out_t, max_results, n_found); });
+}
 
-int32_t azh_propagate_host(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+static int32_t azh_propagate_host_impl(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
                            double *pos, double *vel, int32_t mode, double reference_jd, const uint8_t *mask,
                            int32_t layout, size_t stride, uint8_t *err)
 {
@@ -2002,8 +2020,14 @@ int32_t azh_propagate_host(azh_constellation *c, const double *times, size_t n_t
     if (rc != AZ_OK) (void)hipStreamSynchronize(c->s_main);
     return rc;
 }
+int32_t azh_propagate_host(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+                           double *pos, double *vel, int32_t mode, double reference_jd, const uint8_t *mask,
+                           int32_t layout, size_t stride, uint8_t *err)
+{
+    return guarded([&]() -> int32_t { return azh_propagate_host_impl(c, times, n_times, offsets, pos, vel, mode, reference_jd, mask, layout, stride, err); });
+}
 
-int32_t azh_propagate_jd_host(azh_constellation *c, const double *jd, const double *fr, size_t n_times, double *pos,
+static int32_t azh_propagate_jd_host_impl(azh_constellation *c, const double *jd, const double *fr, size_t n_times, double *pos,
                               double *vel, int32_t mode, int32_t layout, uint8_t *err)
 {
     if (!c || !jd || !fr || !pos) return AZ_ERR_NULL_POINTER;
@@ -2018,6 +2042,11 @@ int32_t azh_propagate_jd_host(azh_constellation *c, const double *jd, const doub
     for (size_t t = 0; t < n_times; ++t) times[t] = ((jd[t] + fr[t]) - ref) * 1440.0;
     for (size_t s = 0; s < c->n; ++s) offs[s] = (ref - c->h_epoch[s]) * 1440.0;
     return azh_propagate_host(c, times.data(), n_times, offs.data(), pos, vel, mode, ref, nullptr, layout, 0, err);
+}
+int32_t azh_propagate_jd_host(azh_constellation *c, const double *jd, const double *fr, size_t n_times, double *pos,
+                              double *vel, int32_t mode, int32_t layout, uint8_t *err)
+{
+    return guarded([&]() -> int32_t { return azh_propagate_jd_host_impl(c, jd, fr, n_times, pos, vel, mode, layout, err); });
 }
 
 int32_t azh_synchronize(azh_constellation *c)
@@ -2040,8 +2069,8 @@ int32_t azh_last_one_stats(azh_constellation *c, uint32_t *n_segments, uint32_t 
     if (c->one_segments == 0) return AZ_OK;
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
     HIP_TRY(hipStreamSynchronize(c->one_stream));
-    std::vector<unsigned> head(AZ_ONE_HEAD);
-    HIP_TRY(hipMemcpy(head.data(), c->d_one_items.p, sizeof(unsigned) * AZ_ONE_HEAD, hipMemcpyDeviceToHost));
+    unsigned head[AZ_ONE_HEAD]; // (8 KB: the list heads sit on their own 128-byte lines)
+    HIP_TRY(hipMemcpy(head, c->d_one_items.p, sizeof(head), hipMemcpyDeviceToHost));
     unsigned cnt = 0;
     for (unsigned k = 0; k < AZ_ONE_LISTS; ++k) cnt += head[32u * k];
     *n_handed_over = cnt;
@@ -2059,7 +2088,7 @@ double azh_last_kernel_ms(azh_constellation *c)
     return (double)ms;
 }
 
-int32_t azh_propagate_one_host(azh_constellation *c, size_t sat, const double *tsince, size_t n, double *pos,
+static int32_t azh_propagate_one_host_impl(azh_constellation *c, size_t sat, const double *tsince, size_t n, double *pos,
                                double *vel, uint8_t *err)
 {
     if (!c || !tsince || !pos) return AZ_ERR_NULL_POINTER;
@@ -2067,8 +2096,13 @@ int32_t azh_propagate_one_host(azh_constellation *c, size_t sat, const double *t
     if (n == 0) return AZ_OK;
     return run_one_satellite(c, sat, tsince, n, 0, nullptr, pos, vel, err);
 }
+int32_t azh_propagate_one_host(azh_constellation *c, size_t sat, const double *tsince, size_t n, double *pos,
+                               double *vel, uint8_t *err)
+{
+    return guarded([&]() -> int32_t { return azh_propagate_one_host_impl(c, sat, tsince, n, pos, vel, err); });
+}
 
-int32_t azh_propagate_one_device(azh_constellation *c, size_t sat, const double *d_tsince, size_t n, double *d_pos,
+static int32_t azh_propagate_one_device_impl(azh_constellation *c, size_t sat, const double *d_tsince, size_t n, double *d_pos,
                                  double *d_vel, uint8_t *d_err, void *stream)
 {
     if (!c || !d_tsince || !d_pos) return AZ_ERR_NULL_POINTER;
@@ -2083,6 +2117,11 @@ int32_t azh_propagate_one_device(azh_constellation *c, size_t sat, const double 
         c->timed = true;
     }
     return AZ_OK;
+}
+int32_t azh_propagate_one_device(azh_constellation *c, size_t sat, const double *d_tsince, size_t n, double *d_pos,
+                                 double *d_vel, uint8_t *d_err, void *stream)
+{
+    return guarded([&]() -> int32_t { return azh_propagate_one_device_impl(c, sat, d_tsince, n, d_pos, d_vel, d_err, stream); });
 }
 
 // device-side known-answer hook for the element math of the kernels (devmath.h): out[0..n) sin, [n..2n) cos,
