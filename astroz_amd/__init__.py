@@ -304,6 +304,8 @@ def coarse_screen(positions, num_sats, threshold, valid_mask=None):
 EARTH_MU = 398600.5          # km^3/s^2, WGS84 (src/constants.zig L41-52)
 EARTH_R_EQ = 6378.137        # km
 EARTH_J2 = 0.00108262998905
+SUN_MU = 1.32712e11          # km^3/s^2 (src/constants.zig L94-97; module constants of the reference's extension, main.zig L73-74)
+MOON_MU = 4.90280e3          # km^3/s^2 (src/constants.zig L167-170)
 
 
 def hohmann_transfer(mu, r1, r2):
@@ -347,4 +349,6 @@ def escape_velocity(mu, radius):
 
 __all__ = ["__version__", "Tle", "Sgp4Constellation", "Constellation", "propagate", "screen", "coarse_screen",
            "set_fetcher", "celestrak_url", "WGS72", "WGS84", "hohmann_transfer", "orbital_velocity", "orbital_period",
-           "escape_velocity", "EARTH_MU", "EARTH_R_EQ", "EARTH_J2"]
+           "escape_velocity", "EARTH_MU", "EARTH_R_EQ", "EARTH_J2", "SUN_MU", "MOON_MU"]
+# (the reference's package also re-exports bi_elliptic_transfer, lambert and propagate_numerical -- its orbital-mechanics and
+# numerical-integration modules, outside the SGP4/SDP4 constellation path this package replaces: DESIGN.md 9)
