@@ -1105,7 +1105,8 @@ class CopyPool {
                 if (next >= jobs_.size()) return; // (stop, nothing left)
                 j = jobs_[next];
             }
-            const size_t k = th_.size(), piece = (j.len / k + 63) & ~size_t(63);
+            // (ceil: with floor(len / k) a multiple of 64 and len % k != 0, k pieces of the floor would stop short of len)
+            const size_t k = th_.size(), piece = ((j.len + k - 1) / k + 63) & ~size_t(63);
             const size_t lo = std::min(j.len, piece * me), hi = std::min(j.len, piece * (me + 1));
             if (hi > lo) memcpy(j.dst + lo, j.src + lo, hi - lo);
             {

@@ -96,20 +96,38 @@ def test_config5_share_full_size(native, orc, synth, arith32):
     torch.cuda.empty_cache()
 
 
-def _bench_line(args, timeout=600):
+def _bench_line(args, timeout=600, full=False):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
-    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    lines = r.stdout.splitlines()
+    # the LAST stdout line is the compact record the driver parses: short, valid JSON, nothing after it
+    assert lines[-1].startswith("{") and len(lines[-1].encode()) < 4096, (len(lines[-1]), lines[-1][:200])
+    j = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert "workload" in j["config"] and {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(j["roofline"])
+    if full:
+        fl = [ln for ln in lines if ln.startswith("BENCH_FULL ")]
+        assert len(fl) == 1
+        return j, json.loads(fl[0][len("BENCH_FULL "):])
+    return j
 
 
 def test_bench_secondary_block(native):
     """The default bench invocation appends `secondary`: every non-headline configuration with its own timing, roofline
     fraction and oracle parity (the 30-GB config-5 share is skipped here: test_config5_share_full_size covers it)."""
-    j = _bench_line(["--steps", "5", "--warmup", "2", "--precondition-ms", "0", "--no-cpu-baseline",
-                     "--secondary-skip", "config5_share,config5_share_f32arith,config5_share_fp64"])
+    j, jf = _bench_line(["--steps", "5", "--warmup", "2", "--precondition-ms", "0", "--cpu-seconds", "0.5",
+                         "--secondary-skip", "config5_share,config5_share_f32arith,config5_share_fp64"], full=True)
     assert j["metric"].startswith("propagations/sec, 13,478 sats") and j["value"] > 0
-    sec = {e["key"]: e for e in j["secondary"]}
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1 and j["cpu_baseline"]["threads_1"] > 0
+    assert j["parity"]["max_abs_dr_km"] < 1e-6 and j["parity"]["max_abs_dv_kms"] < 1e-9
+    sec = {e["key"]: e for e in jf["secondary"]}
+    # the compact line carries key -> [ms_per_step, frac] for every entry of the full block
+    assert set(j["secondary_summary"]) == set(sec), (sorted(j["secondary_summary"]), sorted(sec))
+    assert abs(j["secondary_summary"]["config2_time_major"][0] - sec["config2_time_major"]["ms_per_step"]) < 1e-3 * sec["config2_time_major"]["ms_per_step"]
+    assert abs(jf["value"] - j["value"]) <= 1e-5 * jf["value"]
     want = {"config2_pos_only", "config2_time_major", "config2_time_major_aligned", "config2_ecef_time_major", "config2_ecef_sat_major",
             "config2_geodetic_time_major", "config3_sat_major", "config3_time_major", "one_satellite", "fused_screen"}
     assert want <= set(sec), sorted(sec)

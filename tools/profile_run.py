@@ -7,7 +7,7 @@ Writes gpurun_out/profiles/<name>.txt (+ .json): the --kernel-trace --stats tabl
 share) and, with --pmc, the counter passes of the MI355X guide (separate passes, never combined with traces): SQ
 instruction / wait counters, FETCH_SIZE, WRITE_SIZE, GRBM_GUI_ACTIVE -- per kernel and dispatch, with the derived
 figures (VALU instructions per wave, HBM bytes per dispatch with the guide's corrections).  The JSON carries the
-sha256 fingerprint of astroz_amd/csrc AS IT IS ON THE BOX WHEN THE MEASUREMENT RUNS (bench.csrc_fingerprint):
+sha256 fingerprint of astroz_amd/csrc AS IT IS ON THE BOX WHEN THE MEASUREMENT RUNS (bench_common.csrc_fingerprint):
 profiles/latest_pmc.json is a copy of such a file, never re-stamped afterwards."""
 import glob
 import json
@@ -50,7 +50,7 @@ def main():
     cmd_txt = "python bench.py --no-cpu-baseline --no-secondary " + " ".join(bench_args)
     lines = ["# rocprofv3 summary: " + name, "# command: %s --steps %s --warmup 20" % (cmd_txt, steps), ""]
     js = {"name": name, "command": cmd_txt, "kernels": {}}
-    import bench as bench_mod
+    import bench_common as bench_mod
     js["csrc_sha16"] = bench_mod.csrc_fingerprint()
     lines.append("# csrc_sha16 (sources on the box at measurement time): " + js["csrc_sha16"])
     # ---- kernel trace

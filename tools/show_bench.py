@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """print the headline and the secondary block of a bench.py JSON line: tools/show_bench.py gpurun_out/<tag>/bench.json"""
 import json, sys
-j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+ls = list(open(sys.argv[1]))
+fl = [l for l in ls if l.startswith("BENCH_FULL ")]
+j = json.loads(fl[-1][11:]) if fl else json.loads([l for l in ls if l.startswith("{")][-1])
+print("last line bytes:", len(ls[-1]))
 print("headline ms/step %.4f  value %.4g  frac %.3f  parity %s  power %s" % (j["ms_per_step"], j["value"], j["roofline"]["frac"], j.get("parity"),
       {k: v for k, v in (j.get("power") or {}).items() if k in ("socket_w_median", "sclk_mhz_median")}))
 if j.get("cpu_baseline"): print("cpu_baseline", j["cpu_baseline"].get("value"), j["cpu_baseline"].get("cores"))
