@@ -19,7 +19,7 @@ OUTPUT_MODES = {"teme": OUT_TEME, "ecef": OUT_ECEF, "geodetic": OUT_GEODETIC}
 
 AZ_ERR_HIP = -200
 # azh_last_path bits (include/astroz_hip.h)
-PATH_ROWS_FAST, PATH_TILES_FAST, PATH_ROWS_GENERIC, PATH_LANE_SAT, PATH_DEEP_ROWS, PATH_QUASI_UNIFORM = 1, 2, 4, 8, 16, 32
+PATH_ROWS_FAST, PATH_TILES_FAST, PATH_ROWS_GENERIC, PATH_LANE_SAT, PATH_DEEP_ROWS, PATH_QUASI_UNIFORM, PATH_COLS_FAST = 1, 2, 4, 8, 16, 32, 64
 
 # every symbol include/astroz_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -442,7 +442,9 @@ class DeviceConstellation:
         check(lib().azh_set_fast_path(self._h, 1 if enabled else 0), "azh_set_fast_path")
 
     def set_tile_kernel(self, enabled):
-        check(lib().azh_set_tile_kernel(self._h, 1 if enabled else 0), "azh_set_tile_kernel")
+        """Time-major output on (quasi-)uniform grids: True / 1 = the 16-row tile kernel (default), 2 = the lane = satellite
+        kernel k_cols_fast (opt-in: parity-identical, measured slower), False / 0 = neither (k_propagate)."""
+        check(lib().azh_set_tile_kernel(self._h, int(enabled) if not isinstance(enabled, bool) else (1 if enabled else 0)), "azh_set_tile_kernel")
 
     def set_timing(self, enabled):
         check(lib().azh_set_timing(self._h, 1 if enabled else 0), "azh_set_timing")

@@ -146,7 +146,7 @@ struct azh_constellation {
         DevBuf<double> win;
         DevBuf<unsigned char> flag;
         DevBuf<unsigned> redo;
-    } plan[3];
+    } plan[4]; // ([3]: the lane = satellite time-major kernel, k_cols_fast)
     DevBuf<double> d_inc;       // uniform grids: per-satellite rotation increments (k_prep_inc), [2 * AZ_INC_NUM][n_pad]
     DevBuf<double> d_fast_rec;  // ... and the record of folded constants of the lane = time fast kernels (k_prep_rec), [n_pad][FR_NUM]
     double uniform_step = 0.0;  // step of the staged grid if it is uniform, else 0
@@ -195,6 +195,8 @@ struct azh_constellation {
     unsigned off_cat = 0; // d_list + off_cat: near-earth members in plain catalog order (k_tiles_fast: runs of consecutive rows)
     unsigned off_deep_cat = 0; // d_list + off_deep_cat: deep-space members in plain catalog order (lane = time kernels)
     unsigned off_rowmap = 0;   // d_list + off_rowmap: per catalog row, kind << 30 | slot (AZ_ROW_*: k_tiles_fast)
+    unsigned off_rowmap2 = 0;  // ... the same with near-earth slots counted in the [class 0 | other classes] list (k_cols_fast)
+    int cols_kernel = 0;       // time-major output on (quasi-)uniform grids through k_cols_fast (lane = satellite) instead of k_tiles_fast
     DevBuf<double> d_deep_tmp; // time-major output: the deep-space rows' compact satellite-major scratch (k_deep_transpose)
     bool tile_kernel = true; // time-major output through the tile kernels (azh_set_tile_kernel)
     unsigned off_circ = 0, n_circ = 0; // d_list + off_circ: near-earth members in catalog order, [n_circ of eccentricity class 0 | the rest]
@@ -394,6 +396,20 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
                 else list.push_back(((unsigned)AZ_ROW_NEAR << 30) | near++);
             }
         }
+        // ... and once more for the lane = satellite time-major kernel, whose plan and redo items count near-earth slots in
+        // the [class 0 | other classes] list: slot < n_circ = computed there, the rest arrive through the scratch array
+        c->off_rowmap2 = (unsigned)list.size();
+        {
+            unsigned circ = 0, eccn = 0, deepn = 0;
+            for (size_t s = 0; s < n; ++s) {
+                const unsigned f = c->h_flags[s];
+                if (AZ_FLAG_ERR(f) != 0) list.push_back((unsigned)AZ_ROW_ZERO << 30);
+                else if (f & AZ_FLAG_DEEP) list.push_back(((unsigned)AZ_ROW_COPY << 30) | deepn++);
+                else if (AZ_FLAG_ECLASS(f) == 0) list.push_back(((unsigned)AZ_ROW_NEAR << 30) | circ++);
+                else list.push_back(((unsigned)AZ_ROW_NEAR << 30) | (c->n_circ + eccn++));
+            }
+        }
+        if (const char *e = getenv("ASTROZ_AMD_COLS")) c->cols_kernel = atoi(e);
         if (c->d_list.ensure(list.size()) != AZ_OK ||
             !hip_ok(hipMemcpy(c->d_list.p, list.data(), sizeof(unsigned) * list.size(), hipMemcpyHostToDevice), "H2D list")) {
             rc = AZ_ERR_HIP;
@@ -651,6 +667,86 @@ void launch_tiles(const PropArgs &a0, bool vel, hipStream_t st, const FastShape 
     a.tm_rows = 1;
     dim3 rgrid(256, 4);
     if (ecef) {
+        if (vel) hipLaunchKernelGGL((k_rows<true, true, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_rows<false, true, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
+    } else {
+        if (vel) hipLaunchKernelGGL((k_rows<true, false, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((k_rows<false, false, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
+    }
+}
+
+// time-major output through k_cols_fast (lane = satellite): segment length of the main launch.  A wave is 64 catalog rows x one
+// segment and runs for tens of microseconds, so a second, partly filled generation of waves would cost a large part of the
+// step: when one generation of AZ_COLS_WAVES waves per SIMD can hold the whole grid (config 2: 211 row groups x 19 segments of 76
+// points = 4,009 waves for 4,096 places), the segments are cut for exactly that; larger launches take 128-point segments.
+unsigned cols_tile(unsigned n_rows, unsigned n_times, unsigned forced, double step)
+{
+    const unsigned cap = fast_window_cap(step);
+    if (forced) return std::min(std::max(forced, 1u), std::min(std::max(n_times, 1u), cap));
+    const unsigned groups = (n_rows + 63u) / 64u, places = 1024u * (unsigned)AZ_COLS_WAVES;
+    const unsigned segs = std::max(1u, places / std::max(groups, 1u));
+    unsigned tile = (n_times + segs - 1u) / segs;
+    if (tile < 32u) tile = std::min(128u, std::max(n_times, 1u)); // (several generations anyway)
+    return std::max(1u, std::min(tile, cap));
+}
+FastShape fast_shape_cols(const PropArgs &a, unsigned n_rows, unsigned n_sgp4, unsigned n_circ)
+{
+    FastShape f = fast_shape_rows(a, n_sgp4, n_circ); // tile_e: the eccentric members' own lane = time launch
+    f.tile_e = std::min(rows_tile(std::max(n_sgp4 - n_circ, 1u), a.n_times, a.tile_forced ? a.tile_forced : 256u), fast_window_cap(a.uniform_step));
+    if (a.mode != AZ_OUT_TEME) f.tile_e = std::min(f.tile_e, (unsigned)AZ_FRAME_SEG);
+    if (a.delta || a.delta64) f.tile_e = std::min(f.tile_e, (unsigned)AZ_DELTA_SEG);
+    f.tile_c = cols_tile(n_rows, a.n_times, a.tile_forced, a.uniform_step);
+    f.packed32 = f.mixed32 = false;
+    f.kind = 3;
+    return f;
+}
+template <bool VEL, int FRAME>
+void launch_cols_fast(const PropArgs &a, dim3 grid, hipStream_t st)
+{
+    if (a.delta64) hipLaunchKernelGGL((k_cols_fast<VEL, FRAME, 2>), grid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_cols_fast<VEL, FRAME, 0>), grid, dim3(64), 0, st, a);
+}
+// a: list = [class 0 | other classes], rowmap = the matching row map, tmp_pos / tmp_vel = the scratch array (deep-space rows
+// already in flight on their stream; the caller has made `st` wait for them)
+void launch_cols(const PropArgs &a0, bool vel, hipStream_t st, const FastShape &shape, const EccSide &side, unsigned ecc_row0)
+{
+    PropArgs a = a0;
+    const int frame = a.mode == AZ_OUT_GEODETIC ? 2 : (a.mode != AZ_OUT_TEME ? 1 : 0);
+    // eccentric members: their own lane = time launch into the scratch array, beside whatever precedes the main launch
+    PropArgs e = a;
+    e.list = a.list + a.n_circ;
+    e.n_list = a.n_list - a.n_circ;
+    e.redo_slot0 = a.n_circ;
+    e.tile = shape.tile_e;
+    e.pos = const_cast<double *>(a.tmp_pos);
+    e.vel = vel ? const_cast<double *>(a.tmp_vel) : nullptr;
+    e.rows_compact = 1;
+    e.ecc_row0 = ecc_row0;
+    if (e.n_list) {
+        dim3 egrid((e.n_list + 7) / 8 * 8, (a.n_times + e.tile - 1) / e.tile);
+        hipStream_t se = side.stream ? side.stream : st;
+        if (se != st) {
+            (void)hipEventRecord(side.fork, st);
+            (void)hipStreamWaitEvent(se, side.fork, 0);
+        }
+        if (frame == 2) { if (vel) launch_rows_fast<true, 2, AZ_SINK_F64, true>(e, egrid, se); else launch_rows_fast<false, 2, AZ_SINK_F64, true>(e, egrid, se); }
+        else if (frame == 1) { if (vel) launch_rows_fast<true, 1, AZ_SINK_F64, true>(e, egrid, se); else launch_rows_fast<false, 1, AZ_SINK_F64, true>(e, egrid, se); }
+        else { if (vel) launch_rows_fast<true, 0, AZ_SINK_F64, true>(e, egrid, se); else launch_rows_fast<false, 0, AZ_SINK_F64, true>(e, egrid, se); }
+        if (se != st) {
+            (void)hipEventRecord(side.join, se);
+            (void)hipStreamWaitEvent(st, side.join, 0);
+        }
+    }
+    a.tile = shape.tile_c;
+    a.ecc_row0 = ecc_row0;
+    dim3 grid(((a.n_rows + 63u) / 64u + 7u) / 8u * 8u, (a.n_times + a.tile - 1) / a.tile);
+    if (frame == 2) { if (vel) launch_cols_fast<true, 2>(a, grid, st); else launch_cols_fast<false, 2>(a, grid, st); }
+    else if (frame == 1) { if (vel) launch_cols_fast<true, 1>(a, grid, st); else launch_cols_fast<false, 1>(a, grid, st); }
+    else { if (vel) launch_cols_fast<true, 0>(a, grid, st); else launch_cols_fast<false, 0>(a, grid, st); }
+    // the generic pass over the windows the plan rejected and the eccentric form's hand-overs: 24-byte pieces, row by row
+    a.tm_rows = 1;
+    dim3 rgrid(256, 4);
+    if (frame) {
         if (vel) hipLaunchKernelGGL((k_rows<true, true, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
         else hipLaunchKernelGGL((k_rows<false, true, AZ_SINK_F64, true>), rgrid, dim3(64), 0, st, a);
     } else {
@@ -959,7 +1055,22 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     const bool tiles = c->n_sgp4 > 0 && c->tile_kernel && a.inc != nullptr && layout == AZ_LAYOUT_TIME_MAJOR && !f32 &&
                        a.mask == nullptr && n_times >= 64 &&
                        (size_t)stride * 64 * 24 < 0xf0000000ull; // (k_tiles_fast: 32-bit byte offsets inside a block of 64 time rows)
+    // ... or, when switched on (azh_set_tile_kernel(c, 2) / ASTROZ_AMD_COLS), the lane = satellite kernel k_cols_fast
+    const bool cols = tiles && c->cols_kernel != 0;
+    const unsigned n_ecc = c->n_sgp4 - c->n_circ;
+    // compact satellite-major scratch rows of a time-major launch: [deep-space list slots | (k_cols_fast) eccentric list slots]
+    const size_t scratch_rows = (size_t)c->n_sdp4 + (cols ? n_ecc : 0u);
+    const size_t scratch_per = scratch_rows * n_times * 3, scratch_words = f32 ? (scratch_per + 1) / 2 : scratch_per; // in doubles
+    auto ensure_scratch = [&](hipStream_t user) -> int32_t {
+        if (c->d_deep_tmp.cap < scratch_words * (d_vel ? 2 : 1)) HIP_TRY(hipStreamSynchronize(user));
+        if (c->d_deep_tmp.ensure(scratch_words * (d_vel ? 2 : 1)) != AZ_OK) return AZ_ERR_HIP;
+        a.tmp_pos = c->d_deep_tmp.p;
+        a.tmp_vel = d_vel ? c->d_deep_tmp.p + scratch_words : nullptr;
+        return AZ_OK;
+    };
     const bool fork = c->n_sdp4 > 0;
+    if (cols && !fork && n_ecc)
+        if (int32_t rc = ensure_scratch(st); rc != AZ_OK) return rc;
     if (fork) {
         // deep-space rows on their own stream, concurrent with the near-earth launch
         HIP_TRY(hipEventRecord(c->ev_fork, st));
@@ -970,17 +1081,13 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         if (deep_rows && layout == AZ_LAYOUT_TIME_MAJOR) {
             // time-major: the rows go satellite-major into a compact scratch array (row = list slot), then one pure-memory
             // kernel writes them out as time-major runs (k_deep_transpose)
-            const size_t per = (size_t)c->n_sdp4 * n_times * 3, words = f32 ? (per + 1) / 2 : per; // in doubles
-            if (c->d_deep_tmp.cap < words * (d_vel ? 2 : 1)) HIP_TRY(hipStreamSynchronize(c->s_deep));
-            if (c->d_deep_tmp.ensure(words * (d_vel ? 2 : 1)) != AZ_OK) return AZ_ERR_HIP;
+            if (int32_t rc = ensure_scratch(c->s_deep); rc != AZ_OK) return rc;
             PropArgs t = d;
-            t.pos = c->d_deep_tmp.p;
-            t.vel = d_vel ? c->d_deep_tmp.p + words : nullptr;
+            t.pos = const_cast<double *>(a.tmp_pos);
+            t.vel = const_cast<double *>(a.tmp_vel);
             t.rows_compact = 1;
             path |= launch_propagate(t, AZ_LAYOUT_SAT_MAJOR, d_vel != nullptr, true, c->s_deep);
             HIP_TRY(hipGetLastError());
-            a.tmp_pos = t.pos;
-            a.tmp_vel = t.vel;
             dim3 tg((c->n_sdp4 + AZ_TR_ROWS - 1) / AZ_TR_ROWS, (n_times + 63) / 64);
             if (tiles) { /* the tile kernel copies the scratch rows through its own tiles */ }
             else if (f32)
@@ -1005,28 +1112,32 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         // each other they would not overlap well anyway: a tile workgroup is 16 waves of 128 VGPRs and needs a whole CU's
         // register files at once, so any small workgroup of another kernel resident on the CU keeps it out.)
         if (tiles && fork) HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
-        if (tiles) a.list = c->d_list.p + c->off_cat; // plain catalog order; the redo items index this list
+        if (tiles && !cols) a.list = c->d_list.p + c->off_cat; // plain catalog order; the redo items index this list
         FastShape shape;
         const bool fast = a.inc != nullptr && (tiles || use_rows(a, layout, false));
         if (fast) {
             // uniform grid: every near-earth member -> the branch-free kernels (near-circular or eccentric Kepler form by
             // class), windows prepared and validated once per staged grid by the plan; what the plan rejects and what the
             // eccentric form's Newton validation hands over comes back through the redo list
-            if (!tiles) a.list = c->d_list.p + c->off_circ; // [class 0 | other classes], catalog order inside each
+            if (!tiles || cols) a.list = c->d_list.p + c->off_circ; // [class 0 | other classes], catalog order inside each
             a.n_list = c->n_sgp4;
             a.n_circ = c->n_circ;
-            a.rowmap = c->d_list.p + c->off_rowmap;
+            a.rowmap = c->d_list.p + (cols ? c->off_rowmap2 : c->off_rowmap);
             a.n_rows = (unsigned)c->n;
-            shape = tiles ? fast_shape_tiles(a, (unsigned)c->n) : fast_shape_rows(a, c->n_sgp4, c->n_circ);
+            shape = cols ? fast_shape_cols(a, (unsigned)c->n, c->n_sgp4, c->n_circ)
+                         : (tiles ? fast_shape_tiles(a, (unsigned)c->n) : fast_shape_rows(a, c->n_sgp4, c->n_circ));
             if (int32_t rc = ensure_plan(c, a, shape, st); rc != AZ_OK) return rc;
         }
-        if (a.n_list > 0 && tiles) {
+        if (a.n_list > 0 && cols) {
+            launch_cols(a, d_vel != nullptr, st, shape, EccSide{c->s_ecc, c->ev_fork2, c->ev_join2}, c->n_sdp4);
+            path |= AZH_PATH_COLS_FAST;
+        } else if (a.n_list > 0 && tiles) {
             launch_tiles(a, d_vel != nullptr, st, shape);
             path |= AZH_PATH_TILES_FAST;
         } else if (a.n_list > 0) {
             path |= launch_propagate(a, layout, d_vel != nullptr, false, st, EccSide{c->s_ecc, c->ev_fork2, c->ev_join2}, fast ? &shape : nullptr);
         }
-        if ((a.delta || a.delta64) && (path & (AZH_PATH_TILES_FAST | AZH_PATH_ROWS_FAST))) path |= AZH_PATH_QUASI_UNIFORM;
+        if ((a.delta || a.delta64) && (path & (AZH_PATH_TILES_FAST | AZH_PATH_ROWS_FAST | AZH_PATH_COLS_FAST))) path |= AZH_PATH_QUASI_UNIFORM;
         HIP_TRY(hipGetLastError());
     }
     if (c->n_bad > 0) {
@@ -1544,6 +1655,7 @@ int32_t azh_set_tile_kernel(azh_constellation *c, int32_t enabled)
 {
     if (!c) return AZ_ERR_NULL_POINTER;
     c->tile_kernel = enabled != 0;
+    c->cols_kernel = enabled == 2 ? 1 : (enabled == 1 ? 0 : c->cols_kernel); // 2: the lane = satellite kernel (k_cols_fast), 1: the 16-row tiles
     return AZ_OK;
 }
 

@@ -73,6 +73,7 @@ struct PropArgs {
     int tm_rows; // k_rows (redo pass behind the tile kernel): write this lane's 24 bytes of the time-major layout
     int rows_compact; // k_rows_deep: the output row of a satellite is its LIST SLOT (a compact satellite-major scratch array
                       // that k_deep_transpose turns into time-major runs), not its catalog index
+    unsigned ecc_row0; // k_rows_fast with rows_compact (ahead of k_cols_fast): scratch row of the launch's first list slot
     // fused single-target conjunction screen (sink instead of stores): the target's TEME track,
     // [n_times][3], NaN where the target itself failed; partial minima per (segment or tile, list slot)
     const double *screen_target;
@@ -1054,8 +1055,9 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
         const double off = az_uniform(p.offsets ? p.offsets[s] : 0.0);
         const double *__restrict__ rec = p.fast_rec + (size_t)s * FR_NUM;
         az_fill_fast_table(cold_lds, rec, lane);
-        out_t *prow = SINK == AZ_SINK_SCREEN ? nullptr : reinterpret_cast<out_t *>(p.pos) + (size_t)s * p.n_times * 3;
-        out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + (size_t)s * p.n_times * 3 : nullptr;
+        const size_t out_row = p.rows_compact ? (size_t)p.ecc_row0 + row : (size_t)s; // (compact scratch rows ahead of k_cols_fast)
+        out_t *prow = SINK == AZ_SINK_SCREEN ? nullptr : reinterpret_cast<out_t *>(p.pos) + out_row * p.n_times * 3;
+        out_t *vrow = VEL ? reinterpret_cast<out_t *>(p.vel) + out_row * p.n_times * 3 : nullptr;
         const bool staged = AZ_ROWS_LDS_STORE && SINK != AZ_SINK_SCREEN &&
                             (((reinterpret_cast<size_t>(prow) | (VEL ? reinterpret_cast<size_t>(vrow) : 0)) & 15u) == 0);
         FastKBcast k;
@@ -1344,6 +1346,8 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
         }
     }
 }
+
+#include "cols_kernel.h"
 
 // Staging of the packed kernel, DS instructions written by hand.  Component j of a lane's two grid points sits in
 // one register pair while the row wants (x y z)(x y z): ds_write2_b32 puts the two halves three floats apart without

@@ -334,9 +334,10 @@ int32_t azh_set_time_tile(azh_constellation *c, uint32_t sgp4_tile, uint32_t sdp
 /* enable (default) / disable the branch-free uniform-grid step (astroz_amd/csrc/fast_step.h).  Results
  * of the two paths agree to rounding; the switch exists so that tests can compare them. */
 int32_t azh_set_fast_path(azh_constellation *c, int32_t enabled);
-/* enable (default) / disable the 16-satellite tile kernel for time-major output on uniform grids (k_tiles_fast: lane =
- * time arithmetic, transposed through LDS); disabled, the lane = satellite kernel serves that layout.  Results of the
- * two agree to rounding; the switch exists so that tests and benchmarks can compare them. */
+/* time-major output on (quasi-)uniform grids: 1 (default) = the 16-satellite tile kernel (k_tiles_fast: lane = time
+ * arithmetic, transposed through LDS); 2 = the branch-free lane = satellite kernel (k_cols_fast: one wave = 64 catalog rows,
+ * 1,536-byte runs; measured slower than the tiles, kept as an option); 0 = neither (the generic lane = satellite kernel).
+ * Results agree to rounding; the switch exists so that tests and benchmarks can compare them. */
 int32_t azh_set_tile_kernel(azh_constellation *c, int32_t enabled);
 /* host-returning calls (azh_propagate_host, azh_propagate_jd_host, azh_group_propagate_host): results travel device -> pinned
  * staging slots (kept in the handle) -> the caller's arrays, the second hop by n host threads while the next chunk is on the
@@ -359,6 +360,7 @@ double azh_last_kernel_ms(azh_constellation *c);
 #define AZH_PATH_ROWS_GENERIC 4u  /* k_rows over the whole near-earth list: lane = time, any grid */
 #define AZH_PATH_LANE_SAT 8u      /* k_propagate: lane = satellite (short grids; time-major with masks / fp32 / irregular grids) */
 #define AZH_PATH_DEEP_ROWS 16u    /* k_rows_deep: lane = time deep-space rows */
+#define AZH_PATH_COLS_FAST 64u     /* k_cols_fast: lane = satellite, branch-free, time-major runs of 64 catalog rows */
 #define AZH_PATH_QUASI_UNIFORM 32u /* the staged grid is quasi-uniform: the fast kernels ran in their DELTA form */
 uint32_t azh_last_path(const azh_constellation *c);
 /* the most recent one-satellite call of this handle (azh_propagate_one_host / _device; sgp4_propagate / _batch through their

@@ -88,7 +88,7 @@ def test_jdfr_grids_full_size_all_rows_take_the_fast_kernels(native, orc, synth,
     dev.propagate_device_cached(ptm.data_ptr(), vtm.data_ptr(), layout=native.TIME_MAJOR)
     dev.synchronize()
     path = dev.last_path()
-    assert path & native.PATH_TILES_FAST and path & native.PATH_QUASI_UNIFORM, path
+    assert path & (native.PATH_TILES_FAST | native.PATH_COLS_FAST) and path & native.PATH_QUASI_UNIFORM, path
     assert not path & native.PATH_LANE_SAT, path
     dr = float(np.abs(ptm.cpu().numpy().transpose(1, 0, 2) - p0).max())
     dv = float(np.abs(vtm.cpu().numpy().transpose(1, 0, 2) - v0).max())
@@ -110,7 +110,7 @@ def test_jdfr_grid_matches_the_generic_path_and_ecef(native, orc, synth):
             pos, vel = np.empty(shape), np.empty(shape)
             dev.propagate_host(times, off, pos=pos, vel=vel, mode=mode, reference_jd=ref, layout=layout)
             path = dev.last_path()
-            assert path & native.PATH_QUASI_UNIFORM and path & (native.PATH_ROWS_FAST | native.PATH_TILES_FAST), (layout, mode, path)
+            assert path & native.PATH_QUASI_UNIFORM and path & (native.PATH_ROWS_FAST | native.PATH_TILES_FAST | native.PATH_COLS_FAST), (layout, mode, path)
             _, p0, v0 = cat.propagate(times, off, layout=olay, mode=omode, reference_jd=ref)
             dq = np.abs(pos - p0)
             if mode == native.OUT_GEODETIC:
@@ -155,12 +155,12 @@ def test_satrec_array_jdfr_runs_the_tile_kernel(native, orc, synth):
     e0, p0, v0 = cat.propagate(times, off)
     e, r, v = arr.sgp4(jd, fr)
     path = arr._dev.last_path()
-    assert path & native.PATH_TILES_FAST and path & native.PATH_QUASI_UNIFORM and not path & native.PATH_LANE_SAT, path
+    assert path & (native.PATH_TILES_FAST | native.PATH_COLS_FAST) and path & native.PATH_QUASI_UNIFORM and not path & native.PATH_LANE_SAT, path
     assert np.array_equal(e, e0) and np.abs(r - p0).max() < TOL_R and np.abs(v - v0).max() < TOL_V
     e, r_tm, v_tm = arr.sgp4_device(jd, fr)
     arr.synchronize()
     path = arr._dev.last_path()
-    assert path & native.PATH_TILES_FAST and path & native.PATH_QUASI_UNIFORM, path
+    assert path & (native.PATH_TILES_FAST | native.PATH_COLS_FAST) and path & native.PATH_QUASI_UNIFORM, path
     assert np.abs(r_tm.cpu().numpy().transpose(1, 0, 2) - p0).max() < TOL_R
     assert np.abs(v_tm.cpu().numpy().transpose(1, 0, 2) - v0).max() < TOL_V
     assert r_tm.is_contiguous() and v_tm.is_contiguous() and tuple(r_tm.shape) == (n, 1000, 3)   # dense by default
@@ -257,7 +257,7 @@ def test_jittered_grids_full_size_take_the_fast_kernels(native, orc, synth, n_de
     dev.propagate_device_cached(ptm.data_ptr(), vtm.data_ptr(), layout=native.TIME_MAJOR)
     dev.synchronize()
     path = dev.last_path()
-    assert path & native.PATH_TILES_FAST and path & native.PATH_QUASI_UNIFORM and not path & native.PATH_LANE_SAT, path
+    assert path & (native.PATH_TILES_FAST | native.PATH_COLS_FAST) and path & native.PATH_QUASI_UNIFORM and not path & native.PATH_LANE_SAT, path
     dr = float(np.abs(ptm.cpu().numpy().transpose(1, 0, 2) - p0).max())
     dv = float(np.abs(vtm.cpu().numpy().transpose(1, 0, 2) - v0).max())
     assert dr < TOL_R and dv < TOL_V, (dr, dv)
@@ -280,7 +280,7 @@ def test_jittered_grid_variants_and_limits(native, orc, synth):
             pos, vel = np.empty(shape), np.empty(shape)
             dev.propagate_host(tj, off, pos=pos, vel=vel, mode=mode, reference_jd=synth.START_JD, layout=layout)
             path = dev.last_path()
-            assert path & native.PATH_QUASI_UNIFORM and path & (native.PATH_ROWS_FAST | native.PATH_TILES_FAST), (layout, mode, path)
+            assert path & native.PATH_QUASI_UNIFORM and path & (native.PATH_ROWS_FAST | native.PATH_TILES_FAST | native.PATH_COLS_FAST), (layout, mode, path)
             _, p0, v0 = cat.propagate(tj, off, layout=olay, mode=omode, reference_jd=synth.START_JD)
             dq = np.abs(pos - p0)
             if mode == native.OUT_GEODETIC:
@@ -439,7 +439,7 @@ def test_few_rows_long_series_rotate_over_the_xcds(native, orc, synth, n_near, n
             pos, vel = np.full(shape, np.nan), np.full(shape, np.nan)
             err = np.zeros((dev.n, n), dtype=np.uint8)
             dev.propagate_host(times, off, pos=pos, vel=vel, err=err, layout=layout)
-            assert dev.last_path() & (native.PATH_ROWS_FAST | native.PATH_TILES_FAST), dev.last_path()
+            assert dev.last_path() & (native.PATH_ROWS_FAST | native.PATH_TILES_FAST | native.PATH_COLS_FAST), dev.last_path()
             assert not np.isnan(pos).any() and not np.isnan(vel).any(), (layout, "an output element was left unwritten")
             if layout == native.TIME_MAJOR:
                 pos, vel = pos.transpose(1, 0, 2), vel.transpose(1, 0, 2)

@@ -27,9 +27,9 @@ def build(specs):
         for ln in err.splitlines():
             if "Function Name" in ln:
                 cur = ln.split("Function Name:")[1].split()[0]
-            if cur and ("k_rowsILb1ELb0ELi0" in cur or "k_propagateILi1ELb1ELb0ELb0ELb0" in cur) and any(
+            if cur and ("k_rowsILb1ELb0ELi0" in cur or "k_propagateILi1ELb1ELb0ELb0ELb0" in cur or "k_cols_fastILb1ELi0ELi0" in cur) and any(
                     k in ln for k in (" VGPRs:", "ScratchSize", "Occupancy")):
-                info.append(("rows " if "k_rows" in cur else "prop ") + ln.split("remark:")[1].strip().split(" [")[0])
+                info.append(("rows " if "k_rows" in cur else ("cols " if "k_cols" in cur else "prop ")) + ln.split("remark:")[1].strip().split(" [")[0])
         print(name, pr.returncode, "; ".join(info), flush=True)
 
 
