@@ -76,9 +76,7 @@ def _as_text(source, norad_id=None, fetch=None, allow_network=False):
     """The element text behind `source`: the string itself when it already is element data, the contents of the
     local file it names, or -- opt-in, see the module docstring -- what a URL / CelesTrak group name / `norad_id`
     resolves to (reference: bindings/python/astroz/__init__.py L163-181)."""
-    if norad_id is not None:
-        if source is not None:
-            raise ValueError("pass either 'source' or 'norad_id', not both")
+    if norad_id is not None:   # (with both given the catalog number wins, as in the reference: __init__.py L163-166)
         return _download(celestrak_url(norad_id=norad_id), fetch, allow_network)
     if source is None:
         raise ValueError("Must specify 'source' or 'norad_id'")
@@ -105,9 +103,9 @@ def _as_text(source, norad_id=None, fetch=None, allow_network=False):
             raise ValueError("empty CelesTrak group name")
         return _download(celestrak_url(group=name), fetch, allow_network)
     if one_line and name and all(c.isalnum() or c in "-_" for c in name):
-        if "." in name or os.sep in name:
-            raise FileNotFoundError(name)
         return _download(celestrak_url(group=name), fetch, allow_network)
+    if one_line and name and " " not in name and ("." in name or os.sep in name):
+        raise FileNotFoundError(name)   # looks like a path (catalog.tle, data/active.txt) and is not there: not a group name
     raise ValueError("source is neither TLE text, OMM JSON, an existing local file, a URL nor a CelesTrak group name")
 
 
@@ -260,8 +258,8 @@ def propagate(source, times, *, start_time=None, output="ecef", velocities=False
         raise ValueError("output must be 'ecef', 'teme', or 'geodetic'")
     minutes, offsets, start = _minutes_and_offsets(const, times, start_time)
     shape = (len(minutes), const.num_satellites, 3)
-    pos = np.empty(shape, dtype=np.float64)
-    vel = np.empty(shape, dtype=np.float64) if velocities else None
+    pos = _native.result_empty(shape)     # (large results: pinned memory the device-to-host DMA writes directly)
+    vel = _native.result_empty(shape) if velocities else None
     const._dev.propagate_host(minutes, offsets, pos=pos, vel=vel, mode=_native.OUTPUT_MODES[output],
                               reference_jd=start, layout=_native.TIME_MAJOR)
     return (pos, vel) if velocities else pos
@@ -317,17 +315,13 @@ def hohmann_transfer(mu, r1, r2):
         _fields_ = [(k, C.c_double) for k in ("sma", "dv1", "dv2", "total_dv", "transfer_time", "transfer_time_days")]
     h = _H()
     rc = _native.lib().orbital_hohmann(float(mu), float(r1), float(r2), C.byref(h))
-    if rc == _native.AZ_ERR_HIP:
-        raise _native.NativeError(rc, "orbital_hohmann")   # no device: not an argument error
     if rc != 0:
         raise ValueError("invalid transfer parameters (radii must be positive and differ by >1000 km)")
     return {k: getattr(h, k) for k, _ in _H._fields_}
 
 
 def _scalar(v, what, bad):
-    if v != v:   # NaN: the closed forms run on the device like every other floating-point path -- none visible
-        raise _native.NativeError(_native.AZ_ERR_HIP, what)
-    if v < 0:
+    if v < 0:   # (the c_api's -1.0 for an invalid radius / semi-major axis)
         raise ValueError(bad)
     return v
 

@@ -31,7 +31,7 @@ EXPORTS = [
     "azh_num_satellites", "azh_num_sgp4", "azh_num_sdp4", "azh_get_epochs", "azh_get_status",
     "azh_get_field", "azh_propagate_host", "azh_propagate_device", "azh_propagate_device_cached", "azh_propagate_device_window",
     "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile", "azh_set_timing", "azh_set_fast_path", "azh_set_tile_kernel", "azh_set_f32_arithmetic", "azh_set_f32_mode",
-    "azh_last_kernel_ms", "azh_last_path", "azh_last_one_stats", "azh_set_host_copy_threads", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
+    "azh_last_kernel_ms", "azh_last_path", "azh_last_one_stats", "azh_set_host_copy_threads", "azh_selftest_coords", "azh_host_alloc", "azh_host_free", "azh_host_pool_stats", "azh_host_pool_trim", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
     "azh_screen_target_host", "azh_screen_target_device", "azh_coarse_screen_device", "azh_coarse_screen_host",
     "azh_screen_all_host", "azh_constellation_from_omm_json", "azh_propagate_one_device", "azh_selftest_math",
     "azh_parse_tle_text", "azh_parse_omm_json", "azh_set_parse_threads", "coords_julian_to_gmst",
@@ -192,6 +192,14 @@ def lib():
     L.azh_last_kernel_ms.restype = dbl
     L.azh_set_host_copy_threads.argtypes = [i32]
     L.azh_set_host_copy_threads.restype = None
+    L.azh_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.azh_host_alloc.restype = i32
+    L.azh_host_free.argtypes = [C.c_void_p]
+    L.azh_host_free.restype = None
+    L.azh_host_pool_stats.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.azh_host_pool_stats.restype = None
+    L.azh_host_pool_trim.argtypes = []
+    L.azh_host_pool_trim.restype = None
     L.azh_last_path.argtypes = [vp]
     L.azh_last_path.restype = u32
     L.azh_last_one_stats.argtypes = [vp, vp, vp]
@@ -410,8 +418,8 @@ class DeviceConstellation:
     def propagate_one(self, sat_index, tsince_min):
         t = _f64(np.atleast_1d(tsince_min))
         n = len(t)
-        pos = np.empty((n, 3))
-        vel = np.empty((n, 3))
+        pos = result_empty((n, 3))      # (long series: pinned blocks of the library's pool, the DMA writes them directly)
+        vel = result_empty((n, 3))
         err = np.empty(n, dtype=np.uint8)
         check(lib().azh_propagate_one_host(self._h, sat_index, t.ctypes.data, n, pos.ctypes.data, vel.ctypes.data,
                                            err.ctypes.data), "azh_propagate_one_host")
@@ -509,8 +517,8 @@ class DeviceGroup:
         """-> pos (n, n_times, 3)[, vel][, err (n, n_times) u8], catalog order, host arrays."""
         t = _f64(times_min)
         off = self._offsets(offsets_min)
-        pos = np.empty((self.n, len(t), 3))
-        vel = np.empty_like(pos) if velocities else None
+        pos = result_empty((self.n, len(t), 3))
+        vel = result_empty((self.n, len(t), 3)) if velocities else None
         err = np.zeros((self.n, len(t)), dtype=np.uint8) if errors else None
         check(lib().azh_group_propagate_host(self._h, t.ctypes.data, len(t), _ptr(off), 0 if off is None else len(off), pos.ctypes.data, _ptr(vel), mode,
                                              float(reference_jd), _ptr(err)), "azh_group_propagate_host")
@@ -525,6 +533,64 @@ class DeviceGroup:
         vv = (C.c_void_p * self.n_devices)(*d_vel_ptrs) if d_vel_ptrs is not None else None
         check(lib().azh_group_propagate_allgather(self._h, t.ctypes.data, len(t), _ptr(off), 0 if off is None else len(off), pp, vv),
               "azh_group_propagate_allgather")
+
+
+class _PinnedBlock:
+    """Owner of one azh_host_alloc block: returns it to the library's pool when the last array over it is gone."""
+    __slots__ = ("ptr", "_free", "__weakref__")
+
+    def __init__(self, nbytes):
+        self.ptr = None
+        q = C.c_void_p(0)
+        check(lib().azh_host_alloc(int(nbytes), C.byref(q)), "azh_host_alloc")
+        self.ptr, self._free = q.value, lib().azh_host_free
+
+    def __del__(self):
+        if self.ptr:
+            self._free(self.ptr)
+            self.ptr = None
+
+
+_PINNED_RESULTS = True
+PINNED_MIN_BYTES = 8 << 20   # below this a pageable array costs nothing measurable (the small-call paths do not copy at all)
+
+
+def set_pinned_results(enabled):
+    """Result arrays of the host-returning Python calls (SatrecArray.sgp4, propagate, DeviceGroup.propagate_host) come from the
+    library's pinned pool (default: True for results of 8 MiB and more): the device-to-host DMA lands in them directly.
+    False: plain numpy.empty arrays, filled through the pinned staging slots (about 25 % slower, no pinned memory held by
+    results the caller keeps)."""
+    global _PINNED_RESULTS
+    _PINNED_RESULTS = bool(enabled)
+
+
+def result_empty(shape, dtype=np.float64, pinned=None):
+    """numpy.empty for a RESULT of a host-returning call: a writable C-contiguous ndarray over a pinned block of the library's
+    pool (returned to the pool when the array and all its views are gone), or a plain numpy array when pinned results are
+    switched off, the array is small, or the host cannot pin the memory."""
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    use = _PINNED_RESULTS if pinned is None else pinned
+    if not use or nbytes < PINNED_MIN_BYTES:
+        return np.empty(shape, dtype=dt)
+    try:
+        blk = _PinnedBlock(nbytes)
+    except NativeError:
+        return np.empty(shape, dtype=dt)
+    buf = (C.c_char * nbytes).from_address(blk.ptr)
+    buf._az_owner = blk          # the ctypes array is the ndarray's base: the block lives as long as any view does
+    return np.frombuffer(buf, dtype=dt).reshape(shape)
+
+
+def host_pool_stats():
+    """(bytes of pinned result blocks in use, bytes kept free in the pool)"""
+    a, b = C.c_size_t(0), C.c_size_t(0)
+    lib().azh_host_pool_stats(C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
+
+
+def host_pool_trim():
+    lib().azh_host_pool_trim()
 
 
 def set_host_copy_threads(n):

@@ -202,8 +202,10 @@ class SatrecArray:
         views (api.py L307-320)."""
         times, offsets = self._grid(jd, fr)
         n_times, n_sats = len(times), self._num_sats
-        r_tm = np.empty((n_times, n_sats, 3), dtype=np.float64)
-        v_tm = np.empty((n_times, n_sats, 3), dtype=np.float64) if velocities else None
+        # the callee allocates, as in the reference (api.py L304-314) -- from pinned memory the DMA engines write directly
+        # (large results; _native.set_pinned_results(False) restores plain numpy.empty arrays)
+        r_tm = _native.result_empty((n_times, n_sats, 3))
+        v_tm = _native.result_empty((n_times, n_sats, 3)) if velocities else None
         e = np.zeros((n_sats, n_times), dtype=np.uint8)
         self._dev.propagate_host(times, offsets, pos=r_tm, vel=v_tm, layout=_native.TIME_MAJOR, err=e)
         r = r_tm.transpose(1, 0, 2)

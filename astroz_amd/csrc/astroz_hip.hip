@@ -11,6 +11,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -169,7 +170,8 @@ struct azh_constellation {
     DevBuf<unsigned char> d_one_e;
     DevBuf<unsigned> d_one_items; // k_one_fast -> k_one_satellite hand-over list (count, then segment indices)
     unsigned one_segments = 0;     // segments of the most recent one-satellite call that k_one_fast was launched on (azh_last_one_stats)
-    hipStream_t one_stream = nullptr;
+    hipEvent_t ev_one = nullptr;   // recorded behind the kernels of the most recent k_one_fast call (azh_last_one_stats waits on it:
+                                   // the caller's stream may be gone by then)
     void *h_stage = nullptr; // pinned host staging for small one-satellite calls: h_stage_cap points (grows to kOneStage)
     size_t h_stage_cap = 0;
     // the inputs of the staged grid (stage_inputs skips the staging of byte-identical ones)
@@ -254,6 +256,7 @@ void destroy(azh_constellation *c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_fork2) (void)hipEventDestroy(c->ev_fork2);
     if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
+    if (c->ev_one) (void)hipEventDestroy(c->ev_one);
     if (c->s_ecc && c->s_ecc != c->s_main) (void)hipStreamDestroy(c->s_ecc);
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
@@ -296,6 +299,7 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
             !hip_ok(hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&c->ev_one, hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreate(&c->ev_t0), "hipEventCreate") || !hip_ok(hipEventCreate(&c->ev_t1), "hipEventCreate")) {
             rc = AZ_ERR_HIP;
             break;
@@ -1155,6 +1159,110 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     return AZ_OK;
 }
 
+// Pinned host memory the library hands out for RESULTS (azh_host_alloc / azh_host_free): a host-returning call whose output
+// arrays live here needs no staging hop and no copy threads -- the device-to-host DMA lands in the caller's array at the link
+// rate (57 GB/s: config 2's 932 MB in 16.4 ms; through the pinned staging slots into fresh pageable arrays: 20-25 ms; straight
+// into fresh pageable arrays: 55 ms).  Pinning is the expensive part (hundreds of milliseconds per GB), so freed blocks stay
+// pinned in a pool and the next result of that size takes them over; the pool keeps at most ASTROZ_AMD_HOST_POOL_MB (default
+// 4,096) of free blocks.  What the reference's own Python layer does at this point is numpy.empty per call (api.py L304-314):
+// the callee allocates -- here too, from memory the DMA engines can write.
+class HostPool {
+  public:
+    int32_t alloc(size_t bytes, void **out)
+    {
+        if (!out) return AZ_ERR_NULL_POINTER;
+        *out = nullptr;
+        const size_t need = std::max<size_t>((bytes + kGrain - 1) / kGrain * kGrain, kGrain);
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            auto it = free_.lower_bound(need);
+            if (it != free_.end() && it->first <= need + need / 4 + kGrain) { // (a block up to 25 % larger serves)
+                void *q = it->second;
+                free_bytes_ -= it->first;
+                live_[static_cast<char *>(q)] = it->first;
+                free_.erase(it);
+                *out = q;
+                return AZ_OK;
+            }
+        }
+        void *q = nullptr;
+        if (hipHostMalloc(&q, need, hipHostMallocPortable) != hipSuccess || !q) {
+            (void)hipGetLastError();
+            trim(0); // give the runtime the pool's free blocks back and try once more
+            if (!hip_ok(hipHostMalloc(&q, need, hipHostMallocPortable), "hipHostMalloc(result)")) return AZ_ERR_ALLOC_FAILED;
+        }
+        std::lock_guard<std::mutex> lock(mu_);
+        live_[static_cast<char *>(q)] = need;
+        *out = q;
+        return AZ_OK;
+    }
+    void release(void *q)
+    {
+        if (!q) return;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            auto it = live_.find(static_cast<char *>(q));
+            if (it == live_.end()) return; // not ours
+            free_.emplace(it->second, q);
+            free_bytes_ += it->second;
+            live_.erase(it);
+        }
+        trim(cap());
+    }
+    // [q, q + len) lies inside one live block
+    bool owns(const void *q, size_t len)
+    {
+        if (!q) return false;
+        std::lock_guard<std::mutex> lock(mu_);
+        auto it = live_.upper_bound(const_cast<char *>(static_cast<const char *>(q)));
+        if (it == live_.begin()) return false;
+        --it;
+        return static_cast<const char *>(q) + len <= it->first + it->second;
+    }
+    void stats(size_t *live_bytes, size_t *free_bytes)
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        size_t l = 0;
+        for (auto &kv : live_) l += kv.second;
+        if (live_bytes) *live_bytes = l;
+        if (free_bytes) *free_bytes = free_bytes_;
+    }
+    void trim(size_t keep)
+    {
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            while (free_bytes_ > keep && !free_.empty()) {
+                auto it = std::prev(free_.end()); // largest first
+                drop.push_back(it->second);
+                free_bytes_ -= it->first;
+                free_.erase(it);
+            }
+        }
+        for (void *q : drop) (void)hipHostFree(q);
+    }
+
+  private:
+    static constexpr size_t kGrain = size_t(2) << 20;
+    static size_t cap()
+    {
+        static const size_t c = [] {
+            const char *e = getenv("ASTROZ_AMD_HOST_POOL_MB");
+            return (size_t)(e ? std::max(0L, atol(e)) : 4096L) << 20;
+        }();
+        return c;
+    }
+    std::mutex mu_;
+    std::map<char *, size_t> live_;
+    std::multimap<size_t, void *> free_;
+    size_t free_bytes_ = 0;
+};
+HostPool &host_pool()
+{
+    static HostPool *p = new HostPool(); // (never destroyed: at process exit the HIP runtime may already be gone)
+    return *p;
+}
+
 // Device -> caller's host arrays.  A D2H straight into pageable memory runs at the PCIe rate only when the runtime has seen
 // the destination before: config 2's 932 MB take 17 ms into arrays a previous call wrote, but 55 ms into FRESH ones
 // (numpy.empty every call -- what SatrecArray.sgp4 does), and mapping the pages beforehand does not help (measured with 0-16
@@ -1297,7 +1405,6 @@ int32_t launch_one(azh_constellation *c, size_t sat, const double *d_t, size_t n
     const unsigned f = sat < c->h_flags.size() ? c->h_flags[sat] : ~0u;
     const bool fast = AZ_ONE_FAST && !interleaved && n >= kOneFastMin && f != ~0u && AZ_FLAG_ERR(f) == 0 && !(f & AZ_FLAG_DEEP);
     c->one_segments = 0;
-    c->one_stream = st;
     if (fast) {
         const unsigned n_seg = (unsigned)((n + AZ_ONE_SEG - 1) / AZ_ONE_SEG);
         const unsigned cap = (n_seg + AZ_ONE_LISTS - 1) / AZ_ONE_LISTS; // capacity of each of the AZ_ONE_LISTS hand-over lists
@@ -1313,6 +1420,7 @@ int32_t launch_one(azh_constellation *c, size_t sat, const double *d_t, size_t n
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL((k_one_satellite<true>), dim3(4096), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad, (unsigned)sat, d_t,
                            (unsigned)n, d_p, d_v, d_e, 0, c->g, (const double *)nullptr, 0, (const unsigned *)c->d_one_items.p, cap);
+        HIP_TRY(hipEventRecord(c->ev_one, st));
     } else {
         hipLaunchKernelGGL((k_one_satellite<false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
                            (unsigned)sat, d_t, (unsigned)n, d_p, d_v, d_e, interleaved, c->g, (const double *)nullptr, 0,
@@ -1415,7 +1523,8 @@ int32_t run_one_satellite(azh_constellation *c, size_t sat, const double *tsince
                                (!interleaved && err) ? n : 0};
         const unsigned thr = host_copy_threads();
         bool ok = true;
-        if (thr > 0 && len[0] + len[1] + len[2] >= (size_t(8) << 20)) {
+        const bool pinned_out = host_pool().owns(dst[0], len[0]) && (!len[1] || host_pool().owns(dst[1], len[1])); // azh_host_alloc
+        if (!pinned_out && thr > 0 && len[0] + len[1] + len[2] >= (size_t(8) << 20)) {
             ok = copy_back_staged(c->stager, dst, src, len, 3, st, thr) == AZ_OK;
         } else {
             for (int k = 0; k < 3 && ok; ++k)
@@ -1651,6 +1760,17 @@ int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t enabled)
 
 void azh_set_host_copy_threads(int32_t n) { g_host_copy_threads.store(n < 0 ? -1 : n, std::memory_order_relaxed); }
 
+int32_t azh_host_alloc(size_t bytes, void **out)
+{
+    return guarded([&]() -> int32_t { return host_pool().alloc(bytes, out); });
+}
+void azh_host_free(void *p)
+{
+    (void)guarded([&]() -> int32_t { host_pool().release(p); return AZ_OK; });
+}
+void azh_host_pool_stats(size_t *live_bytes, size_t *free_bytes) { host_pool().stats(live_bytes, free_bytes); }
+void azh_host_pool_trim(void) { host_pool().trim(0); }
+
 int32_t azh_set_tile_kernel(azh_constellation *c, int32_t enabled)
 {
     if (!c) return AZ_ERR_NULL_POINTER;
@@ -1694,7 +1814,7 @@ int32_t azh_propagate_device(azh_constellation *c, const double *times, size_t n
     return guarded([&]() -> int32_t { return azh_propagate_device_impl(c, times, n_times, offsets, d_pos, d_vel, mode, reference_jd, mask, layout, stride, d_err, stream); });
 }
 
-int32_t azh_propagate_device_cached(azh_constellation *c, double *d_pos, double *d_vel, int32_t layout,
+static int32_t azh_propagate_device_cached_impl(azh_constellation *c, double *d_pos, double *d_vel, int32_t layout,
                                     size_t stride, uint8_t *d_err, void *stream)
 {
     if (!c || !d_pos) return AZ_ERR_NULL_POINTER;
@@ -1703,8 +1823,13 @@ int32_t azh_propagate_device_cached(azh_constellation *c, double *d_pos, double 
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
     return launch_all(c, d_pos, d_vel, layout, stride, d_err, stream ? (hipStream_t)stream : c->s_main);
 }
+int32_t azh_propagate_device_cached(azh_constellation *c, double *d_pos, double *d_vel, int32_t layout,
+                                    size_t stride, uint8_t *d_err, void *stream)
+{
+    return guarded([&]() -> int32_t { return azh_propagate_device_cached_impl(c, d_pos, d_vel, layout, stride, d_err, stream); });
+}
 
-int32_t azh_propagate_device_window(azh_constellation *c, size_t row_lo, size_t row_hi, double *d_pos, double *d_vel,
+static int32_t azh_propagate_device_window_impl(azh_constellation *c, size_t row_lo, size_t row_hi, double *d_pos, double *d_vel,
                                     int32_t layout, size_t stride, uint8_t *d_err, void *stream)
 {
     if (!c || !d_pos) return AZ_ERR_NULL_POINTER;
@@ -1713,8 +1838,13 @@ int32_t azh_propagate_device_window(azh_constellation *c, size_t row_lo, size_t 
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
     return launch_all(c, d_pos, d_vel, layout, stride, d_err, stream ? (hipStream_t)stream : c->s_main, 0, row_lo, row_hi);
 }
+int32_t azh_propagate_device_window(azh_constellation *c, size_t row_lo, size_t row_hi, double *d_pos, double *d_vel,
+                                    int32_t layout, size_t stride, uint8_t *d_err, void *stream)
+{
+    return guarded([&]() -> int32_t { return azh_propagate_device_window_impl(c, row_lo, row_hi, d_pos, d_vel, layout, stride, d_err, stream); });
+}
 
-int32_t azh_propagate_device_f32(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+static int32_t azh_propagate_device_f32_impl(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
                                  float *d_pos, float *d_vel, int32_t mode, double reference_jd, const uint8_t *mask,
                                  int32_t layout, size_t stride, uint8_t *d_err, void *stream)
 {
@@ -1727,8 +1857,14 @@ int32_t azh_propagate_device_f32(azh_constellation *c, const double *times, size
     if (rc != AZ_OK) return rc;
     return launch_all(c, reinterpret_cast<double *>(d_pos), reinterpret_cast<double *>(d_vel), layout, stride, d_err, st, 1);
 }
+int32_t azh_propagate_device_f32(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+                                 float *d_pos, float *d_vel, int32_t mode, double reference_jd, const uint8_t *mask,
+                                 int32_t layout, size_t stride, uint8_t *d_err, void *stream)
+{
+    return guarded([&]() -> int32_t { return azh_propagate_device_f32_impl(c, times, n_times, offsets, d_pos, d_vel, mode, reference_jd, mask, layout, stride, d_err, stream); });
+}
 
-int32_t azh_propagate_device_cached_f32(azh_constellation *c, float *d_pos, float *d_vel, int32_t layout, size_t stride,
+static int32_t azh_propagate_device_cached_f32_impl(azh_constellation *c, float *d_pos, float *d_vel, int32_t layout, size_t stride,
                                         uint8_t *d_err, void *stream)
 {
     if (!c || !d_pos) return AZ_ERR_NULL_POINTER;
@@ -1738,10 +1874,15 @@ int32_t azh_propagate_device_cached_f32(azh_constellation *c, float *d_pos, floa
     return launch_all(c, reinterpret_cast<double *>(d_pos), reinterpret_cast<double *>(d_vel), layout, stride, d_err,
                       stream ? (hipStream_t)stream : c->s_main, 1);
 }
+int32_t azh_propagate_device_cached_f32(azh_constellation *c, float *d_pos, float *d_vel, int32_t layout, size_t stride,
+                                        uint8_t *d_err, void *stream)
+{
+    return guarded([&]() -> int32_t { return azh_propagate_device_cached_f32_impl(c, d_pos, d_vel, layout, stride, d_err, stream); });
+}
 
 // Fused single-target conjunction screen (Constellation.screenConstellation, src/Constellation.zig
 // L683-756): nothing but 12 bytes per satellite ever leaves the chip.
-int32_t azh_screen_target_device(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+static int32_t azh_screen_target_device_impl(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
                                  size_t target, double threshold_km, double reference_jd, double *d_min_dist,
                                  uint32_t *d_min_t, void *stream)
 {
@@ -1865,6 +2006,12 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
         c->timed = true;
     }
     return AZ_OK;
+}
+int32_t azh_screen_target_device(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
+                                 size_t target, double threshold_km, double reference_jd, double *d_min_dist,
+                                 uint32_t *d_min_t, void *stream)
+{
+    return guarded([&]() -> int32_t { return azh_screen_target_device_impl(c, times, n_times, offsets, target, threshold_km, reference_jd, d_min_dist, d_min_t, stream); });
 }
 
 static int32_t azh_screen_target_host_impl(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
@@ -2121,7 +2268,9 @@ static int32_t azh_propagate_host_impl(azh_constellation *c, const double *times
         const void *const src[3] = {d_pos, d_vel, d_err};
         const size_t len[3] = {bytes, vel ? bytes : 0, err ? c->n * n_times : 0};
         const unsigned thr = host_copy_threads();
-        if (thr > 0 && len[0] + len[1] + len[2] >= (size_t(8) << 20)) {
+        // result arrays from azh_host_alloc are pinned: the DMA goes straight into them (no staging hop, no copy threads)
+        const bool pinned_out = host_pool().owns(pos, bytes) && (!vel || host_pool().owns(vel, bytes));
+        if (!pinned_out && thr > 0 && len[0] + len[1] + len[2] >= (size_t(8) << 20)) {
             if ((rc = copy_back_staged(c->stager, dst, src, len, 3, c->s_main, thr)) != AZ_OK) break;
         } else {
             for (int k = 0; k < 3 && rc == AZ_OK; ++k)
@@ -2181,7 +2330,7 @@ int32_t azh_last_one_stats(azh_constellation *c, uint32_t *n_segments, uint32_t 
     *n_handed_over = 0;
     if (c->one_segments == 0) return AZ_OK;
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
-    HIP_TRY(hipStreamSynchronize(c->one_stream));
+    HIP_TRY(hipEventSynchronize(c->ev_one));
     unsigned head[AZ_ONE_HEAD]; // (8 KB: the list heads sit on their own 128-byte lines)
     HIP_TRY(hipMemcpy(head, c->d_one_items.p, sizeof(head), hipMemcpyDeviceToHost));
     unsigned cnt = 0;
@@ -2430,7 +2579,7 @@ int32_t azh_group_get_epochs(const azh_group *g, double *out)
     return AZ_OK;
 }
 
-int32_t azh_group_propagate_host(azh_group *g, const double *times, size_t n_times, const double *offsets, size_t n_offsets,
+static int32_t azh_group_propagate_host_impl(azh_group *g, const double *times, size_t n_times, const double *offsets, size_t n_offsets,
                                  double *pos, double *vel, int32_t mode, double reference_jd, uint8_t *err)
 {
     if (!g || !pos || (n_times && !times)) return AZ_ERR_NULL_POINTER;
@@ -2453,9 +2602,11 @@ int32_t azh_group_propagate_host(azh_group *g, const double *times, size_t n_tim
     // thread, host-synchronous pageable copies would take turns) and at least N threads write the host arrays.
     if (rc == AZ_OK) {
         std::vector<int32_t> rcs(g->n_dev, AZ_OK);
-        const bool staged = host_copy_threads() > 0;
+        const size_t arr_bytes = g->n * row * sizeof(double);
+        // (result arrays from azh_host_alloc are pinned: every device's DMA goes straight into them)
+        const bool staged = host_copy_threads() > 0 && !(host_pool().owns(pos, arr_bytes) && (!vel || host_pool().owns(vel, arr_bytes)));
         const unsigned per_dev = std::max(1u, host_copy_threads() / (unsigned)std::max(1, g->n_dev)); // host threads behind each device
-        auto copier = [&](int d) {
+        auto copy_cells = [&](int d) {
             azh_constellation *c = g->shard[d];
             if (!c) return;
             if (hipSetDevice(c->device) != hipSuccess) { rcs[d] = AZ_ERR_HIP; return; }
@@ -2483,6 +2634,16 @@ int32_t azh_group_propagate_host(azh_group *g, const double *times, size_t n_tim
             }
             if (hipStreamSynchronize(c->s_main) != hipSuccess) rcs[d] = AZ_ERR_HIP;
         };
+        // (it runs in std::thread: an exception that left it -- a vector growing out of memory -- would be std::terminate)
+        auto copier = [&](int d) {
+            try {
+                copy_cells(d);
+            } catch (const std::bad_alloc &) {
+                rcs[d] = AZ_ERR_ALLOC_FAILED;
+            } catch (...) {
+                rcs[d] = AZ_ERR_UNKNOWN;
+            }
+        };
         std::vector<std::thread> th;
         for (int d = 1; d < g->n_dev; ++d) {
             try {
@@ -2504,8 +2665,13 @@ int32_t azh_group_propagate_host(azh_group *g, const double *times, size_t n_tim
     }
     return rc;
 }
+int32_t azh_group_propagate_host(azh_group *g, const double *times, size_t n_times, const double *offsets, size_t n_offsets,
+                                 double *pos, double *vel, int32_t mode, double reference_jd, uint8_t *err)
+{
+    return guarded([&]() -> int32_t { return azh_group_propagate_host_impl(g, times, n_times, offsets, n_offsets, pos, vel, mode, reference_jd, err); });
+}
 
-int32_t azh_group_propagate_allgather(azh_group *g, const double *times, size_t n_times, const double *offsets, size_t n_offsets,
+static int32_t azh_group_propagate_allgather_impl(azh_group *g, const double *times, size_t n_times, const double *offsets, size_t n_offsets,
                                       double *const *d_pos, double *const *d_vel)
 {
     if (!g || !d_pos || (n_times && !times)) return AZ_ERR_NULL_POINTER;
@@ -2569,6 +2735,11 @@ int32_t azh_group_propagate_allgather(azh_group *g, const double *times, size_t 
             rc = rc == AZ_OK ? AZ_ERR_HIP : rc;
     }
     return rc;
+}
+int32_t azh_group_propagate_allgather(azh_group *g, const double *times, size_t n_times, const double *offsets, size_t n_offsets,
+                                      double *const *d_pos, double *const *d_vel)
+{
+    return guarded([&]() -> int32_t { return azh_group_propagate_allgather_impl(g, times, n_times, offsets, n_offsets, d_pos, d_vel); });
 }
 
 // ======================================================================================= (A)
@@ -2655,10 +2826,8 @@ int32_t sgp4_propagate_batch(void *h, const double *times, double *results, uint
     return run_one_satellite(static_cast<Sgp4Handle *>(h)->c, 0, times, count, 1, results, nullptr, nullptr, nullptr);
 }
 
-// root.zig L73-81 / src/c_api/coordinates.zig: the output-mode math of the constellation path as scalar calls.
-// One tiny launch each, on device 0, using the very device functions of the kernels' epilogue (k_gmst,
-// az_to_ecef, az_ecef_to_geodetic) -- no host-side floating point.  A round trip to the GPU per call (~25 us):
-// loops belong in azh_propagate_*'s output modes.  Without a device the outputs are NaN.
+// the device side of azh_selftest_coords: one tiny launch on device 0 through the very device functions of the kernels' epilogue
+// (k_gmst's formula, az_to_ecef, az_ecef_to_geodetic)
 namespace {
 int32_t coords_call(int op, const double in[4], double *out, int n_out = 3)
 {
@@ -2669,6 +2838,7 @@ int32_t coords_call(int op, const double in[4], double *out, int n_out = 3)
     for (int i = 0; i < n_out; ++i) out[i] = nan;
     if (!hip_ok(hipSetDevice(0), "hipSetDevice")) return AZ_ERR_HIP;
     if (!d_buf && !hip_ok(hipMalloc((void **)&d_buf, sizeof(double) * 12), "hipMalloc")) return AZ_ERR_HIP;
+    HIP_TRY(hipMemset(d_buf + 4, 0, sizeof(double) * 8));
     HIP_TRY(hipMemcpy(d_buf, in, sizeof(double) * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_coords, dim3(1), dim3(64), 0, nullptr, op, d_buf, d_buf + 4);
     HIP_TRY(hipGetLastError());
@@ -2677,64 +2847,87 @@ int32_t coords_call(int op, const double in[4], double *out, int n_out = 3)
 }
 } // namespace
 
-// orbital_* (src/c_api/root.zig L60-71 over src/c_api/orbital_mechanics.zig): four closed-form scalars a link-time client of
-// libastroz_c.so resolves; evaluated on the device like coords_* (no host-side floating point: NaN / AZ_ERR_HIP without one)
+// The seven closed-form scalars of the reference's c_api (src/c_api/root.zig L60-81): pure host functions there, pure host
+// functions here -- a link-time client of libastroz_c.so gets them without a device (rounds 2-4 evaluated them in a
+// one-thread kernel behind a mutex: an H2D copy, a launch and a D2H copy for a square root, and NaN without a GPU).  They are
+// not on the propagation path; the rule "no CPU fallback" is about that path (tests/test_host_cpu.py::test_no_cpu_fallback).
+// The device evaluations stay as known-answer tests of the device code they share with the output frames of the kernels
+// (az_to_ecef, az_ecef_to_geodetic): azh_selftest_coords.
+//
+// orbital_*: src/c_api/orbital_mechanics.zig over src/calculations.zig L83-125
 int32_t orbital_hohmann(double mu, double r1, double r2, azh_hohmann_result *out)
 {
     if (!out) return AZ_ERR_NULL_POINTER;
     if (r1 <= 0 || r2 <= 0 || std::fabs(r1 - r2) < 1000) return AZ_ERR_VALUE;
-    const double in[4] = {mu, r1, r2, 0};
-    double o[5];
-    const int32_t rc = coords_call(4, in, o, 5);
-    out->semi_major_axis = o[0]; out->delta_v1 = o[1]; out->delta_v2 = o[2]; out->total_delta_v = o[3];
-    out->transfer_time = o[4]; out->transfer_time_days = o[4] / 86400.0;
-    return rc;
+    const double sma = 0.5 * (r1 + r2), v1c = std::sqrt(mu / r1), v2c = std::sqrt(mu / r2);
+    const double dv1 = v1c * std::sqrt(2.0 * r2 / (r1 + r2)) - v1c, dv2 = v2c - v2c * std::sqrt(2.0 * r1 / (r1 + r2));
+    out->semi_major_axis = sma; out->delta_v1 = dv1; out->delta_v2 = dv2; out->total_delta_v = std::fabs(dv1) + std::fabs(dv2);
+    out->transfer_time = AZ_PI * std::sqrt(sma * sma * sma / mu);
+    out->transfer_time_days = out->transfer_time / 86400.0;
+    return AZ_OK;
 }
 double orbital_velocity(double mu, double radius, double sma)
 {
     if (radius <= 0 || sma < 0) return -1.0;
-    const double in[4] = {mu, radius, sma, 0};
-    double o[3];
-    (void)coords_call(3, in, o);
-    return o[0];
+    return std::sqrt(sma != 0.0 ? mu * (2.0 / radius - 1.0 / sma) : mu / radius); // vis-viva; sma = 0: circular
 }
 double orbital_period(double mu, double sma)
 {
     if (sma <= 0) return -1.0;
-    const double in[4] = {mu, 1.0, sma, 0};
-    double o[3];
-    (void)coords_call(3, in, o);
-    return o[1];
+    return 2.0 * AZ_PI * std::sqrt(sma * sma * sma / mu);
 }
 double orbital_escape_velocity(double mu, double radius)
 {
     if (radius <= 0) return -1.0;
-    const double in[4] = {mu, radius, 0, 0};
-    double o[3];
-    (void)coords_call(3, in, o);
-    return o[2];
+    return std::sqrt(2.0 * mu / radius);
 }
 
+// coords_*: src/WorldCoordinateSystem.zig L98-154 (julianToGmst, eciToEcef, ecefToGeodeticDeg)
 double coords_julian_to_gmst(double jd)
 {
-    const double in[4] = {jd, 0, 0, 0};
-    double out[3];
-    (void)coords_call(0, in, out);
-    return out[0];
+    const double d = jd - 2451545.0, tc = d / 36525.0;
+    double gm = 280.46061837 + 360.98564736629 * d + 0.000387933 * tc * tc - tc * tc * tc / 38710000.0;
+    gm = std::fmod(gm, 360.0);
+    if (gm < 0) gm += 360.0;
+    return gm * (AZ_PI / 180.0);
 }
 
 void coords_eci_to_ecef(const double eci[3], double gmst, double ecef[3])
 {
     if (!eci || !ecef) return;
-    const double in[4] = {eci[0], eci[1], eci[2], gmst};
-    (void)coords_call(1, in, ecef);
+    const double sg = std::sin(gmst), cg = std::cos(gmst);
+    const double x = eci[0] * cg + eci[1] * sg, y = eci[1] * cg - eci[0] * sg;
+    ecef[0] = x; ecef[1] = y; ecef[2] = eci[2];
 }
 
 void coords_ecef_to_geodetic(const double ecef[3], double lla[3])
 {
     if (!ecef || !lla) return;
-    const double in[4] = {ecef[0], ecef[1], ecef[2], 0};
-    (void)coords_call(2, in, lla);
+    // the reference's fixed-point iteration, as it stands (WorldCoordinateSystem.zig L98-121): at most ten trips, exit once the
+    // latitude moves by less than 1e-12 rad; degrees out (ecefToGeodeticDeg)
+    const double f = 1.0 / 298.257223563, e2 = 2.0 * f - f * f, a = 6378.137;
+    const double x = ecef[0], y = ecef[1], z = ecef[2];
+    const double lon = std::atan2(y, x), rho = std::sqrt(x * x + y * y);
+    double lat = std::atan2(z, rho * (1.0 - e2));
+    for (int it = 0; it < 10; ++it) {
+        const double prev = lat, sl = std::sin(lat);
+        const double N = a / std::sqrt(1.0 - e2 * sl * sl);
+        lat = std::atan2(z + e2 * N * sl, rho);
+        if (std::fabs(lat - prev) < 1e-12) break;
+    }
+    const double sl = std::sin(lat), cl = std::cos(lat);
+    const double N = a / std::sqrt(1.0 - e2 * sl * sl);
+    lla[0] = lat * (180.0 / AZ_PI); lla[1] = lon * (180.0 / AZ_PI); lla[2] = rho / cl - N;
+}
+
+// known-answer hook: the same seven quantities evaluated ON THE DEVICE (k_coords: the kernels' own frame code).  op 0: GMST of
+// in[0]; 1: ECI in[0..2] -> ECEF at GMST in[3]; 2: ECEF -> (lat deg, lon deg, alt km); 3: (velocity, period, escape velocity)
+// of (mu, radius, sma); 4: Hohmann (sma, dv1, dv2, |dv1| + |dv2|, transfer time) of (mu, r1, r2).  AZ_ERR_HIP without a device.
+int32_t azh_selftest_coords(int32_t op, const double in[4], double out[5])
+{
+    if (!in || !out) return AZ_ERR_NULL_POINTER;
+    if (op < 0 || op > 4) return AZ_ERR_VALUE;
+    return guarded([&]() -> int32_t { return coords_call(op, in, out, 5); });
 }
 
 } // extern "C"

@@ -180,6 +180,15 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             sa = SatrecArray([sat], device=cuda.index or 0)
             us_sa = wall(lambda: sa.sgp4(jd, fr), 200)
             us_one = wall(lambda: sat.sgp4(jd[0], fr[7]), 500)
+            # the same calls on a grid that CHANGES every call (stage_inputs skips the staging of byte-identical
+            # inputs, so the loops above time the repeated-grid case): fr moved by a few microseconds per call
+            box = {"k": 0}
+
+            def fresh():
+                box["k"] += 1
+                return fr + box["k"] * 1e-10
+            us_sa_fresh = wall(lambda: sa.sgp4(jd, fresh()), 200)
+            us_arr_fresh = wall(lambda: sat.sgp4_array(jd, fresh()), 300)
             e_, r_, v_ = sat.sgp4_array(jd, fr)
             e2, r2, v2 = sa.sgp4(jd, fr)
             cat = oracle.Catalog.from_pairs([(l1, l2)], oracle.WGS72)
@@ -187,6 +196,9 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             _, p0, v0 = cat.propagate(ts, None, layout=oracle.SAT_MAJOR)
             ent.update({"ms_per_step": us_arr / 1e3, "value": 1440 / (us_arr / 1e6), "unit": "propagations/s (Satrec.sgp4_array, host arrays)",
                         "sgp4_array_us": us_arr, "satrec_array_sgp4_us": us_sa, "scalar_sgp4_us": us_one,
+                        "sgp4_array_fresh_grid_us": us_arr_fresh, "satrec_array_sgp4_fresh_grid_us": us_sa_fresh,
+                        "note": "sgp4_array_us / satrec_array_sgp4_us: the SAME (jd, fr) every call (the staged grid is reused); "
+                                "*_fresh_grid_us: a different grid every call (times and offsets re-staged, increments / record / plan rebuilt)",
                         "parity": {"max_abs_dr_km": float(max(np.abs(r_ - p0[0]).max(), np.abs(r2[0] - p0[0]).max())),
                                    "max_abs_dv_kms": float(max(np.abs(v_ - v0[0]).max(), np.abs(v2[0] - v0[0]).max())),
                                    "err_nonzero": int(np.count_nonzero(e_) + np.count_nonzero(e2))}})
@@ -219,19 +231,25 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
                 return ws, (e_, r_, v_)
             calls(2)
             ws, (e_, r_, v_) = calls(7)
-            _native.set_host_copy_threads(0)           # the plain path: pageable D2H straight into the fresh arrays
+            _native.set_pinned_results(False)          # numpy.empty results: pinned staging slots + host copy threads (round 4's path)
+            ws1, _ = calls(4)
+            _native.set_host_copy_threads(0)           # ... and the plain path: pageable D2H straight into the fresh arrays
             ws0, _ = calls(3)
             _native.set_host_copy_threads(-1)
+            _native.set_pinned_results(True)
             ms = sorted(ws)[len(ws) // 2]
             out_bytes = r_.nbytes + v_.nbytes + e_.nbytes
             ent.update({"ms_per_step": ms, "min_ms": min(ws), "value": n2 * 1440 / (ms / 1e3), "unit": "propagations/s (host arrays, PCIe-inclusive)",
                         "n_sats": n2, "n_times": 1440, "calls_ms": ws, "d2h_GB_per_s_of_wall": out_bytes / (ms / 1e3) / 1e9,
                         "path": arr._dev.last_path(),
+                        "numpy_empty_staged_ms": sorted(ws1[1:])[len(ws1[1:]) // 2], "numpy_empty_staged_calls_ms": ws1,
                         "direct_pageable_copy_ms": sorted(ws0)[len(ws0) // 2],
-                        "what": "results travel device -> pinned staging slots -> the fresh numpy arrays, the second hop by host threads while "
-                                "the next chunk is on the link (azh_set_host_copy_threads); direct_pageable_copy_ms: the same call with "
-                                "plain pageable D2H copies (the runtime pins the fresh range first).  PCIe Gen5 x16 moves the 932 MB in "
-                                "~16.4 ms: that, not the 0.3-ms kernel, bounds this call"})
+                        "what": "the result arrays are ndarrays over pinned blocks of the library's pool (azh_host_alloc; returned to the pool "
+                                "when the caller drops them): the device-to-host DMA lands in them directly.  numpy_empty_staged_ms: the same "
+                                "call with plain numpy.empty results (_native.set_pinned_results(False)): device -> pinned staging slots -> "
+                                "the fresh arrays by host copy threads; direct_pageable_copy_ms: ... with plain pageable D2H copies (the "
+                                "runtime pins the fresh range first).  PCIe Gen5 x16 moves the 932 MB in ~16.4 ms: that, not the 0.3-ms "
+                                "kernel, bounds this call"})
             rws = _sample_rows(n2, 16)
             cat = oracle.Catalog.from_pairs([pairs2[i] for i in rws], oracle.WGS72)
             rjd = jd[0] + fr[0]

@@ -118,11 +118,18 @@ pub extern "c" fn azh_set_f32_arithmetic(h: ?*Handle, enabled: i32) i32; // bool
 pub extern "c" fn azh_set_fast_path(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_set_tile_kernel(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_set_host_copy_threads(n: i32) void; // host threads behind the pinned staging of host-returning copies (-1 auto, 0 = direct pageable copies)
+// result arrays the DMA engines write directly (pinned, pooled inside the library): a Zig host allocates `positions` / `velocities`
+// here instead of from its allocator, and azh_propagate_host lands in them at the link rate (no staging hop)
+pub extern "c" fn azh_host_alloc(bytes: usize, out: *?*anyopaque) i32;
+pub extern "c" fn azh_host_free(p: ?*anyopaque) void;
+pub extern "c" fn azh_host_pool_stats(live_bytes: ?*usize, free_bytes: ?*usize) void;
+pub extern "c" fn azh_host_pool_trim() void;
 pub extern "c" fn azh_last_path(h: ?*const Handle) u32; // AZH_PATH_* bits: which kernel families the last call launched
 pub extern "c" fn azh_last_one_stats(h: ?*Handle, n_segments: ?*u32, n_handed_over: ?*u32) i32; // last one-satellite call: fast segments / handed over
 pub extern "c" fn azh_propagate_one_device(h: ?*Handle, sat_index: usize, d_tsince_min: [*]const f64, n: usize, d_pos: [*]f64,
     d_vel: ?[*]f64, d_err: ?[*]u8, stream: ?*anyopaque) i32;
 pub extern "c" fn azh_selftest_math(x: [*]const f64, n: usize, out6n: [*]f64, device: i32) i32;
+pub extern "c" fn azh_selftest_coords(op: i32, in: *const [4]f64, out: *[5]f64) i32; // part (A)'s closed forms through the kernels' frame code (KAT)
 
 // src/c_api/coords.zig
 pub extern "c" fn coords_julian_to_gmst(jd: f64) f64;

@@ -82,8 +82,8 @@ int32_t sgp4_propagate_batch(void *handle, const double *times_min, double *resu
 
 /* root.zig L73-81 / src/c_api/coordinates.zig: the output-mode math of this path (WorldCoordinateSystem.zig
  * L87-154) as scalar calls.  gmst in radians; lla = (lat deg, lon deg, alt km), degrees like the reference's
- * ecefToGeodeticDeg.  Each call is one tiny launch on device 0 (the same device functions as the kernels'
- * ECEF / geodetic epilogue); without a device the outputs are NaN. */
+ * ecefToGeodeticDeg.  Pure host functions, as in the reference (no device needed); azh_selftest_coords evaluates the
+ * same quantities through the kernels' own frame code on the device. */
 double coords_julian_to_gmst(double jd);
 void coords_eci_to_ecef(const double eci[3], double gmst, double ecef[3]);
 void coords_ecef_to_geodetic(const double ecef[3], double lla[3]);
@@ -92,7 +92,7 @@ void coords_ecef_to_geodetic(const double ecef[3], double lla[3]);
  * the propagation path but belong to the reference's C surface, so that a client of libastroz_c.so links unchanged.  Same
  * argument checks and return conventions: orbital_hohmann -> AZ_ERR_VALUE for r <= 0 or |r1 - r2| < 1000; the scalar
  * functions return -1.0 for an invalid radius / semi-major axis; orbital_velocity(sma = 0) is the circular speed.
- * Evaluated on device 0 like coords_* (NaN / AZ_ERR_HIP without one). */
+ * Pure host functions like coords_*. */
 typedef struct azh_hohmann_result {
     double semi_major_axis, delta_v1, delta_v2, total_delta_v, transfer_time, transfer_time_days;
 } azh_hohmann_result; /* = HohmannResult, orbital_mechanics.zig L9-16 */
@@ -328,6 +328,11 @@ int32_t azh_propagate_one_device(azh_constellation *c, size_t sat_index, const d
  * [0,n) sin x, [n,2n) cos x, [2n,3n) x*rcp(x), [3n,4n) |x|*rsqrt(|x|)^2, [4n,6n) (sin,cos)(0.7321 + x) obtained
  * by rotating (sin,cos)(0.7321).  Test infrastructure; not part of the reference surface. */
 int32_t azh_selftest_math(const double *x, size_t n, double *out6n, int32_t device);
+/* the seven closed-form scalars of part (A) (coords_*, orbital_*) evaluated ON THE DEVICE through the kernels' own frame code
+ * (known-answer tests; part (A)'s functions themselves are host closed forms).  op 0: GMST of in[0]; 1: ECI in[0..2] -> ECEF
+ * at GMST in[3]; 2: ECEF -> (lat deg, lon deg, alt km); 3: (velocity, period, escape velocity) of (mu, radius, sma);
+ * 4: Hohmann (sma, dv1, dv2, |dv1| + |dv2|, transfer time) of (mu, r1, r2).  Unused outputs are 0. */
+int32_t azh_selftest_coords(int32_t op, const double in[4], double out[5]);
 
 /* tuning knobs (kernel time-tile length; 0 = automatic).  Not part of the reference surface. */
 int32_t azh_set_time_tile(azh_constellation *c, uint32_t sgp4_tile, uint32_t sdp4_tile);
@@ -344,6 +349,18 @@ int32_t azh_set_tile_kernel(azh_constellation *c, int32_t enabled);
  * link.  A direct copy into FRESH pageable arrays pays the runtime's first-time pinning of the range (config 2: 55 ms instead
  * of the link's 17).  -1 automatic (default: 6), 0 = direct pageable copies. */
 void azh_set_host_copy_threads(int32_t n);
+/* Result arrays the DMA engines can write: pinned host memory from a pool inside the library.  A host-returning call
+ * (azh_propagate_host, azh_propagate_jd_host, azh_group_propagate_host, azh_propagate_one_host) whose pos / vel arrays were
+ * allocated here skips the staging hop: the device-to-host copy lands in them at the link rate (config 2's 932 MB: 16.4 ms
+ * on PCIe Gen5 x16, against 20-25 ms through the staging slots into fresh pageable arrays).  azh_host_free returns a block
+ * to the pool (it stays pinned for the next result of that size; at most ASTROZ_AMD_HOST_POOL_MB -- default 4,096 -- of free
+ * blocks are kept); azh_host_pool_trim releases the free blocks.  The reference's Python layer allocates its results itself
+ * per call (numpy.empty, bindings/python/astroz/api.py L304-314); astroz_amd.api does the same from this pool.
+ * Any thread; blocks are 2-MiB multiples.  AZ_ERR_ALLOC_FAILED when the host cannot pin the memory. */
+int32_t azh_host_alloc(size_t bytes, void **out);
+void azh_host_free(void *p);
+void azh_host_pool_stats(size_t *live_bytes, size_t *free_bytes);
+void azh_host_pool_trim(void);
 /* enable (default) / disable the hipEvent pair recorded around every propagate call; disabling it
  * removes two event records per call from tight replay loops (azh_last_kernel_ms then returns -1) */
 int32_t azh_set_timing(azh_constellation *c, int32_t enabled);

@@ -132,3 +132,92 @@ def test_cols_kernel_opt_in(native, orc, synth, grid):
     dev.synchronize()
     assert dev.last_path() & native.PATH_TILES_FAST
     assert np.abs((pos2.cpu().numpy() - p0)[:, good]).max() < TOL_R
+
+
+def test_pinned_result_arrays(native, synth):
+    """SatrecArray.sgp4 / propagate() return ndarrays over pinned blocks of the library's pool (the DMA lands
+    in them directly); the blocks go back to the pool when the caller drops the arrays and are taken over by the next call.
+    Same bytes as with plain numpy.empty results; views keep the block alive."""
+    import gc
+    from astroz_amd.api import Satrec, SatrecArray
+    pairs = synth.synth_catalog(n_near=3000, n_deep=100, seed=12)
+    arr = SatrecArray([Satrec.twoline2rv(a, b) for a, b in pairs])
+    jd = np.full(700, synth.START_JD)
+    fr = 0.25 + np.arange(700) / 1440.0
+    native.host_pool_trim()
+    live0, free0 = native.host_pool_stats()
+    e, r, v = arr.sgp4(jd, fr)
+    assert r.shape == (3100, 700, 3) and r.flags.writeable and not r.flags.owndata
+    live1, free1 = native.host_pool_stats()
+    need = 2 * 700 * 3100 * 24
+    assert live1 - live0 >= need and live1 - live0 < need + (8 << 20)
+    native.set_pinned_results(False)
+    try:
+        e2, r2, v2 = arr.sgp4(jd, fr)
+    finally:
+        native.set_pinned_results(True)
+    assert native.host_pool_stats()[0] == live1                      # plain numpy arrays: nothing taken from the pool
+    assert np.array_equal(r, r2) and np.array_equal(v, v2) and np.array_equal(e, e2)
+    keep = r[5, 10:20]          # a view keeps its block
+    r[0, 0, 0] = 1.5            # writable
+    del r, v, e
+    gc.collect()
+    live2, free2 = native.host_pool_stats()
+    assert live1 - live2 >= need // 2 and live2 > live0 and free2 > free1     # v's block is back in the pool, r's is held by the view
+    assert np.array_equal(keep, r2[5, 10:20])
+    del keep
+    gc.collect()
+    live3, free3 = native.host_pool_stats()
+    assert live3 == live0 and free3 - free0 >= need
+    e, r, v = arr.sgp4(jd, fr)                                          # takes the pooled blocks over: no new pinning
+    live4, free4 = native.host_pool_stats()
+    assert live4 - live0 >= need and free4 <= free3 - need + (8 << 20)
+    assert np.array_equal(r, r2) and np.array_equal(v, v2)
+    # C hosts: azh_host_alloc'ed outputs through azh_propagate_host, against pageable ones
+    import ctypes as C
+    q = C.c_void_p(0)
+    nb = 700 * 3100 * 24
+    assert native.lib().azh_host_alloc(nb, C.byref(q)) == 0 and q.value
+    pos = np.frombuffer((C.c_char * nb).from_address(q.value), dtype=np.float64).reshape(700, 3100, 3)
+    times = ((jd + fr) - (jd[0] + fr[0])) * 1440.0
+    off = ((jd[0] + fr[0]) - arr._epochs) * 1440.0
+    arr._dev.propagate_host(times, off, pos=pos, layout=native.TIME_MAJOR)
+    assert np.array_equal(pos.transpose(1, 0, 2), r2)
+    del pos
+    native.lib().azh_host_free(q)
+    native.lib().azh_host_free(q)          # (a block that is not live: ignored)
+    del e, r, v
+    gc.collect()
+    native.host_pool_trim()
+    assert native.host_pool_stats() == (live0, 0)
+
+
+def test_closed_forms_host_vs_device_kat(native):
+    """Part (A)'s coords_* / orbital_* are host closed forms; azh_selftest_coords evaluates the same quantities through the
+    kernels' own frame code on the device (az_to_ecef, the Bowring geodetic conversion with polynomial atan2): they agree to
+    rounding -- the device conversion reaches the reference's fixed point to 2e-13 rad / 1e-6 km."""
+    import ctypes as C
+    L = native.lib()
+    L.azh_selftest_coords.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.azh_selftest_coords.restype = C.c_int32
+    rng = np.random.default_rng(4)
+
+    def dev(op, *a):
+        i = (C.c_double * 4)(*(list(a) + [0.0] * (4 - len(a))))
+        o = (C.c_double * 5)()
+        assert L.azh_selftest_coords(op, i, o) == 0
+        return np.array(o[:])
+    for jd in (2451545.0, 2460500.5, 2460800.75):
+        assert abs(dev(0, jd)[0] - native.julian_to_gmst(jd)) < 1e-12
+    for _ in range(30):
+        eci = rng.uniform(-9000.0, 9000.0, 3) * rng.choice([1.0, 5.0])
+        gm = rng.uniform(0, 2 * np.pi)
+        ecef = native.eci_to_ecef(eci, gm)
+        assert np.abs(dev(1, *eci, gm)[:3] - ecef).max() < 1e-11
+        lla_h, lla_d = native.ecef_to_geodetic(ecef), dev(2, *ecef)[:3]
+        assert abs(lla_h[0] - lla_d[0]) < 2e-11 and abs((lla_h[1] - lla_d[1] + 180.0) % 360.0 - 180.0) < 2e-11 and abs(lla_h[2] - lla_d[2]) < 1e-6
+    mu, r1, r2 = 398600.4418, 6778.0, 42164.0
+    o = dev(3, mu, r1, 0.5 * (r1 + r2))
+    assert abs(o[0] - L.orbital_velocity(mu, r1, 0.5 * (r1 + r2))) < 1e-12 and abs(o[2] - L.orbital_escape_velocity(mu, r1)) < 1e-12
+    assert abs(o[1] - L.orbital_period(mu, 0.5 * (r1 + r2))) < 1e-8
+    assert L.azh_selftest_coords(7, (C.c_double * 4)(), (C.c_double * 5)()) == -20

@@ -183,27 +183,26 @@ def test_source_resolution_round4():
     az._as_text("celestrak:iss", fetch=fetch)
     az._as_text("gps", fetch=fetch)
     assert seen[0].endswith("GROUP=stations&FORMAT=tle") and seen[1].endswith("GROUP=gps-ops&FORMAT=tle")
-    with pytest.raises(ValueError):
-        az._as_text("starlink", norad_id=25544, fetch=fetch)          # either a source or a catalog number
+    az._as_text("starlink", norad_id=25544, fetch=fetch)              # both given: the catalog number wins (reference L163-166)
+    assert "CATNR=25544" in seen[2]
     with pytest.raises(ValueError):
         az._as_text("celestrak:", fetch=fetch)
-    with pytest.raises((FileNotFoundError, ValueError)):
+    with pytest.raises(FileNotFoundError):
         az._as_text("catalog.tle", fetch=fetch)                       # a file name that does not exist is not a group name
-    assert len(seen) == 2
+    with pytest.raises(FileNotFoundError):
+        az._as_text(os.path.join("data", "active.txt"), fetch=fetch)
+    assert len(seen) == 3
 
 
-def test_orbital_scalars_report_a_missing_device():
-    """The four closed-form scalars run on the device like every floating-point path: without one the Python wrappers raise
-    NativeError (not ValueError, not NaN); with one they return the reference's values (src/calculations.zig L83-125)."""
+def test_orbital_scalars_need_no_device():
+    """The four closed-form scalars are host functions, as in the reference (src/c_api/root.zig L60-71; round 5: rounds 2-4
+    evaluated them in a one-thread kernel and raised NativeError without a device): with or without a GPU the Python wrappers
+    return the reference's values (src/calculations.zig L83-125), and argument errors are ValueError."""
     import astroz_amd as az
-    from astroz_amd import _native
-    if _native.device_count() == 0:
-        for call in (lambda: az.orbital_velocity(az.EARTH_MU, 7000.0), lambda: az.orbital_period(az.EARTH_MU, 7000.0),
-                     lambda: az.escape_velocity(az.EARTH_MU, 7000.0), lambda: az.hohmann_transfer(az.EARTH_MU, 7000.0, 42164.0)):
-            with pytest.raises(_native.NativeError):
-                call()
-    else:
-        assert abs(az.orbital_velocity(az.EARTH_MU, 7000.0) - (az.EARTH_MU / 7000.0) ** 0.5) < 1e-12
+    assert abs(az.orbital_velocity(az.EARTH_MU, 7000.0) - (az.EARTH_MU / 7000.0) ** 0.5) < 1e-12
+    assert abs(az.orbital_period(az.EARTH_MU, 7000.0) - 2 * 3.141592653589793 * (7000.0 ** 3 / az.EARTH_MU) ** 0.5) < 1e-9
+    assert abs(az.escape_velocity(az.EARTH_MU, 7000.0) - (2 * az.EARTH_MU / 7000.0) ** 0.5) < 1e-12
+    assert abs(az.hohmann_transfer(az.EARTH_MU, 7000.0, 42164.0)["sma"] - 0.5 * (7000.0 + 42164.0)) < 1e-9
     with pytest.raises(ValueError):
         az.orbital_velocity(az.EARTH_MU, -1.0)                        # argument errors stay ValueError either way
     with pytest.raises(ValueError):

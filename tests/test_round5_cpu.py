@@ -54,3 +54,52 @@ def test_compact_bench_line_degrades_in_a_fixed_order():
     j = json.loads(line)
     assert j["value"] == pytest.approx(out["value"], rel=1e-5) and j["roofline"]["frac"] > 0 and j["cpu_baseline"]["value"] > 0
     assert "secondary_summary" not in j
+
+
+def test_c_api_closed_forms_on_the_host(orc):
+    """coords_* and orbital_* (the reference's c_api, src/c_api/root.zig L60-81) are pure host functions there and here:
+    no device needed (this tier has none).  Against the oracle's restatement of WorldCoordinateSystem.zig and the closed
+    forms of src/calculations.zig L83-125; argument checks of src/c_api/orbital_mechanics.zig."""
+    import ctypes as C
+    import numpy as np
+    from astroz_amd import _native as native
+    import astroz_amd as az
+    for jd in (2451545.0, 2460500.5, 2460800.75, 2433282.5):
+        assert abs(native.julian_to_gmst(jd) - orc.julian_to_gmst(jd)) < 1e-12
+    L = orc.lib()
+    rng = np.random.default_rng(8)
+    for k in range(40):
+        eci = rng.uniform(-9000.0, 9000.0, 3) * (1.0 if k % 4 else 6.0)   # (LEO to beyond GEO)
+        gm = rng.uniform(0, 2 * np.pi)
+        want = np.empty(3)
+        L.orc_eci_to_ecef(eci.ctypes.data_as(C.c_void_p), C.c_double(np.sin(gm)), C.c_double(np.cos(gm)), want.ctypes.data_as(C.c_void_p))
+        got = native.eci_to_ecef(eci, gm)
+        assert np.abs(got - want).max() < 1e-11
+        lla = np.empty(3)
+        L.orc_ecef_to_geodetic(want.ctypes.data_as(C.c_void_p), lla.ctypes.data_as(C.c_void_p))
+        got = native.ecef_to_geodetic(want)
+        assert abs(got[0] - np.degrees(lla[0])) < 1e-11 and abs(got[1] - np.degrees(lla[1])) < 1e-11 and abs(got[2] - lla[2]) < 1e-9
+    lib = native.lib()
+    mu, r1, r2 = 398600.4418, 6778.0, 42164.0
+
+    class H(C.Structure):
+        _fields_ = [(n, C.c_double) for n in ("sma", "dv1", "dv2", "dvt", "t", "t_days")]
+    h = H()
+    assert lib.orbital_hohmann(mu, r1, r2, C.byref(h)) == 0
+    sma = 0.5 * (r1 + r2)
+    v1, v2 = np.sqrt(mu / r1), np.sqrt(mu / r2)
+    dv1, dv2 = v1 * np.sqrt(2 * r2 / (r1 + r2)) - v1, v2 - v2 * np.sqrt(2 * r1 / (r1 + r2))
+    for got, want in ((h.sma, sma), (h.dv1, dv1), (h.dv2, dv2), (h.dvt, abs(dv1) + abs(dv2)), (h.t, np.pi * np.sqrt(sma ** 3 / mu)),
+                      (h.t_days, np.pi * np.sqrt(sma ** 3 / mu) / 86400.0)):
+        assert abs(got - want) <= 1e-14 * abs(want)
+    assert lib.orbital_hohmann(mu, -1.0, r2, C.byref(h)) == -20 and lib.orbital_hohmann(mu, r1, r1 + 10.0, C.byref(h)) == -20
+    assert lib.orbital_hohmann(mu, r1, r2, None) == -101
+    assert abs(lib.orbital_velocity(mu, r1, 0.0) - v1) < 1e-13 and abs(lib.orbital_velocity(mu, r1, sma) - np.sqrt(mu * (2 / r1 - 1 / sma))) < 1e-13
+    assert abs(lib.orbital_period(mu, r2) - 2 * np.pi * np.sqrt(r2 ** 3 / mu)) < 1e-9
+    assert lib.orbital_velocity(mu, -1.0, 0.0) == -1.0 and lib.orbital_period(mu, 0.0) == -1.0 and lib.orbital_escape_velocity(mu, 0.0) == -1.0
+    d = az.hohmann_transfer(az.EARTH_MU, r1, r2)
+    assert abs(d["sma"] - sma) < 1e-9 and abs(az.escape_velocity(az.EARTH_MU, r1) - np.sqrt(2 * az.EARTH_MU / r1)) < 1e-12
+    # the device evaluation is a known-answer test and fails loudly without a device
+    out = (C.c_double * 5)()
+    if native.device_count() == 0:
+        assert lib.azh_selftest_coords(0, (C.c_double * 4)(2451545.0, 0, 0, 0), out) == native.AZ_ERR_HIP
