@@ -208,7 +208,7 @@ def test_closed_forms_host_vs_device_kat(native):
         assert L.azh_selftest_coords(op, i, o) == 0
         return np.array(o[:])
     for jd in (2451545.0, 2460500.5, 2460800.75):
-        assert abs(dev(0, jd)[0] - native.julian_to_gmst(jd)) < 1e-12
+        assert abs(dev(0, jd)[0] - native.julian_to_gmst(jd)) < 1e-10   # (3e6 degrees before the fmod: an ulp there is 5e-10 deg)
     for _ in range(30):
         eci = rng.uniform(-9000.0, 9000.0, 3) * rng.choice([1.0, 5.0])
         gm = rng.uniform(0, 2 * np.pi)
