@@ -30,7 +30,7 @@ EXPORTS = [
     "azh_constellation_from_tle_lines", "azh_constellation_from_elements", "azh_constellation_subset", "azh_constellation_free",
     "azh_num_satellites", "azh_num_sgp4", "azh_num_sdp4", "azh_get_epochs", "azh_get_status",
     "azh_get_field", "azh_propagate_host", "azh_propagate_device", "azh_propagate_device_cached", "azh_propagate_device_window",
-    "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile", "azh_set_timing", "azh_set_fast_path", "azh_set_tile_kernel", "azh_set_f32_arithmetic", "azh_set_f32_mode",
+    "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile", "azh_set_timing", "azh_set_fast_path", "azh_set_tile_kernel", "azh_set_graphs", "azh_set_f32_arithmetic", "azh_set_f32_mode",
     "azh_last_kernel_ms", "azh_last_path", "azh_last_one_stats", "azh_set_host_copy_threads", "azh_selftest_coords", "azh_host_alloc", "azh_host_free", "azh_host_pool_stats", "azh_host_pool_trim", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
     "azh_screen_target_host", "azh_screen_target_device", "azh_coarse_screen_device", "azh_coarse_screen_host",
     "azh_screen_all_host", "azh_constellation_from_omm_json", "azh_propagate_one_device", "azh_selftest_math",
@@ -184,6 +184,8 @@ def lib():
     L.azh_set_fast_path.restype = i32
     L.azh_set_tile_kernel.argtypes = [vp, i32]
     L.azh_set_tile_kernel.restype = i32
+    L.azh_set_graphs.argtypes = [vp, i32]
+    L.azh_set_graphs.restype = i32
     L.azh_set_f32_arithmetic.argtypes = [vp, i32]
     L.azh_set_f32_arithmetic.restype = i32
     L.azh_set_f32_mode.argtypes = [vp, i32]
@@ -453,6 +455,11 @@ class DeviceConstellation:
         """Time-major output on (quasi-)uniform grids: True / 1 = the 16-row tile kernel (default), 2 = the lane = satellite
         kernel k_cols_fast (opt-in: parity-identical, measured slower), False / 0 = neither (k_propagate)."""
         check(lib().azh_set_tile_kernel(self._h, int(enabled) if not isinstance(enabled, bool) else (1 if enabled else 0)), "azh_set_tile_kernel")
+
+    def set_graphs(self, enabled):
+        """hipGraph replay of repeated cached-input launch sets (propagate_device_cached / _window); default off: it pays for
+        multi-window pipelines (ShardedPropagator with several chunks), not for a single launch set."""
+        check(lib().azh_set_graphs(self._h, 1 if enabled else 0), "azh_set_graphs")
 
     def set_timing(self, enabled):
         check(lib().azh_set_timing(self._h, 1 if enabled else 0), "azh_set_timing")

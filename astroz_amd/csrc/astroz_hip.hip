@@ -133,6 +133,7 @@ struct azh_constellation {
     std::vector<double> h_raw[AZ_NUM_RAW]; // the TLE-unit inputs (for azh_constellation_subset)
     // launch lists (table indices)
     DevBuf<unsigned> d_list; // [near-earth | deep (by irez) | bad]
+    std::vector<unsigned> h_list; // host copy (row windows: the slot range of a window in the catalog-ordered sub-lists)
     unsigned n_sgp4 = 0, n_sdp4 = 0, n_bad = 0;
     // per-call scratch
     DevBuf<double> d_times, d_offsets, d_sin, d_cos, d_seeds;
@@ -198,6 +199,23 @@ struct azh_constellation {
     unsigned off_deep_cat = 0; // d_list + off_deep_cat: deep-space members in plain catalog order (lane = time kernels)
     unsigned off_rowmap = 0;   // d_list + off_rowmap: per catalog row, kind << 30 | slot (AZ_ROW_*: k_tiles_fast)
     unsigned off_rowmap2 = 0;  // ... the same with near-earth slots counted in the [class 0 | other classes] list (k_cols_fast)
+    // hipGraph cache of the cached-input launch sets (azh_propagate_device_cached / _window): a launch set is 3-9 API calls
+    // (kernels on up to three streams, fork / join events, a memset); captured once per (outputs, layout, stride, row window,
+    // redo-counter parity) it replays as ONE hipGraphLaunch.  Dropped whenever new inputs are staged or a switch changes.
+    struct LaunchGraph {
+        const void *pos, *vel, *err;
+        int layout, f32;
+        size_t stride, row_lo, row_hi;
+        hipStream_t st;
+        unsigned sig_before, sig_after; // parity bits of the four window plans before / after the launch set
+        unsigned path;
+        unsigned seen;                  // calls with this key before it was captured
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+    };
+    std::vector<LaunchGraph> graphs;
+    int graphs_on = 0;         // azh_set_graphs / ASTROZ_AMD_GRAPHS (off by default: measured, it only pays for multi-window pipelines)
+    bool capturing = false;    // inside a stream capture: anything that must allocate, synchronize or rebuild first returns AZ_RC_EAGER
     int cols_kernel = 0;       // time-major output on (quasi-)uniform grids through k_cols_fast (lane = satellite) instead of k_tiles_fast
     DevBuf<double> d_deep_tmp; // time-major output: the deep-space rows' compact satellite-major scratch (k_deep_transpose)
     bool tile_kernel = true; // time-major output through the tile kernels (azh_set_tile_kernel)
@@ -215,12 +233,16 @@ struct azh_constellation {
 
 namespace {
 
+// internal return code: the launch set cannot be captured yet (a plan, the seeds or a scratch buffer must be built first)
+constexpr int32_t AZ_RC_EAGER = 0x7a5eca9;
 int set_device(const azh_constellation *c) { return hip_ok(hipSetDevice(c->device), "hipSetDevice") ? AZ_OK : AZ_ERR_HIP; }
 
+void drop_graphs(azh_constellation *c);
 void destroy(azh_constellation *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    drop_graphs(c);
     if (c->d_el) (void)hipFree(c->d_el);
     if (c->d_flags) (void)hipFree(c->d_flags);
     c->d_list.release();
@@ -414,6 +436,8 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
             }
         }
         if (const char *e = getenv("ASTROZ_AMD_COLS")) c->cols_kernel = atoi(e);
+        if (const char *e = getenv("ASTROZ_AMD_GRAPHS")) c->graphs_on = atoi(e);
+        c->h_list = list;
         if (c->d_list.ensure(list.size()) != AZ_OK ||
             !hip_ok(hipMemcpy(c->d_list.p, list.data(), sizeof(unsigned) * list.size(), hipMemcpyHostToDevice), "H2D list")) {
             rc = AZ_ERR_HIP;
@@ -615,26 +639,35 @@ void launch_rows2(const PropArgs &a, dim3 grid, bool deep, hipStream_t st, const
         e.tile = shape->tile_e;
         c.tile = shape->tile_c;
         const bool packed32 = shape->packed32 && !FR;
-        dim3 egrid((e.n_list + 7) / 8 * 8, (a.n_times + e.tile - 1) / e.tile);
-        dim3 cgrid((c.n_list + 7) / 8 * 8, (a.n_times + c.tile - 1) / c.tile);
+        // a row window: both launches are cut to the list slots it covers (their lists are in catalog order)
+        const bool win = a.row_lo > 0 || a.row_hi < a.n_rows;
+        unsigned n_e = e.n_list, n_c = c.n_list;
+        if (win) {
+            c.slot_lo = a.win_circ_lo; c.slot_hi = a.win_circ_hi; n_c = c.slot_hi - c.slot_lo;
+            e.slot_lo = a.win_ecc_lo; e.slot_hi = a.win_ecc_hi; n_e = e.slot_hi - e.slot_lo;
+            if (c.slot_hi == 0) c.n_list = n_c = 0; // (slot_hi = 0 means "whole list" to the kernels: an empty window launches nothing)
+            if (e.slot_hi == 0) e.n_list = n_e = 0;
+        }
+        dim3 egrid((n_e + 7) / 8 * 8, (a.n_times + e.tile - 1) / e.tile);
+        dim3 cgrid((n_c + 7) / 8 * 8, (a.n_times + c.tile - 1) / c.tile);
         // the generic pass: every workgroup takes items b, b + gridDim.x, ... and a quarter of each; enough workgroups that a
         // large catalog's rejected windows (1 % of 125,000 x 14 segments in config 5's share) do not queue up behind 1,024 waves
         dim3 rgrid(std::min(8192u, std::max(256u, (a.n_list * cgrid_y(a.n_times, shape->tile_c) + 63u) / 64u)), 4);
         // redo items carry (list slot, first, end): slots of the eccentric launch are offset into the common list
         e.redo_slot0 = a.n_circ;
-        const bool beside = side.stream != nullptr && c.n_list;
+        const bool beside = side.stream != nullptr && n_c;
         hipStream_t se = beside ? side.stream : st;
         if (beside) {
             (void)hipEventRecord(side.fork, st);
             (void)hipStreamWaitEvent(se, side.fork, 0);
         }
-        if (e.n_list) {
+        if (n_e) {
             if (a.f32) launch_rows_fast<VEL, FRAME, AZ_SINK_F32, true>(e, egrid, se);
             else launch_rows_fast<VEL, FRAME, AZ_SINK_F64, true>(e, egrid, se);
         }
         if (a.f32) hipLaunchKernelGGL((k_rows<VEL, FR, AZ_SINK_F32, true>), rgrid, dim3(64), 0, se, a);
         else hipLaunchKernelGGL((k_rows<VEL, FR, AZ_SINK_F64, true>), rgrid, dim3(64), 0, se, a);
-        if (c.n_list) {
+        if (n_c) {
             if (packed32 && shape->mixed32) launch_rows_fast32<VEL, true>(c, cgrid, st);
             else if (packed32) launch_rows_fast32<VEL, false>(c, cgrid, st);
             else if (a.f32) launch_rows_fast<VEL, FRAME, AZ_SINK_F32, false>(c, cgrid, st);
@@ -768,7 +801,8 @@ unsigned launch_propagate(const PropArgs &a, int layout, bool vel, bool deep, hi
         PropArgs b = a;
         b.tile = rows_tile(a.n_list, a.n_times, a.tile_forced);
         if (deep) b.tile = std::min(b.tile, 64u * (unsigned)AZ_DEEP_SEED_MAX); // k_rows_deep stages a segment's chunk seeds in LDS
-        dim3 grid((a.n_list + 7) / 8 * 8, (a.n_times + b.tile - 1) / b.tile);
+        const unsigned n_slots = a.slot_hi ? a.slot_hi - a.slot_lo : a.n_list; // (a row window's share of a catalog-ordered list)
+        dim3 grid((n_slots + 7) / 8 * 8, (a.n_times + b.tile - 1) / b.tile);
         if (deep || a.screen_target || a.inc == nullptr) b.redo_items = nullptr; // k_rows_fast: near-earth rows on a uniform grid
         if (a.screen_target) {
             if (deep) hipLaunchKernelGGL((k_rows_deep<false, false, AZ_SINK_SCREEN>), grid, dim3(64), 0, st, b);
@@ -842,6 +876,7 @@ int32_t stage_inputs(azh_constellation *c, const double *times, size_t n_times, 
     c->cached_n_times = (unsigned)n_times;
     c->cached_mode = mode;
     c->seeds_valid = false; // new time grid / offsets
+    drop_graphs(c);          // (captured launch sets hold the old grid's buffers and shapes)
     for (auto &pl : c->plan) pl.valid = false;
     // uniform grid?  times[i] == times[0] + i*step up to the rounding of the grid itself: the fast step
     // (fast_step.h) then advances its carried angles by per-satellite constant rotations
@@ -951,6 +986,7 @@ int32_t prepare_deep(azh_constellation *c, PropArgs &d, hipStream_t st, bool row
     const unsigned seed_tile = rows ? 64u : d.tile;
     const unsigned n_tiles = (n_times + seed_tile - 1) / seed_tile;
     if (!c->seeds_valid || c->seeds_tile != seed_tile || c->seeds_rows != rows) {
+        if (c->capturing) return AZ_RC_EAGER;
         if (c->d_seeds.ensure((size_t)n_tiles * 3 * c->n_sdp4) != AZ_OK) return AZ_ERR_HIP;
         if (c->d_node_cache.p == nullptr) {
             if (c->d_node_cache.ensure(3 * c->n_pad) != AZ_OK) return AZ_ERR_HIP;
@@ -974,6 +1010,7 @@ int32_t ensure_plan(azh_constellation *c, PropArgs &a, const FastShape &shape, h
     const unsigned n_list = a.n_list;
     const unsigned n_seg = (a.n_times + std::min(shape.tile_c, shape.tile_e) - 1) / std::min(shape.tile_c, shape.tile_e);
     if (!pl.valid || pl.tile_c != shape.tile_c || pl.tile_e != shape.tile_e || pl.n_list != n_list || pl.mixed32 != shape.mixed32) {
+        if (c->capturing) return AZ_RC_EAGER;
         // static items: at most one per (slot, segment); dynamic ones: only waves of eccentric members file them, at most one
         // per 64-point iteration
         const size_t items = (size_t)n_list * n_seg + ((size_t)a.n_times + 63) / 64 * (c->n_sgp4 - c->n_circ);
@@ -1007,6 +1044,21 @@ int32_t ensure_plan(azh_constellation *c, PropArgs &a, const FastShape &shape, h
     a.redo_items = pl.redo.p + 4;
     pl.parity ^= 1u;
     return AZ_OK;
+}
+
+void drop_graphs(azh_constellation *c)
+{
+    for (auto &g : c->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    c->graphs.clear();
+}
+unsigned plan_sig(const azh_constellation *c)
+{
+    unsigned s = 0;
+    for (unsigned k = 0; k < 4; ++k) s |= (c->plan[k].parity & 1u) << k;
+    return s;
 }
 
 // the launches proper; inputs already staged on the device
@@ -1049,6 +1101,19 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     a.grid_exact_uniform = (c->uniform_step != 0.0 && c->delta_max == 0.0) ? 1 : 0;
     a.row_lo = (unsigned)row_lo;
     a.row_hi = (unsigned)row_hi;
+    // a row window: the slots it covers in the catalog-ordered sub-lists (the lane = time launches are cut to them)
+    const bool windowed = row_lo > 0 || row_hi < c->n;
+    auto slots_of = [&](unsigned off, unsigned cnt, unsigned &lo, unsigned &hi) {
+        const unsigned *b = c->h_list.data() + off, *e = b + cnt;
+        lo = (unsigned)(std::lower_bound(b, e, (unsigned)row_lo) - b);
+        hi = (unsigned)(std::lower_bound(b, e, (unsigned)row_hi) - b);
+    };
+    unsigned deep_lo = 0, deep_hi = 0;
+    if (windowed) {
+        slots_of(c->off_circ, c->n_circ, a.win_circ_lo, a.win_circ_hi);
+        slots_of(c->off_circ + c->n_circ, c->n_sgp4 - c->n_circ, a.win_ecc_lo, a.win_ecc_hi);
+        slots_of(c->off_deep_cat, c->n_sdp4, deep_lo, deep_hi);
+    }
 
     unsigned path = 0;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
@@ -1066,6 +1131,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     const size_t scratch_rows = (size_t)c->n_sdp4 + (cols ? n_ecc : 0u);
     const size_t scratch_per = scratch_rows * n_times * 3, scratch_words = f32 ? (scratch_per + 1) / 2 : scratch_per; // in doubles
     auto ensure_scratch = [&](hipStream_t user) -> int32_t {
+        if (c->capturing && c->d_deep_tmp.cap < scratch_words * (d_vel ? 2 : 1)) return AZ_RC_EAGER;
         if (c->d_deep_tmp.cap < scratch_words * (d_vel ? 2 : 1)) HIP_TRY(hipStreamSynchronize(user));
         if (c->d_deep_tmp.ensure(scratch_words * (d_vel ? 2 : 1)) != AZ_OK) return AZ_ERR_HIP;
         a.tmp_pos = c->d_deep_tmp.p;
@@ -1081,6 +1147,8 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         HIP_TRY(hipStreamWaitEvent(c->s_deep, c->ev_fork, 0));
         PropArgs d = a;
         const bool deep_rows = use_rows(d, layout, true);
+        const bool deep_skip = windowed && deep_rows && deep_hi == deep_lo; // (no deep-space row inside the window)
+        if (windowed && deep_rows) { d.slot_lo = deep_lo; d.slot_hi = deep_hi; }
         if (int32_t rc = prepare_deep(c, d, c->s_deep, deep_rows, /*beside_bulk=*/!tiles && a.inc != nullptr); rc != AZ_OK) return rc;
         if (deep_rows && layout == AZ_LAYOUT_TIME_MAJOR) {
             // time-major: the rows go satellite-major into a compact scratch array (row = list slot), then one pure-memory
@@ -1090,10 +1158,10 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
             t.pos = const_cast<double *>(a.tmp_pos);
             t.vel = const_cast<double *>(a.tmp_vel);
             t.rows_compact = 1;
-            path |= launch_propagate(t, AZ_LAYOUT_SAT_MAJOR, d_vel != nullptr, true, c->s_deep);
+            if (!deep_skip) path |= launch_propagate(t, AZ_LAYOUT_SAT_MAJOR, d_vel != nullptr, true, c->s_deep);
             HIP_TRY(hipGetLastError());
             dim3 tg((c->n_sdp4 + AZ_TR_ROWS - 1) / AZ_TR_ROWS, (n_times + 63) / 64);
-            if (tiles) { /* the tile kernel copies the scratch rows through its own tiles */ }
+            if (tiles || deep_skip) { /* the tile kernel copies the scratch rows through its own tiles / no deep-space row in the window */ }
             else if (f32)
                 hipLaunchKernelGGL((k_deep_transpose<float>), tg, dim3(192), 0, c->s_deep, reinterpret_cast<const float *>(t.pos),
                                    reinterpret_cast<const float *>(t.vel), reinterpret_cast<float *>(d_pos), reinterpret_cast<float *>(d_vel),
@@ -1101,7 +1169,7 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
             else
                 hipLaunchKernelGGL((k_deep_transpose<double>), tg, dim3(192), 0, c->s_deep, t.pos, t.vel, d_pos, d_vel, d.list, c->n_sdp4,
                                    n_times, stride, d.mask, d.row_lo, d.row_hi);
-        } else {
+        } else if (!deep_skip) {
             path |= launch_propagate(d, layout, d_vel != nullptr, true, c->s_deep);
         }
         HIP_TRY(hipGetLastError());
@@ -1156,6 +1224,69 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
         HIP_TRY(hipEventRecord(c->ev_t1, st));
         c->timed = true;
     }
+    return AZ_OK;
+}
+
+// launch_all for the cached-input entry points, through the graph cache.  The first call with a key runs eagerly (it may
+// have to build a plan, seeds or a scratch buffer); the second is captured -- the launch set on the caller's stream and the
+// handle's side streams, joined back by the same events as in the eager form -- and every later one is one hipGraphLaunch.
+int32_t launch_cached(azh_constellation *c, double *d_pos, double *d_vel, int layout, size_t stride, uint8_t *d_err, hipStream_t st,
+                      int f32 = 0, size_t row_lo = 0, size_t row_hi = ~(size_t)0)
+{
+    if (!c->graphs_on || c->timing || c->cached_n_times == 0) return launch_all(c, d_pos, d_vel, layout, stride, d_err, st, f32, row_lo, row_hi);
+    const unsigned sig = plan_sig(c);
+    azh_constellation::LaunchGraph *hit = nullptr, *pending = nullptr;
+    for (auto &g : c->graphs)
+        if (g.pos == d_pos && g.vel == d_vel && g.err == d_err && g.layout == layout && g.f32 == f32 && g.stride == stride &&
+            g.row_lo == row_lo && g.row_hi == row_hi && g.st == st) {
+            if (g.exec && g.sig_before == sig) { hit = &g; break; }
+            if (!g.exec && g.sig_before == sig) pending = &g;
+        }
+    if (hit) {
+        HIP_TRY(hipGraphLaunch(hit->exec, st));
+        for (unsigned k = 0; k < 4; ++k) c->plan[k].parity = (hit->sig_after >> k) & 1u;
+        c->last_path = hit->path;
+        return AZ_OK;
+    }
+    if (!pending) {
+        // first sight of this key: eager, remembered
+        if (c->graphs.size() >= 24) drop_graphs(c); // (a caller cycling through many output buffers: start over)
+        const int32_t rc = launch_all(c, d_pos, d_vel, layout, stride, d_err, st, f32, row_lo, row_hi);
+        if (rc == AZ_OK) {
+            try {
+                c->graphs.push_back({d_pos, d_vel, d_err, layout, f32, stride, row_lo, row_hi, st, sig, plan_sig(c), c->last_path, 1u, nullptr, nullptr});
+            } catch (const std::bad_alloc &) {
+            }
+        }
+        return rc;
+    }
+    // second sight: capture
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return launch_all(c, d_pos, d_vel, layout, stride, d_err, st, f32, row_lo, row_hi);
+    }
+    unsigned parity0[4];
+    for (unsigned k = 0; k < 4; ++k) parity0[k] = c->plan[k].parity;
+    c->capturing = true;
+    const int32_t rc = launch_all(c, d_pos, d_vel, layout, stride, d_err, st, f32, row_lo, row_hi);
+    c->capturing = false;
+    hipGraph_t graph = nullptr;
+    const hipError_t e_end = hipStreamEndCapture(st, &graph);
+    hipGraphExec_t exec = nullptr;
+    if (rc != AZ_OK || e_end != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        for (unsigned k = 0; k < 4; ++k) c->plan[k].parity = parity0[k]; // (nothing ran)
+        pending->seen = 0;
+        pending->sig_before = ~0u; // never captured again
+        if (rc != AZ_OK && rc != AZ_RC_EAGER) return rc;
+        return launch_all(c, d_pos, d_vel, layout, stride, d_err, st, f32, row_lo, row_hi);
+    }
+    pending->graph = graph;
+    pending->exec = exec;
+    pending->sig_after = plan_sig(c);
+    pending->path = c->last_path;
+    HIP_TRY(hipGraphLaunch(exec, st));
     return AZ_OK;
 }
 
@@ -1750,6 +1881,7 @@ int32_t azh_set_f32_mode(azh_constellation *c, int32_t mode)
     if (!c) return AZ_ERR_NULL_POINTER;
     if (mode < 0 || mode > 2) return AZ_ERR_VALUE;
     c->f32_mode = mode;
+    drop_graphs(c);
     return AZ_OK;
 }
 
@@ -1776,6 +1908,7 @@ int32_t azh_set_tile_kernel(azh_constellation *c, int32_t enabled)
     if (!c) return AZ_ERR_NULL_POINTER;
     c->tile_kernel = enabled != 0;
     c->cols_kernel = enabled == 2 ? 1 : (enabled == 1 ? 0 : c->cols_kernel); // 2: the lane = satellite kernel (k_cols_fast), 1: the 16-row tiles
+    drop_graphs(c);
     return AZ_OK;
 }
 
@@ -1783,6 +1916,7 @@ int32_t azh_set_fast_path(azh_constellation *c, int32_t enabled)
 {
     if (!c) return AZ_ERR_NULL_POINTER;
     c->fast_path = enabled != 0;
+    drop_graphs(c);
     return AZ_OK;
 }
 
@@ -1791,6 +1925,15 @@ int32_t azh_set_time_tile(azh_constellation *c, uint32_t sgp4_tile, uint32_t sdp
     if (!c) return AZ_ERR_NULL_POINTER;
     c->tile_sgp4 = sgp4_tile;
     c->tile_sdp4 = sdp4_tile;
+    drop_graphs(c);
+    return AZ_OK;
+}
+
+int32_t azh_set_graphs(azh_constellation *c, int32_t enabled)
+{
+    if (!c) return AZ_ERR_NULL_POINTER;
+    c->graphs_on = enabled != 0;
+    if (!c->graphs_on) drop_graphs(c);
     return AZ_OK;
 }
 
@@ -1821,7 +1964,7 @@ static int32_t azh_propagate_device_cached_impl(azh_constellation *c, double *d_
     if (layout < 0 || layout > 1) return AZ_ERR_VALUE;
     if (c->cached_n_times == 0) return AZ_ERR_NOT_INITIALIZED;
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
-    return launch_all(c, d_pos, d_vel, layout, stride, d_err, stream ? (hipStream_t)stream : c->s_main);
+    return launch_cached(c, d_pos, d_vel, layout, stride, d_err, stream ? (hipStream_t)stream : c->s_main);
 }
 int32_t azh_propagate_device_cached(azh_constellation *c, double *d_pos, double *d_vel, int32_t layout,
                                     size_t stride, uint8_t *d_err, void *stream)
@@ -1836,7 +1979,7 @@ static int32_t azh_propagate_device_window_impl(azh_constellation *c, size_t row
     if (layout < 0 || layout > 1) return AZ_ERR_VALUE;
     if (c->cached_n_times == 0) return AZ_ERR_NOT_INITIALIZED;
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
-    return launch_all(c, d_pos, d_vel, layout, stride, d_err, stream ? (hipStream_t)stream : c->s_main, 0, row_lo, row_hi);
+    return launch_cached(c, d_pos, d_vel, layout, stride, d_err, stream ? (hipStream_t)stream : c->s_main, 0, row_lo, row_hi);
 }
 int32_t azh_propagate_device_window(azh_constellation *c, size_t row_lo, size_t row_hi, double *d_pos, double *d_vel,
                                     int32_t layout, size_t stride, uint8_t *d_err, void *stream)
@@ -1871,8 +2014,8 @@ static int32_t azh_propagate_device_cached_f32_impl(azh_constellation *c, float 
     if (layout < 0 || layout > 1) return AZ_ERR_VALUE;
     if (c->cached_n_times == 0) return AZ_ERR_NOT_INITIALIZED;
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
-    return launch_all(c, reinterpret_cast<double *>(d_pos), reinterpret_cast<double *>(d_vel), layout, stride, d_err,
-                      stream ? (hipStream_t)stream : c->s_main, 1);
+    return launch_cached(c, reinterpret_cast<double *>(d_pos), reinterpret_cast<double *>(d_vel), layout, stride, d_err,
+                         stream ? (hipStream_t)stream : c->s_main, 1);
 }
 int32_t azh_propagate_device_cached_f32(azh_constellation *c, float *d_pos, float *d_vel, int32_t layout, size_t stride,
                                         uint8_t *d_err, void *stream)

@@ -97,6 +97,12 @@ struct PropArgs {
     // row window: only satellites with row_lo <= table index < row_hi are produced by this launch (chunked
     // launches whose results feed a collective while the next chunk is still being computed)
     unsigned row_lo, row_hi;
+    // ... and, for the lane = time kernels whose list is in catalog order, the LIST SLOTS that window covers: the launch's grid
+    // is cut to them (a window launch over the full grid starts 80,000 workgroups of which three in four return at once:
+    // 0.13 ms per window in round 4's chunked pipeline).  slot_hi = 0: the whole list.  win_*: the slot ranges of the two
+    // sub-lists [class 0 | other classes] of a fast launch (host: launch_all -> launch_rows2)
+    unsigned slot_lo, slot_hi;
+    unsigned win_circ_lo, win_circ_hi, win_ecc_lo, win_ecc_hi;
     // k_rows_fast -> k_rows hand-over: (list slot, first grid point, end) of every segment remainder the fast
     // step rejected
     int arith32;         // fp32 outputs: 0 mixed-precision step, 1 packed fp32 step (both k_rows_fast32), 2 fp64 rounded at the store
@@ -915,6 +921,9 @@ __device__ __forceinline__ unsigned az_xcd_row()
     const unsigned range = per_xcd <= 8u ? ((blockIdx.x + blockIdx.y) & 7u) : (blockIdx.x & 7u);
     return range * per_xcd + (blockIdx.x >> 3);
 }
+// the list slot of a workgroup of the row kernels: the XCD-aware row of a grid cut to the slot window [slot_lo, slot_hi)
+__device__ __forceinline__ unsigned az_list_slot(const PropArgs &p) { return p.slot_lo + az_xcd_row(); }
+__device__ __forceinline__ unsigned az_list_end(const PropArgs &p) { return p.slot_hi ? p.slot_hi : p.n_list; }
 // one wave's work on a row segment, shared by the two row kernels: where a finished iteration goes
 template <bool VEL, class out_t>
 __device__ __forceinline__ void az_rows_store(bool staged, bool full, bool live, unsigned lane, out_t *stage, out_t *prow,
@@ -1038,8 +1047,8 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
 {
     typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
     const unsigned lane = threadIdx.x;
-    const unsigned row = az_xcd_row(); // XCD-aware row assignment, see k_rows
-    if (row >= p.n_list) return;
+    const unsigned row = az_list_slot(p); // XCD-aware row assignment, see k_rows
+    if (row >= az_list_end(p)) return;
     const unsigned s = p.list[row]; // wave-uniform
     if (SINK != AZ_SINK_SCREEN && ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi)) return;
     const unsigned t_lo = blockIdx.y * p.tile;
@@ -1387,8 +1396,8 @@ template <bool VEL, bool MIXED = false, bool DELTA = false> // MIXED: az_sgp4_fa
 __global__ void __launch_bounds__(64, MIXED ? AZ_ROWSF32P_WAVES : AZ_ROWSF32_WAVES) k_rows_fast32(PropArgs p)
 {
     const unsigned lane = threadIdx.x;
-    const unsigned row = az_xcd_row(); // XCD-aware row assignment, see k_rows
-    if (row >= p.n_list) return;
+    const unsigned row = az_list_slot(p); // XCD-aware row assignment, see k_rows
+    if (row >= az_list_end(p)) return;
     const unsigned s = p.list[row];
     const unsigned fl = p.flags[s];
     if ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi) return;
@@ -1531,8 +1540,8 @@ __global__ void __launch_bounds__(64, AZ_ROWS_WAVES) k_rows(PropArgs p)
         // XCD-aware row assignment: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the
         // rows are dealt out in eight contiguous ranges -- every XCD then reads one eighth of the SoA
         // element table (8 satellites share each 64-B line) instead of all of it
-        row = az_xcd_row(); // (gridDim.x is a multiple of 8)
-        if (row >= p.n_list) return;
+        row = az_list_slot(p); // (gridDim.x is a multiple of 8)
+        if (row >= az_list_end(p)) return;
         // blockIdx.y: time segment of p.tile grid points (a multiple of 64) -- splits long rows so that
         // the grid has enough waves to fill the chip several times over
         t_lo = blockIdx.y * p.tile;
@@ -1660,8 +1669,8 @@ __global__ void __launch_bounds__(64, AZ_ROWSD_WAVES) k_rows_deep(PropArgs p)
     typedef typename std::conditional<SINK == AZ_SINK_F32, float, double>::type out_t;
     constexpr unsigned TL = 512;
     const unsigned lane = threadIdx.x;
-    const unsigned row = az_xcd_row(); // XCD-aware row assignment, see k_rows
-    if (row >= p.n_list) return;
+    const unsigned row = az_list_slot(p); // XCD-aware row assignment, see k_rows
+    if (row >= az_list_end(p)) return;
     const unsigned s = p.list[row];
     const unsigned fl = p.flags[s];
     if (SINK != AZ_SINK_SCREEN && ((p.mask != nullptr && p.mask[s] == 0) || s < p.row_lo || s >= p.row_hi)) return;

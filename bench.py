@@ -62,7 +62,7 @@ def parse_args():
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the N > 1 code path (shard plan, chunk pipeline, RCCL all-gather) with whatever world size there "
                          "is, including 1: a smoke test of the config-4 path on a single-GPU box")
-    ap.add_argument("--chunks", type=int, default=4, help="N > 1: pipeline depth of the compute / all-gather overlap")
+    ap.add_argument("--chunks", type=int, default=0, help="N > 1: pipeline depth of the compute / all-gather overlap (0 = from the rows per rank: one chunk per ~3,000 rows, at most 4)")
     ap.add_argument("--tile", type=int, default=0, help="time steps per workgroup (0 = auto)")
     ap.add_argument("--stride-align", type=int, default=0,
                     help="time-major only: round the row length (out_stride_sats) up to a multiple of this many "
@@ -135,7 +135,10 @@ def main():
     if sharded:
         allp = synth.synth_catalog(n_near=a.sats, n_deep=a.deep, seed=20260926)
         n_total = len(allp)
-        plan = ShardPlan(n_total, world, a.chunks)
+        # chunk pipeline depth: a window of fewer than ~3,000 rows no longer fills the chip (its launches are latency-bound), so
+        # small shards are ONE chunk (8 ranks x 1,685 rows) and only large ones are pipelined against their gathers
+        n_chunks = a.chunks if a.chunks > 0 else max(1, min(4, (n_total // world) // 3000))
+        plan = ShardPlan(n_total, world, n_chunks)
         pairs = [allp[i] for i in plan.local_rows(rank)]
     else:
         pairs = synth.synth_catalog(n_near=a.sats, n_deep=a.deep, seed=(20260927 if a.config5_share else 20260926) + 101 * rank)
@@ -254,7 +257,7 @@ def main():
 
     # config 4: the kernels alone, timed the same way, so that t_kernel and t_allgather are reported next to
     # t_total
-    kernel_only_ms = None
+    kernel_only_ms = kernel_graphs_ms = None
     if sharded:
         dist.barrier()
         torch.cuda.synchronize()
@@ -270,6 +273,28 @@ def main():
         kt = torch.tensor([k0.elapsed_time(k1) / a.steps], dtype=torch.float64, device=cuda)
         dist.all_reduce(kt, op=dist.ReduceOp.MAX)
         kernel_only_ms = float(kt[0])
+        # ... and the same windows replayed as hipGraphs (azh_set_graphs: every window's launch set is one hipGraphLaunch)
+        kernel_graphs_ms = None
+        if plan.n_chunks > 1:
+            dev.set_graphs(True)
+            for _ in range(4):
+                step(False)       # (eager, captured, replayed x2: both redo-counter parities)
+            drain()
+            torch.cuda.synchronize()
+            dist.barrier()
+            g0 = torch.cuda.Event(enable_timing=True)
+            g1 = torch.cuda.Event(enable_timing=True)
+            g0.record(stream)
+            sp.compute.wait_stream(stream)
+            for _ in range(a.steps):
+                step(False)
+            drain()
+            g1.record(stream)
+            torch.cuda.synchronize()
+            gt = torch.tensor([g0.elapsed_time(g1) / a.steps], dtype=torch.float64, device=cuda)
+            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
+            kernel_graphs_ms = float(gt[0])
+            dev.set_graphs(False)
 
     # config 4, the alternative DESIGN.md 6 recommends to consumers that need everything everywhere: every GPU propagates
     # the FULL catalog itself ("replicate": zero bytes moved), timed the same way (barrier, events, max over ranks)
@@ -437,7 +462,7 @@ def main():
             "precondition_ms": a.precondition_ms, "precondition_steps": n_pre,
             **({"t_kernel_ms": kernel_only_ms, "t_allgather_ms": max(elapsed / a.steps * 1e3 - kernel_only_ms, 0.0),
                 "t_total_ms": elapsed / a.steps * 1e3, "rccl_ranks": world, "chunks": plan.n_chunks,
-                "kernel_only_value": props_per_step / (kernel_only_ms / 1e3),
+                "kernel_only_value": props_per_step / (kernel_only_ms / 1e3), "t_kernel_graphs_ms": kernel_graphs_ms,
                 "t_replicate_ms": replicate_ms, "replicate_value": props_per_step / (replicate_ms / 1e3),
                 "replicate_note": "every GPU propagates the FULL catalog itself (no shards, zero bytes moved): the same "
                                   "deliverable as the gathered run -- the full arrays on every GPU",

@@ -197,7 +197,7 @@ def compact_line(out, full_path=None, limit=LINE_LIMIT):
                                           "scaling", "vs_baseline", "dtype", "data")}
     c = {"workload": _short(cfg.get("workload", ""), 420)}
     for k in ("n_sats_total", "n_sats_per_gpu", "n_times", "parallelism", "gather", "launch_path", "t_kernel_ms", "t_allgather_ms",
-              "t_total_ms", "kernel_only_value", "t_replicate_ms", "replicate_value", "chunks", "rccl_ranks", "gather_bytes_per_gpu"):
+              "t_total_ms", "kernel_only_value", "t_kernel_graphs_ms", "t_replicate_ms", "replicate_value", "chunks", "rccl_ranks", "gather_bytes_per_gpu"):
         if k in cfg:
             c[k] = _num(cfg[k]) if not isinstance(cfg[k], str) else _short(cfg[k], 120)
     gh = cfg.get("group_host")

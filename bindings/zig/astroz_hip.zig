@@ -117,6 +117,7 @@ pub extern "c" fn azh_set_f32_mode(h: ?*Handle, mode: i32) i32; // 0 mixed preci
 pub extern "c" fn azh_set_f32_arithmetic(h: ?*Handle, enabled: i32) i32; // boolean: 0 = fp64 rounded at the store, else packed fp32
 pub extern "c" fn azh_set_fast_path(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_set_tile_kernel(h: ?*Handle, enabled: i32) i32;
+pub extern "c" fn azh_set_graphs(h: ?*Handle, enabled: i32) i32; // hipGraph replay of repeated cached-input launch sets (default off; pays for multi-window pipelines)
 pub extern "c" fn azh_set_host_copy_threads(n: i32) void; // host threads behind the pinned staging of host-returning copies (-1 auto, 0 = direct pageable copies)
 // result arrays the DMA engines write directly (pinned, pooled inside the library): a Zig host allocates `positions` / `velocities`
 // here instead of from its allocator, and azh_propagate_host lands in them at the link rate (no staging hop)

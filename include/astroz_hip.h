@@ -344,6 +344,14 @@ int32_t azh_set_fast_path(azh_constellation *c, int32_t enabled);
  * 1,536-byte runs; measured slower than the tiles, kept as an option); 0 = neither (the generic lane = satellite kernel).
  * Results agree to rounding; the switch exists so that tests and benchmarks can compare them. */
 int32_t azh_set_tile_kernel(azh_constellation *c, int32_t enabled);
+/* hipGraph replay of the cached-input launch sets (azh_propagate_device_cached / _cached_f32 / _window): a launch set is three
+ * to nine runtime calls (kernels on up to three streams, fork / join events, a memset); the second call with the same
+ * outputs, layout, stride, row window and stream is captured and every later one is ONE hipGraphLaunch.  OFF by default
+ * (environment ASTROZ_AMD_GRAPHS=1 switches it on for new handles): measured on MI355X / ROCm 7.0 it pays where one step is
+ * several launch sets -- the chunked row-window pipeline of a sharded run: 0.40 -> 0.33 ms for four windows of config 2 --
+ * and costs 1-4 % on a single launch set (profiles/r05_experiments.txt B).  The cache is dropped whenever new inputs are
+ * staged or a switch of the handle changes.  Not used while azh_set_timing is on (its event pair sits inside the set). */
+int32_t azh_set_graphs(azh_constellation *c, int32_t enabled);
 /* host-returning calls (azh_propagate_host, azh_propagate_jd_host, azh_group_propagate_host): results travel device -> pinned
  * staging slots (kept in the handle) -> the caller's arrays, the second hop by n host threads while the next chunk is on the
  * link.  A direct copy into FRESH pageable arrays pays the runtime's first-time pinning of the range (config 2: 55 ms instead
