@@ -2362,6 +2362,18 @@ static int32_t azh_propagate_host_impl(azh_constellation *c, const double *times
     // device-side result buffers live in the handle and only ever grow: repeated calls (the Python propagate(),
     // SatrecArray.sgp4) do not pay a hipMalloc/hipFree pair of hundreds of megabytes each time
     const size_t words = bytes / sizeof(double);
+    // ONE satellite (BASELINE config 1: SatrecArray([sat]).sgp4(jd, fr)), TEME, no mask: (n_times, 1, 3) and (1, n_times, 3) are the
+    // same bytes as the one-satellite path's (n_times, 3), so the call IS azh_propagate_one_host on tsince = times + offset -- one
+    // kernel that reads its times from and writes into a pinned buffer, no staging of a grid, no increment / record / plan
+    // kernels: 30 us whether the grid repeats or not (through the constellation launch set: 49 us repeated, 109 us on a fresh grid)
+    if (c->n == 1 && mode == AZ_OUT_TEME && mask == nullptr && (layout == AZ_LAYOUT_SAT_MAJOR || stride <= 1) && n_times <= kOneStage &&
+        AZ_FLAG_ERR(c->h_flags[0]) == 0) {
+        std::vector<double> ts(times, times + n_times);
+        if (offsets)
+            for (auto &t : ts) t += offsets[0];
+        c->last_path = 0; // (none of the constellation kernel families)
+        return run_one_satellite(c, 0, ts.data(), n_times, 0, nullptr, pos, vel, err);
+    }
     // A few satellites (what Satrec / SatrecArray([sat]) / a c_api client make): the kernels write straight into a pinned host
     // buffer of the handle (device-addressable, coherent) and one synchronize ends the call -- three pageable device-to-host
     // copies of a few KB cost ~15 us each.

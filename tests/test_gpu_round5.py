@@ -285,3 +285,52 @@ def test_graph_replay_of_cached_launch_sets(native, orc, synth):
         dev.synchronize()
         assert np.array_equal(p32.cpu().numpy(), ref)
     dev.set_graphs(False)
+
+
+def test_single_satellite_constellation_call(native, orc, golden):
+    """BASELINE config 1 through SatrecArray([sat]).sgp4 / azh_propagate_host on a one-satellite handle: the call is the
+    one-satellite path on tsince = times + offset (no grid staging): same results as the oracle on uniform, (jd, fr) and
+    irregular grids, both layouts, pos-only, a deep-space member, an over-long grid (falls back to the constellation kernels),
+    ECEF (constellation kernels)."""
+    from astroz_amd.api import Satrec, SatrecArray, WGS72
+    l1 = "1 25544U 98067A   24127.82853009  .00015698  00000+0  27310-3 0  9995"
+    l2 = "2 25544  51.6393 160.4574 0003580 140.6673 205.7250 15.50957674452123"
+    sat = Satrec.twoline2rv(l1, l2, WGS72)
+    sa = SatrecArray([sat])
+    jd = np.full(1440, sat.jdsatepoch)
+    fr = sat.jdsatepochF + np.arange(1440) / 1440.0
+    cat = orc.Catalog.from_pairs([(l1, l2)], orc.WGS72)
+    ts = ((jd + fr) - (sat.jdsatepoch + sat.jdsatepochF)) * 1440.0
+    _, p0, v0 = cat.propagate(ts, None, layout=orc.SAT_MAJOR)
+    for k in range(3):
+        e, r, v = sa.sgp4(jd, fr + k * 1e-9)
+        assert e.shape == (1, 1440) and r.shape == (1, 1440, 3) and not e.any()
+        rjd = jd[0] + (fr + k * 1e-9)[0]
+        _, pk, vk = cat.propagate(((jd + (fr + k * 1e-9)) - rjd) * 1440.0, (rjd - sa._epochs) * 1440.0, layout=orc.SAT_MAJOR)
+        assert np.abs(r - pk).max() < TOL_R and np.abs(v - vk).max() < TOL_V
+    dev = native.DeviceConstellation.from_tle_lines([(l1, l2)], native.WGS72, 0)
+    rng = np.random.default_rng(1)
+    for times in (np.arange(0.0, 300.0, 0.5), np.sort(rng.uniform(-2000.0, 5000.0, 777)), np.arange(20000.0) * 0.1):
+        for layout, shape in ((native.TIME_MAJOR, (len(times), 1, 3)), (native.SAT_MAJOR, (1, len(times), 3))):
+            pos, vel = np.full(shape, np.nan), np.full(shape, np.nan)
+            err = np.full((1, len(times)), 9, dtype=np.uint8)
+            dev.propagate_host(times, np.array([12.5]), pos=pos, vel=vel, err=err, layout=layout)
+            e0, pp, vv = cat.propagate(times, np.array([12.5]), layout=orc.SAT_MAJOR)
+            assert np.array_equal(err, e0)
+            assert np.abs(pos.reshape(-1, 3) - pp[0]).max() < TOL_R and np.abs(vel.reshape(-1, 3) - vv[0]).max() < TOL_V
+        pos = np.full((len(times), 1, 3), np.nan)
+        dev.propagate_host(times, None, pos=pos, layout=native.TIME_MAJOR)          # positions only, no offsets
+        _, pp, _ = cat.propagate(times, None, layout=orc.SAT_MAJOR)
+        assert np.abs(pos[:, 0] - pp[0]).max() < TOL_R
+    pos = np.empty((300, 1, 3))
+    dev.propagate_host(np.arange(300.0), None, pos=pos, mode=native.OUT_ECEF, reference_jd=2460437.0, layout=native.TIME_MAJOR)
+    _, pe, _ = cat.propagate(np.arange(300.0), None, mode=native.OUT_ECEF, reference_jd=2460437.0, layout=orc.SAT_MAJOR)
+    assert np.abs(pos[:, 0] - pe[0]).max() < TOL_R
+    for g in golden["G4_G5_deep_space_wgs72"]["cases"]:        # GPS, GEO, HEO: a deep-space member alone in its handle
+        d2 = native.DeviceConstellation.from_tle_lines([(g["line1"], g["line2"])], native.WGS72, 0)
+        c2 = orc.Catalog.from_pairs([(g["line1"], g["line2"])], orc.WGS72)
+        t = np.arange(0.0, 1441.0, 10.0)
+        pos, vel = np.empty((len(t), 1, 3)), np.empty((len(t), 1, 3))
+        d2.propagate_host(t, None, pos=pos, vel=vel, layout=native.TIME_MAJOR)
+        _, pp, vv = c2.propagate(t, None, layout=orc.SAT_MAJOR)
+        assert np.abs(pos[:, 0] - pp[0]).max() < TOL_R and np.abs(vel[:, 0] - vv[0]).max() < TOL_V

@@ -27,7 +27,7 @@ PMC_SETS = {
     "write": "WRITE_SIZE",
     "grbm": "GRBM_GUI_ACTIVE GRBM_COUNT",
 }
-KERNEL_PREFIXES = ("k_propagate", "k_rows", "k_tiles", "k_one", "k_deep", "k_prep", "k_classify")
+KERNEL_PREFIXES = ("k_propagate", "k_rows", "k_tiles", "k_cols", "k_one", "k_deep", "k_prep", "k_classify")
 
 
 def short(name):
@@ -116,7 +116,7 @@ def main():
                 lines.append("  derived: HBM read traffic  = %.1f MB/dispatch (2 x FETCH_SIZE KB x 1024: the guide's gfx950 correction)" % (
                     2 * d["FETCH_SIZE"] * 1024 / 1e6))
             lines.append("")
-        step_k = [k for k in js["kernels"] if "pmc" in js["kernels"][k] and k.startswith(("k_rows", "k_tiles", "k_propagate"))]
+        step_k = [k for k in js["kernels"] if "pmc" in js["kernels"][k] and k.startswith(("k_rows", "k_tiles", "k_cols", "k_propagate"))]
         W = sum(js["kernels"][k]["pmc"].get("WRITE_SIZE", 0.0) for k in step_k)
         F = sum(js["kernels"][k]["pmc"].get("FETCH_SIZE", 0.0) for k in step_k)
         V = sum(js["kernels"][k]["pmc"].get("SQ_INSTS_VALU", 0.0) for k in step_k)
