@@ -20,3 +20,4 @@ ASTROZ_AMD_COLS=1 run r05_config2_time_major_cols --pmc -- --layout time
 ASTROZ_AMD_COLS=1 run r05_config3_time_major_cols -- --deep 1522 --layout time
 cp $P/r05_config2_sat_major.json $P/latest_pmc.json
 ls -la $P | tail -30
+rm -rf gpurun_out/prof_raw
