@@ -1118,14 +1118,14 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     unsigned path = 0;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
     if (d_err) HIP_TRY(hipMemsetAsync(d_err + row_lo * (size_t)n_times, 0, (row_hi - row_lo) * (size_t)n_times, st));
-    // time-major output on a (quasi-)uniform grid: the near-earth members take the 16-satellite tile kernel.  (Irregular grids
-    // and masked launches stay on the lane = satellite kernel: a generic-step tile kernel was built and measured in round 4 --
-    // 0.40 ms against k_propagate's 0.35 on an irregular grid, 0.65 against 0.44 with a mask -- see profiles/r04_experiments.txt.)
+    // time-major output on a (quasi-)uniform grid: the near-earth members take the 16-satellite tile kernel, with or without a
+    // satellite mask (round 5).  (Irregular grids stay on the lane = satellite kernel: a generic-step tile kernel was built and
+    // measured in round 4 -- 0.40 ms against k_propagate's 0.35 -- see profiles/r04_experiments.txt.)
     const bool tiles = c->n_sgp4 > 0 && c->tile_kernel && a.inc != nullptr && layout == AZ_LAYOUT_TIME_MAJOR && !f32 &&
-                       a.mask == nullptr && n_times >= 64 &&
+                       n_times >= 64 && // (masked launches too, round 5: the flush has write-enable bits per piece)
                        (size_t)stride * 64 * 24 < 0xf0000000ull; // (k_tiles_fast: 32-bit byte offsets inside a block of 64 time rows)
     // ... or, when switched on (azh_set_tile_kernel(c, 2) / ASTROZ_AMD_COLS), the lane = satellite kernel k_cols_fast
-    const bool cols = tiles && c->cols_kernel != 0;
+    const bool cols = tiles && c->cols_kernel != 0 && a.mask == nullptr;
     const unsigned n_ecc = c->n_sgp4 - c->n_circ;
     // compact satellite-major scratch rows of a time-major launch: [deep-space list slots | (k_cols_fast) eccentric list slots]
     const size_t scratch_rows = (size_t)c->n_sdp4 + (cols ? n_ecc : 0u);

@@ -1215,11 +1215,21 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
     const unsigned s = s_first + (have ? w : 0u);
     const unsigned fl = p.flags[s];
     const unsigned rm = p.rowmap[s], kind = rm >> 30, slot = rm & 0x3fffffffu;
-    // a full tile inside the row window leaves as 16-byte pieces (384-byte runs); the last tile of the catalog and a tile a
-    // row window cuts through as 8-byte pieces at per-satellite columns
-    const bool contig = n_valid == AZ_TILE_SATS && s_first >= p.row_lo && s_first + n_valid <= p.row_hi;
+    // a full tile inside the row window with every member writable leaves as unconditional 16-byte pieces (384-byte runs); the
+    // last tile of the catalog, a tile a row window cuts through and a tile with members the satellite mask switches off leave
+    // through the same piece mapping with two write-enable bits per piece (a piece is two doubles: both writable = the same
+    // 16-byte store, one = an 8-byte store, none = nothing) -- masked launches used to fall back to the lane = satellite kernel
     const unsigned t_lo = blockIdx.y * p.tile, t_hi = min(t_lo + p.tile, p.n_times);
-    const bool in_window = have && s >= p.row_lo && s < p.row_hi;
+    const bool in_window = have && s >= p.row_lo && s < p.row_hi && (p.mask == nullptr || p.mask[s] != 0);
+    // (wave w's verdict for member w, collected over the workgroup below: bit j of `writable` = member j is written)
+    __shared__ unsigned writable_lds;
+    if (threadIdx.x == 0) writable_lds = 0u;
+    __syncthreads();
+    if (lane == 0 && in_window) atomicOr(&writable_lds, 1u << w);
+    __syncthreads();
+    const unsigned writable = writable_lds;
+    if (writable == 0u) return; // nothing of this tile is written (uniform over the workgroup)
+    const bool contig = writable == 0xffffu;
     bool dead = !(in_window && kind == AZ_ROW_NEAR);   // no arithmetic in this wave
     const bool copy = in_window && kind == AZ_ROW_COPY, zero = in_window && kind == AZ_ROW_ZERO;
     if (ECEF) {
@@ -1270,6 +1280,8 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
         f_out[m] = (unsigned)(((size_t)row * p.stride_sats + s_first) * 24u + col * 16u);
 #endif
         f_row |= (row | (arr << 7)) << (8u * m);
+        // write-enable bits of the piece's two doubles (bits 24 + 2 m, 25 + 2 m): double d of the run belongs to member d / 3
+        f_row |= (((writable >> ((col * 2u) / 3u)) & 1u) | (((writable >> ((col * 2u + 1u) / 3u)) & 1u) << 1)) << (24u + 2u * m);
     }
     // time rows that start on a 128-byte boundary (a padded out_stride_sats: 16 satellites = 384 bytes): every 384-byte run
     // is three whole lines and leaves with the streaming hint (0.283 -> 0.270 ms); unaligned rows share their first and
@@ -1344,13 +1356,18 @@ __global__ void __launch_bounds__(1024, 1) k_tiles_fast(PropArgs p)
                 else *g = val;
             }
         } else {
-            // the last tile of the catalog / a tile a row window cuts through: 8-byte pieces at per-satellite columns,
-            // addresses worked out on the spot (rare)
-            for (unsigned e = threadIdx.x; e < NA * 3072u; e += 1024u) {
-                const unsigned arr = e / 3072u, pe = e - arr * 3072u, row = pe / 48u, d = pe - row * 48u, j = d / 3u;
-                const unsigned sj = s_first + j;
-                if (j >= n_valid || sj < p.row_lo || sj >= p.row_hi || base + row >= t_hi) continue;
-                ((arr ? p.vel : p.pos) + gbase + ((size_t)row * p.stride_sats + s_first) * 3)[d] = buf[arr * (64u * AZ_TILE_PITCH) + row * AZ_TILE_PITCH + d];
+            // the same pieces, each with its write-enable bits
+            const char *bufc = reinterpret_cast<const char *>(buf);
+            char *pos_b = reinterpret_cast<char *>(p.pos + gbase), *vel_b = VEL ? reinterpret_cast<char *>(p.vel + gbase) : nullptr; // uniform
+#pragma unroll
+            for (unsigned m = 0; m < 3; ++m) {
+                const unsigned en = (f_row >> (24u + 2u * m)) & 3u;
+                if (f_lds[m] == 0xffffffffu || en == 0u || (!full && base + ((f_row >> (8u * m)) & 63u) >= t_hi)) continue;
+                const az_d2s val = *reinterpret_cast<const az_d2s *>(bufc + f_lds[m]);
+                double *g = reinterpret_cast<double *>((((f_row >> (8u * m)) & 128u) ? vel_b : pos_b) + f_out[m]);
+                if (en == 3u) *reinterpret_cast<az_d2s *>(g) = val;
+                else if (en == 1u) g[0] = val.x;
+                else g[1] = val.y;
             }
         }
     }

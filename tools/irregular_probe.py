@@ -36,7 +36,6 @@ def run(layout, tile_kernel, label, m=None, tt=None):
     print("%-40s path=%3d  %.4f ms" % (label, path, e0.elapsed_time(e1) / 100), flush=True)
 
 
-run(_native.TIME_MAJOR, 17, "irregular time-major, k_tiles (16 rows)")
 run(_native.TIME_MAJOR, 0, "irregular time-major, k_propagate")
 run(_native.TIME_MAJOR, 1, "irregular time-major, default routing")
 run(_native.SAT_MAJOR, 1, "irregular sat-major, k_rows")
