@@ -575,8 +575,13 @@ def result_empty(shape, dtype=np.float64, pinned=None):
     """numpy.empty for a RESULT of a host-returning call: a writable C-contiguous ndarray over a pinned block of the library's
     pool (returned to the pool when the array and all its views are gone), or a plain numpy array when pinned results are
     switched off, the array is small, or the host cannot pin the memory."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    if n * 8 < PINNED_MIN_BYTES and dtype is np.float64:
+        return np.empty(shape)            # (the small-call paths: nothing here may cost a microsecond)
     dt = np.dtype(dtype)
-    nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    nbytes = n * dt.itemsize
     use = _PINNED_RESULTS if pinned is None else pinned
     if not use or nbytes < PINNED_MIN_BYTES:
         return np.empty(shape, dtype=dt)
