@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 
 # algorithmic traffic / work per propagation (restated in DESIGN.md)
 from bench_common import (BYTES_OUT_P, BYTES_OUT_PV, ELEM_BYTES_PER_SAT, FLOPS_PER_PROP, FP64_VALU_PEAK_TF, HBM_PEAK_GBS,  # noqa: E402
-                          PowerSampler, _sample_rows, compact_line, cpu_baseline, csrc_fingerprint, usable_cpus)
+                          PowerSampler, _sample_rows, compact_line, cpu_baseline, csrc_fingerprint, describe_workload, usable_cpus)
 
 
 def parse_args():
@@ -255,71 +255,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(tt[0]), float(tt[1])
 
-    # config 4: the kernels alone, timed the same way, so that t_kernel and t_allgather are reported next to
-    # t_total
-    kernel_only_ms = kernel_graphs_ms = None
+    # config 4 extras, timed the same way (barrier, events, max over ranks): the kernels alone -- eager and as hipGraphs -- and
+    # the "replicate" point (every GPU propagates the FULL catalog itself): bench_sharded.py
+    kernel_only_ms = kernel_graphs_ms = replicate_ms = None
     if sharded:
-        dist.barrier()
-        torch.cuda.synchronize()
-        k0 = torch.cuda.Event(enable_timing=True)
-        k1 = torch.cuda.Event(enable_timing=True)
-        k0.record(stream)
-        sp.compute.wait_stream(stream)
-        for _ in range(a.steps):
-            step(False)
-        drain()
-        k1.record(stream)
-        torch.cuda.synchronize()
-        kt = torch.tensor([k0.elapsed_time(k1) / a.steps], dtype=torch.float64, device=cuda)
-        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
-        kernel_only_ms = float(kt[0])
-        # ... and the same windows replayed as hipGraphs (azh_set_graphs: every window's launch set is one hipGraphLaunch)
-        kernel_graphs_ms = None
-        if plan.n_chunks > 1:
-            dev.set_graphs(True)
-            for _ in range(4):
-                step(False)       # (eager, captured, replayed x2: both redo-counter parities)
-            drain()
-            torch.cuda.synchronize()
-            dist.barrier()
-            g0 = torch.cuda.Event(enable_timing=True)
-            g1 = torch.cuda.Event(enable_timing=True)
-            g0.record(stream)
-            sp.compute.wait_stream(stream)
-            for _ in range(a.steps):
-                step(False)
-            drain()
-            g1.record(stream)
-            torch.cuda.synchronize()
-            gt = torch.tensor([g0.elapsed_time(g1) / a.steps], dtype=torch.float64, device=cuda)
-            dist.all_reduce(gt, op=dist.ReduceOp.MAX)
-            kernel_graphs_ms = float(gt[0])
-            dev.set_graphs(False)
-
-    # config 4, the alternative DESIGN.md 6 recommends to consumers that need everything everywhere: every GPU propagates
-    # the FULL catalog itself ("replicate": zero bytes moved), timed the same way (barrier, events, max over ranks)
-    replicate_ms = None
-    if sharded:
-        dev_full = _native.DeviceConstellation.from_tle_lines(allp, _native.WGS72, local_rank)
-        dev_full.set_timing(False)
-        offs_full = (synth.START_JD - dev_full.epochs) * 1440.0
-        fp, fv = sp.full[0].data_ptr(), (sp.full[1].data_ptr() if vel_on else None)   # (padded >= n_total) x n_times x 3
-        dev_full.propagate_device(times, offs_full, fp, fv, layout=_native.SAT_MAJOR, stream=sptr)
-        for _ in range(max(5, a.warmup // 4)):
-            dev_full.propagate_device_cached(fp, fv, layout=_native.SAT_MAJOR, stream=sptr)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        r0 = torch.cuda.Event(enable_timing=True)
-        r1 = torch.cuda.Event(enable_timing=True)
-        r0.record(stream)
-        for _ in range(a.steps):
-            dev_full.propagate_device_cached(fp, fv, layout=_native.SAT_MAJOR, stream=sptr)
-        r1.record(stream)
-        torch.cuda.synchronize()
-        rt = torch.tensor([r0.elapsed_time(r1) / a.steps], dtype=torch.float64, device=cuda)
-        dist.all_reduce(rt, op=dist.ReduceOp.MAX)
-        replicate_ms = float(rt[0])
+        import bench_sharded
+        kernel_only_ms, kernel_graphs_ms = bench_sharded.kernel_only(torch, dist, a, dev, sp, plan, step, drain, stream, cuda)
+        replicate_ms = bench_sharded.replicate(torch, dist, _native, synth, a, allp, sp, times, vel_on, stream, sptr, cuda, local_rank)
         if gather:
             # leave the gathered result of the sharded pipeline in sp.full for the parity check below
             sp.compute.wait_stream(stream)
@@ -328,10 +270,6 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    # config 4, host-returning consumers (the C-host route, azh_group_propagate_host): ONE process, all N devices, every
-    # device copies its shard straight into the caller's catalog-ordered host arrays over its own PCIe link -- no collective.
-    # The one case where sharding this path pays: the call is PCIe-bound (16.4 ms for 932 MB over one link).  Rank 0 only,
-    # after the timed region and after the other ranks have gone.
     # Every collective is behind us: all ranks leave the process group HERE, together, and ranks != 0 exit -- rank 0 does the rest
     # (group_host on all devices, oracle parity, the secondary block) alone, with no communicator alive and no peer process
     # holding a GPU in a barrier kernel.
@@ -342,43 +280,12 @@ def main():
         dist.destroy_process_group()
     if rank != 0:
         return
-    group_host = None
+    # config 4, host-returning consumers (azh_group_propagate_host: ONE process, all N devices, every device copies its shard
+    # into the caller's catalog-ordered host arrays over its own PCIe link, no collective): rank 0 only, behind a watchdog
+    group_host, group_host_stuck = None, False
     if sharded:
-        box = {}
-
-        def _group_host():
-            try:
-                text = "\n".join(x + "\n" + y for x, y in allp)
-                devs = list(range(world)) if world > 1 else [local_rank]
-                grp = _native.DeviceGroup(text, devs, _native.WGS72, n_chunks=1)
-                goff = (synth.START_JD - grp.epochs) * 1440.0
-                ws = []
-                gp = gv = None
-                for _ in range(5):
-                    del gp, gv              # (the previous result is returned to the OS outside the timed call)
-                    t0 = time.perf_counter()
-                    res_ = grp.propagate_host(times, goff, velocities=vel_on)
-                    ws.append((time.perf_counter() - t0) * 1e3)
-                    gp, gv = res_[0], res_[1]
-                    del res_
-                gms = sorted(ws[1:])[len(ws[1:]) // 2]
-                box["r"] = {"ms_per_call": gms, "calls_ms": ws, "devices": len(devs), "value": n_total * n_times / (gms / 1e3),
-                            "GB_per_s": (gp.nbytes + (gv.nbytes if gv is not None else 0)) / (gms / 1e3) / 1e9,
-                            "what": "azh_group_propagate_host: one process, N devices, fresh host arrays each call; wall clock"}
-                del gp, gv
-                grp.close()
-            except Exception as exc:
-                box["r"] = {"failed": repr(exc)}
-
-        # (a watchdog: this is an extra, it must never take the headline line down with it)
-        import threading
-        th = threading.Thread(target=_group_host, daemon=True)
-        th.start()
-        th.join(timeout=120.0)
-        group_host = box.get("r", {"failed": "timed out after 120 s"})
-        group_host_stuck = th.is_alive()
-    else:
-        group_host_stuck = False
+        import bench_sharded
+        group_host, group_host_stuck = bench_sharded.group_host(_native, synth, allp, world, local_rank, times, vel_on, n_total, n_times)
 
     props_per_step = n_total * n_times
     value = props_per_step * a.steps / elapsed
@@ -417,39 +324,7 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
 
-    if world == 1 and a.config5_share:
-        wl = "config 5, ONE GPU's share of 8: %d synthetic satellites (seed 20260927) x %d one-minute steps" % (a.sats, n_times)
-        par = "single GPU (1/8 of the 1M-satellite job; shards are independent, no gather)"
-    elif world == 1:
-        wl = ("config 3: %d-sat synthetic catalog (%d SGP4 near-earth + %d deep-space SDP4) x %d one-minute steps" % (
-            a.sats + a.deep, a.sats, a.deep, n_times)) if a.deep else (
-            "config 2: %d-sat synthetic active catalog (SGP4 near-earth) x %d one-minute steps" % (a.sats, n_times))
-        par = "single GPU"
-    elif sharded:
-        wl = "config 4: the %d-sat synthetic catalog%s x %d one-minute steps, block-cyclic satellite shards over %d GPUs%s" % (
-            n_total, " (incl. %d deep-space SDP4)" % a.deep if a.deep else "", n_times, world,
-            ", RCCL all-gather of the full result onto every GPU (%d-chunk compute/gather pipeline)" % plan.n_chunks
-            if gather else ", NO gather (--no-gather: every GPU keeps its shard)")
-        par = "satellite-sharded x%d%s" % (world, " + RCCL all-gather" if gather else ", no data-path collective")
-    else:
-        wl = "WEAK scaling (--scaling weak): %d GPUs x an own %d-sat synthetic catalog x %d one-minute steps, no gather" % (
-            world, a.sats + a.deep, n_times)
-        par = "independent catalogs x%d, no data-path collective" % world
-    f32_fast = a.f32_out and not a.f32_fp64 and not a.no_fast_path and layout == _native.SAT_MAJOR and mode == 0
-    arith = "fp64 arithmetic" if not f32_fast else (
-        "packed fp32 arithmetic with fp64 phase and radius chains (near-circular members; fp64 for the rest)" if a.f32_arith else
-        "mixed-precision arithmetic (O(1) quantities fp64, small ones packed fp32; near-circular members; fp64 for the rest)")
-    wl += ", %s, %s %s %s, %s-major device-resident output" % (
-        arith, "fp32-stored" if a.f32_out else "fp64", a.mode.upper(), "pos+vel" if vel_on else "pos only", a.layout)
-    if layout == _native.SAT_MAJOR:
-        kname = ("k_rows_fast<%s> (branch-free uniform-grid step, one wave per satellite row, lane = time) + k_rows redo pass"
-                 if not a.no_fast_path else "k_rows<%s> (one wave per satellite row, lane = time)") % ("pos+vel" if vel_on else "pos")
-        if f32_fast:
-            kname = kname.replace("k_rows_fast<", "k_rows_fast32<MIXED," if not a.f32_arith else "k_rows_fast32<")
-    else:
-        kname = ("k_tiles_fast<%s> (16-satellite tiles of lane = time waves, LDS transpose) + k_rows redo pass"
-                 if not (a.no_fast_path or a.no_tile_kernel or a.f32_out) else "k_propagate<time-major,%s> (lane = satellite)") % (
-                     "pos+vel" if vel_on else "pos")
+    wl, par, arith, kname = describe_workload(a, world, sharded, gather, plan.n_chunks if plan else 0, n_total, n_times, layout == _native.SAT_MAJOR, mode, vel_on)
     out = {
         "metric": ("propagations/sec, 13,478 sats x 1,440 times, at 1/2/4/8 MI355X" if not a.config5_share else
                    "propagations/sec, config 5 (1M sats x 10,000 times, fp32, 8 MI355X): one GPU's 125,000-satellite share"),

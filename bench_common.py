@@ -169,6 +169,44 @@ def csrc_fingerprint():
     return h.hexdigest()[:16]
 
 
+def describe_workload(a, world, sharded, gather, n_chunks, n_total, n_times, sat_major, mode, vel_on):
+    """(config.workload, config.parallelism, the arithmetic behind the outputs, roofline.kernel) of a bench.py invocation"""
+    if world == 1 and a.config5_share:
+        wl = "config 5, ONE GPU's share of 8: %d synthetic satellites (seed 20260927) x %d one-minute steps" % (a.sats, n_times)
+        par = "single GPU (1/8 of the 1M-satellite job; shards are independent, no gather)"
+    elif world == 1:
+        wl = ("config 3: %d-sat synthetic catalog (%d SGP4 near-earth + %d deep-space SDP4) x %d one-minute steps" % (
+            a.sats + a.deep, a.sats, a.deep, n_times)) if a.deep else (
+            "config 2: %d-sat synthetic active catalog (SGP4 near-earth) x %d one-minute steps" % (a.sats, n_times))
+        par = "single GPU"
+    elif sharded:
+        wl = "config 4: the %d-sat synthetic catalog%s x %d one-minute steps, block-cyclic satellite shards over %d GPUs%s" % (
+            n_total, " (incl. %d deep-space SDP4)" % a.deep if a.deep else "", n_times, world,
+            ", RCCL all-gather of the full result onto every GPU (%d-chunk compute/gather pipeline)" % n_chunks
+            if gather else ", NO gather (--no-gather: every GPU keeps its shard)")
+        par = "satellite-sharded x%d%s" % (world, " + RCCL all-gather" if gather else ", no data-path collective")
+    else:
+        wl = "WEAK scaling (--scaling weak): %d GPUs x an own %d-sat synthetic catalog x %d one-minute steps, no gather" % (
+            world, a.sats + a.deep, n_times)
+        par = "independent catalogs x%d, no data-path collective" % world
+    f32_fast = a.f32_out and not a.f32_fp64 and not a.no_fast_path and sat_major and mode == 0
+    arith = "fp64 arithmetic" if not f32_fast else (
+        "packed fp32 arithmetic with fp64 phase and radius chains (near-circular members; fp64 for the rest)" if a.f32_arith else
+        "mixed-precision arithmetic (O(1) quantities fp64, small ones packed fp32; near-circular members; fp64 for the rest)")
+    wl += ", %s, %s %s %s, %s-major device-resident output" % (
+        arith, "fp32-stored" if a.f32_out else "fp64", a.mode.upper(), "pos+vel" if vel_on else "pos only", a.layout)
+    if sat_major:
+        kname = ("k_rows_fast<%s> (branch-free uniform-grid step, one wave per satellite row, lane = time) + k_rows redo pass"
+                 if not a.no_fast_path else "k_rows<%s> (one wave per satellite row, lane = time)") % ("pos+vel" if vel_on else "pos")
+        if f32_fast:
+            kname = kname.replace("k_rows_fast<", "k_rows_fast32<MIXED," if not a.f32_arith else "k_rows_fast32<")
+    else:
+        kname = ("k_tiles_fast<%s> (16-satellite tiles of lane = time waves, LDS transpose) + k_rows redo pass"
+                 if not (a.no_fast_path or a.no_tile_kernel or a.f32_out) else "k_propagate<time-major,%s> (lane = satellite)") % (
+                     "pos+vel" if vel_on else "pos")
+    return wl, par, arith, kname
+
+
 LINE_LIMIT = 4096   # bytes: the driver keeps a bounded tail of stdout and parses the LAST line (round 4's 21-KB line was cut)
 
 
