@@ -570,10 +570,7 @@ FastShape fast_shape_rows(const PropArgs &a, unsigned n_sgp4, unsigned n_circ)
     f.tile_e = n_circ >= 4u * n_ecc ? f.tile_c : std::min(rows_tile(std::max(n_ecc, 1u), a.n_times, 256), cap);
     // packed fp32 kernel: a lane carries two grid points, a wave iteration 128 (windows shorter than that -- grid
     // steps beyond ~23 minutes -- keep the fp64 kernel with rounded stores)
-    if (a.mode != AZ_OUT_TEME) { // ECEF / geodetic: a wave stages its segment's Greenwich-angle table in LDS (k_rows_fast)
-        f.tile_c = std::min(f.tile_c, (unsigned)AZ_FRAME_SEG);
-        f.tile_e = std::min(f.tile_e, (unsigned)AZ_FRAME_SEG);
-    }
+    // (ECEF / geodetic: the Greenwich-angle table of k_rows_fast holds 256 points and is refilled inside the loop)
     if (a.delta || a.delta64) { // quasi-uniform grid: a wave stages its segment's deviations in LDS
         f.tile_c = std::min(f.tile_c, (unsigned)AZ_DELTA_SEG);
         f.tile_e = std::min(f.tile_e, (unsigned)AZ_DELTA_SEG);
@@ -730,7 +727,6 @@ FastShape fast_shape_cols(const PropArgs &a, unsigned n_rows, unsigned n_sgp4, u
 {
     FastShape f = fast_shape_rows(a, n_sgp4, n_circ); // tile_e: the eccentric members' own lane = time launch
     f.tile_e = std::min(rows_tile(std::max(n_sgp4 - n_circ, 1u), a.n_times, a.tile_forced ? a.tile_forced : 256u), fast_window_cap(a.uniform_step));
-    if (a.mode != AZ_OUT_TEME) f.tile_e = std::min(f.tile_e, (unsigned)AZ_FRAME_SEG);
     if (a.delta || a.delta64) f.tile_e = std::min(f.tile_e, (unsigned)AZ_DELTA_SEG);
     f.tile_c = cols_tile(n_rows, a.n_times, a.tile_forced, a.uniform_step);
     f.packed32 = f.mixed32 = false;

@@ -1033,7 +1033,7 @@ __global__ void __launch_bounds__(64, 3) k_one_fast(const double *el, const unsi
 // item of the redo list and its wave exits at once; a wave of the eccentric form whose Newton iteration needs more than
 // its five fixed-tier trips appends the rest of its segment to that list; the generic kernel runs the list beside the bulk.
 // FRAME: 0 TEME, 1 ECEF, 2 geodetic (compile-time: the geodetic conversion's registers stay out of the ECEF kernel).  The
-// (sin,cos) of the Greenwich angle of this wave's whole segment (the host keeps FRAME segments at AZ_FRAME_SEG points)
+// (sin,cos) of the Greenwich angle of AZ_FRAME_SEG points of this wave's segment at a time (refilled inside the loop)
 // are staged in LDS before the loop: no table load inside it (round 2's FRAME kernels loaded two doubles per iteration,
 // each load waiting for the stores in flight, and carried the run-time choice of ECEF / geodetic: 149-173 VGPRs + scratch).
 // The pair is NOT carried by a constant rotation although the angle is linear in time: the reference evaluates GMST from
@@ -1143,6 +1143,19 @@ __global__ void __launch_bounds__(64, FRAME == 2 ? 4 : (ECC ? AZ_ROWSF_ECC_WAVES
                 continue;
             }
             if (FRAME) {
+                // the Greenwich table holds AZ_FRAME_SEG points: refilled every AZ_FRAME_SEG / 64 iterations (round 5: segments of
+                // ECEF / geodetic launches are as long as TEME ones -- cut to 256 points each wave paid its set-up, 185 VALU +
+                // the table, every four iterations: ECEF satellite-major ran 15 % behind TEME for 5 % more arithmetic)
+                if (((base - t_lo) & (AZ_FRAME_SEG - 1u)) == 0u && base != t_lo) {
+                    az_wave_lds_fence();
+#pragma unroll
+                    for (unsigned j = lane; j < AZ_FRAME_SEG; j += 64) {
+                        const unsigned jn = min(base + j, p.n_times - 1);
+                        gst_lds[2 * j] = p.sin_g[jn];
+                        gst_lds[2 * j + 1] = p.cos_g[jn];
+                    }
+                    az_wave_lds_fence();
+                }
                 const unsigned jj = (i - t_lo) & (AZ_FRAME_SEG - 1u);
                 const double sg = gst_lds[2 * jj], cg = gst_lds[2 * jj + 1];
                 az_to_ecef(r, sg, cg);
