@@ -579,7 +579,9 @@ __global__ void __launch_bounds__(64) k_deep_seed(const double *el, const unsign
 // one satellite x many times: lane = time, the satellite's constants are wave-uniform.  Every
 // evaluation is a 'first' step (full sincos seeds); deep-space lanes integrate the resonance from
 // epoch themselves, like the reference's sdp4Times8 (src/Sdp4.zig L1105-1128).
+#ifndef AZ_ONE_SEG
 #define AZ_ONE_SEG 1024 /* points per wave of k_one_fast; k_one_satellite's item lists count in these */
+#endif
 // The hand-over lists of k_one_fast: AZ_ONE_LISTS of them (a segment goes onto list seg mod AZ_ONE_LISTS), each with its own
 // counter on its own 128-byte line -- ten thousand waves pushing onto ONE list head with an atomic each took as long as the
 // arithmetic they had skipped (118 us for an all-irregular series of 10^7 points; spread over 64 heads: 16 us).
