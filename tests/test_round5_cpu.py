@@ -103,3 +103,27 @@ def test_c_api_closed_forms_on_the_host(orc):
     out = (C.c_double * 5)()
     if native.device_count() == 0:
         assert lib.azh_selftest_coords(0, (C.c_double * 4)(2451545.0, 0, 0, 0), out) == native.AZ_ERR_HIP
+
+
+def test_bench_workload_descriptions():
+    """bench_common.describe_workload: the `config.workload` / `roofline.kernel` strings of the bench record name the BASELINE
+    config, the arithmetic and the kernel family for every flag combination the driver or the profile set uses."""
+    import argparse
+    import bench_common
+
+    def ns(**kw):
+        d = dict(sats=13478, deep=0, config5_share=False, f32_out=False, f32_fp64=False, f32_arith=False, no_fast_path=False,
+                 no_tile_kernel=False, mode="teme", layout="sat")
+        d.update(kw)
+        return argparse.Namespace(**d)
+    wl, par, arith, kn = bench_common.describe_workload(ns(), 1, False, False, 0, 13478, 1440, True, 0, True)
+    assert wl.startswith("config 2: 13478-sat") and "fp64 TEME pos+vel" in wl and par == "single GPU" and arith == "fp64 arithmetic"
+    assert kn.startswith("k_rows_fast<pos+vel>")
+    wl, par, arith, kn = bench_common.describe_workload(ns(deep=1522, layout="time"), 1, False, False, 0, 15000, 1440, False, 0, True)
+    assert wl.startswith("config 3: 15000-sat") and "time-major" in wl and kn.startswith("k_tiles_fast<pos+vel>")
+    wl, par, arith, kn = bench_common.describe_workload(ns(), 8, True, True, 1, 13478, 1440, True, 0, True)
+    assert wl.startswith("config 4:") and "RCCL all-gather" in wl and "1-chunk" in wl and par == "satellite-sharded x8 + RCCL all-gather"
+    wl, par, arith, kn = bench_common.describe_workload(ns(sats=125000, config5_share=True, f32_out=True), 1, False, False, 0, 125000, 10000, True, 0, True)
+    assert wl.startswith("config 5, ONE GPU's share") and "mixed-precision" in arith and "k_rows_fast32<MIXED," in kn
+    wl, par, arith, kn = bench_common.describe_workload(ns(layout="time", no_tile_kernel=True), 1, False, False, 0, 13478, 1440, False, 0, False)
+    assert kn.startswith("k_propagate<time-major,pos>") and "pos only" in wl
