@@ -206,7 +206,10 @@ class SatrecArray:
         # (large results; _native.set_pinned_results(False) restores plain numpy.empty arrays)
         r_tm = _native.result_empty((n_times, n_sats, 3))
         v_tm = _native.result_empty((n_times, n_sats, 3)) if velocities else None
-        e = np.zeros((n_sats, n_times), dtype=np.uint8)
+        # (the error matrix too when it is large: 19 MB for config 2 -- a pageable array of that size costs the copy a millisecond
+        # of first-time pinning; the library writes every byte of it, so it needs no zero-fill)
+        big = n_sats * n_times >= _native.PINNED_MIN_BYTES
+        e = _native.result_empty((n_sats, n_times), np.uint8) if big else np.zeros((n_sats, n_times), dtype=np.uint8)
         self._dev.propagate_host(times, offsets, pos=r_tm, vel=v_tm, layout=_native.TIME_MAJOR, err=e)
         r = r_tm.transpose(1, 0, 2)
         v = v_tm.transpose(1, 0, 2) if velocities else np.zeros((n_sats, n_times, 3), dtype=np.float64)
