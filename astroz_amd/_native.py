@@ -422,7 +422,7 @@ class DeviceConstellation:
         n = len(t)
         pos = result_empty((n, 3))      # (long series: pinned blocks of the library's pool, the DMA writes them directly)
         vel = result_empty((n, 3))
-        err = np.empty(n, dtype=np.uint8)
+        err = result_empty((n,), np.uint8)          # (pinned when the series is long: the library writes every byte)
         check(lib().azh_propagate_one_host(self._h, sat_index, t.ctypes.data, n, pos.ctypes.data, vel.ctypes.data,
                                            err.ctypes.data), "azh_propagate_one_host")
         return err, pos, vel
@@ -526,7 +526,8 @@ class DeviceGroup:
         off = self._offsets(offsets_min)
         pos = result_empty((self.n, len(t), 3))
         vel = result_empty((self.n, len(t), 3)) if velocities else None
-        err = np.zeros((self.n, len(t)), dtype=np.uint8) if errors else None
+        big = self.n * len(t) >= PINNED_MIN_BYTES
+        err = (result_empty((self.n, len(t)), np.uint8) if big else np.zeros((self.n, len(t)), dtype=np.uint8)) if errors else None
         check(lib().azh_group_propagate_host(self._h, t.ctypes.data, len(t), _ptr(off), 0 if off is None else len(off), pos.ctypes.data, _ptr(vel), mode,
                                              float(reference_jd), _ptr(err)), "azh_group_propagate_host")
         return pos, vel, err
