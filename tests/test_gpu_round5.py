@@ -334,3 +334,28 @@ def test_single_satellite_constellation_call(native, orc, golden):
         d2.propagate_host(t, None, pos=pos, vel=vel, layout=native.TIME_MAJOR)
         _, pp, vv = c2.propagate(t, None, layout=orc.SAT_MAJOR)
         assert np.abs(pos[:, 0] - pp[0]).max() < TOL_R and np.abs(vel[:, 0] - vv[0]).max() < TOL_V
+
+
+def test_sgp4_device_sat_layout(native, orc, synth):
+    """SatrecArray.sgp4_device(layout="sat"): dense (n_sats, n_times, 3) device tensors, same values as the time-major call."""
+    import torch
+    from astroz_amd.api import Satrec, SatrecArray
+    pairs = synth.synth_catalog(n_near=500, n_deep=40, seed=8)
+    arr = SatrecArray([Satrec.twoline2rv(a, b) for a, b in pairs])
+    jd = np.full(300, synth.START_JD)
+    fr = 0.1 + np.arange(300) / 1440.0
+    e1, r1, v1 = arr.sgp4_device(jd, fr)
+    e2, r2, v2 = arr.sgp4_device(jd, fr, layout="sat")
+    arr.synchronize()
+    assert r2.shape == (540, 300, 3) and r2.is_contiguous() and v2.is_contiguous() and e2.shape == (540, 300)
+    assert torch.equal(e1, e2)
+    # (two kernels, two segmentations: rounding-level differences, far inside the 1e-6 km / 1e-9 km/s gate against the oracle)
+    assert float((r1.permute(1, 0, 2) - r2).abs().max()) < 1e-7 and float((v1.permute(1, 0, 2) - v2).abs().max()) < 1e-10
+    eh, rh, vh = arr.sgp4(jd, fr)
+    assert np.abs(r2.cpu().numpy() - rh).max() < 1e-7 and np.abs(v2.cpu().numpy() - vh).max() < 1e-10
+    cat = orc.Catalog.from_pairs(pairs, orc.WGS72)
+    rjd = jd[0] + fr[0]
+    _, p0, v0 = cat.propagate(((jd + fr) - rjd) * 1440.0, (rjd - arr._epochs) * 1440.0, layout=orc.SAT_MAJOR)
+    assert np.abs(r2.cpu().numpy() - p0).max() < TOL_R and np.abs(v2.cpu().numpy() - v0).max() < TOL_V
+    with pytest.raises(ValueError):
+        arr.sgp4_device(jd, fr, layout="diag")
