@@ -19,7 +19,7 @@ OUTPUT_MODES = {"teme": OUT_TEME, "ecef": OUT_ECEF, "geodetic": OUT_GEODETIC}
 
 AZ_ERR_HIP = -200
 # azh_last_path bits (include/astroz_hip.h)
-PATH_ROWS_FAST, PATH_TILES_FAST, PATH_ROWS_GENERIC, PATH_LANE_SAT, PATH_DEEP_ROWS, PATH_QUASI_UNIFORM, PATH_COLS_FAST = 1, 2, 4, 8, 16, 32, 64
+PATH_ROWS_FAST, PATH_TILES_FAST, PATH_ROWS_GENERIC, PATH_LANE_SAT, PATH_DEEP_ROWS, PATH_QUASI_UNIFORM, PATH_COLS_FAST, PATH_HOST_STEP = 1, 2, 4, 8, 16, 32, 64, 128
 
 # every symbol include/astroz_hip.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -31,7 +31,7 @@ EXPORTS = [
     "azh_num_satellites", "azh_num_sgp4", "azh_num_sdp4", "azh_get_epochs", "azh_get_status",
     "azh_get_field", "azh_propagate_host", "azh_propagate_device", "azh_propagate_device_cached", "azh_propagate_device_window",
     "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile", "azh_set_timing", "azh_set_fast_path", "azh_set_tile_kernel", "azh_set_graphs", "azh_set_f32_arithmetic", "azh_set_f32_mode",
-    "azh_last_kernel_ms", "azh_last_path", "azh_last_one_stats", "azh_set_host_copy_threads", "azh_selftest_coords", "azh_host_alloc", "azh_host_free", "azh_host_pool_stats", "azh_host_pool_trim", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
+    "azh_last_kernel_ms", "azh_last_path", "azh_last_one_stats", "azh_set_host_copy_threads", "azh_set_host_points", "azh_get_host_points", "azh_selftest_coords", "azh_host_alloc", "azh_host_free", "azh_host_pool_stats", "azh_host_pool_trim", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
     "azh_screen_target_host", "azh_screen_target_device", "azh_coarse_screen_device", "azh_coarse_screen_host",
     "azh_screen_all_host", "azh_constellation_from_omm_json", "azh_propagate_one_device", "azh_selftest_math",
     "azh_parse_tle_text", "azh_parse_omm_json", "azh_set_parse_threads", "coords_julian_to_gmst",
@@ -194,6 +194,10 @@ def lib():
     L.azh_last_kernel_ms.restype = dbl
     L.azh_set_host_copy_threads.argtypes = [i32]
     L.azh_set_host_copy_threads.restype = None
+    L.azh_set_host_points.argtypes = [sz]
+    L.azh_set_host_points.restype = None
+    L.azh_get_host_points.argtypes = []
+    L.azh_get_host_points.restype = sz
     L.azh_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     L.azh_host_alloc.restype = i32
     L.azh_host_free.argtypes = [C.c_void_p]
@@ -561,6 +565,16 @@ class _PinnedBlock:
 
 _PINNED_RESULTS = True
 PINNED_MIN_BYTES = 8 << 20   # below this a pageable array costs nothing measurable (the small-call paths do not copy at all)
+# Budget of LIVE pinned result bytes (blocks the caller still holds): beyond it results are plain numpy.empty arrays again (filled
+# through the staging slots), so a caller who accumulates results -- as the reference's numpy.empty arrays allow -- does not page-
+# lock the host.  Default 8 GiB = four config-2 results (1.9 GB each); ASTROZ_AMD_PINNED_LIVE_MB / set_pinned_budget change it.
+_PINNED_LIVE_BUDGET = int(os.environ.get("ASTROZ_AMD_PINNED_LIVE_MB", "8192")) << 20
+
+
+def set_pinned_budget(nbytes):
+    """Upper bound on pinned result bytes alive at once (see set_pinned_results); results beyond it are pageable arrays."""
+    global _PINNED_LIVE_BUDGET
+    _PINNED_LIVE_BUDGET = max(0, int(nbytes))
 
 
 def set_pinned_results(enabled):
@@ -586,6 +600,8 @@ def result_empty(shape, dtype=np.float64, pinned=None):
     use = _PINNED_RESULTS if pinned is None else pinned
     if not use or nbytes < PINNED_MIN_BYTES:
         return np.empty(shape, dtype=dt)
+    if host_pool_stats()[0] + nbytes > _PINNED_LIVE_BUDGET:
+        return np.empty(shape, dtype=dt)  # (the caller keeps earlier results alive: stay inside the live-bytes budget)
     try:
         blk = _PinnedBlock(nbytes)
     except NativeError:

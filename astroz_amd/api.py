@@ -216,12 +216,15 @@ class SatrecArray:
         return e, r, v
 
     def sgp4_device(self, jd, fr, *, velocities=True, stream=None, padded=False, layout="time"):
-        """Same computation, results left resident in HBM: returns torch tensors on the GPU
-        (e (n_sats, n_times) uint8, r_tm, v_tm (n_times, n_sats, 3) float64, dense and contiguous).  Asynchronous with respect
-        to the host; ordered on the constellation's stream (or `stream`).
+        """Same computation, results left resident in HBM: returns torch tensors on the GPU, (e, r, v) with e (n_sats, n_times)
+        uint8 and float64 r, v whose shape follows `layout`.  Asynchronous with respect to the host; ordered on the
+        constellation's stream (or `stream`).
 
-        layout="sat": r, v come back as dense (n_sats, n_times, 3) tensors instead -- the shapes `sgp4` returns, in the physical
-        layout the GPU writes a third faster (the reference's time-major layout exists for its CPU threads).
+        layout="time" (default): r, v are (n_times, n_sats, 3), the reference's physical layout (api.py L304-314), dense and
+        contiguous unless padded=True.
+        layout="sat": r, v are dense (n_sats, n_times, 3) tensors -- the shapes `sgp4` returns, in the physical layout the GPU
+        writes a third faster (the reference's time-major layout exists for its CPU threads).  padded=True has no meaning
+        there and raises ValueError.
 
         padded=True: the time rows of the underlying arrays are padded to a multiple of 16 satellites (384 bytes = three whole
         128-byte lines: every run of the time-major tile kernel then starts on a line boundary and leaves as streaming stores,
@@ -230,6 +233,10 @@ class SatrecArray:
         dense layout."""
         import torch
 
+        if layout not in ("time", "sat"):
+            raise ValueError("layout must be 'time' or 'sat'")
+        if layout == "sat" and padded:
+            raise ValueError("padded=True applies to layout='time' only (satellite-major rows are dense)")
         times, offsets = self._grid(jd, fr)
         n_times, n_sats = len(times), self._num_sats
         dev = torch.device("cuda", self._device)  # the device the element table lives on
@@ -243,8 +250,6 @@ class SatrecArray:
             self._dev.propagate_device(times, offsets, r.data_ptr(), None if v is None else v.data_ptr(),
                                        layout=_native.SAT_MAJOR, d_err=e.data_ptr(), stream=stream)
             return e, r, v
-        if layout != "time":
-            raise ValueError("layout must be 'time' or 'sat'")
         stride = (n_sats + 15) // 16 * 16 if padded else n_sats
         alloc = torch.zeros if stride != n_sats else torch.empty
         r_tm = alloc((n_times, stride, 3), dtype=torch.float64, device=dev)

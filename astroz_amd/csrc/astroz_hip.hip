@@ -24,6 +24,7 @@
 
 #include "kernels.h"
 #include "tle_host.h"
+#include "host_step.h"
 
 namespace {
 
@@ -210,6 +211,7 @@ struct azh_constellation {
         unsigned sig_before, sig_after; // parity bits of the four window plans before / after the launch set
         unsigned path;
         unsigned seen;                  // calls with this key before it was captured
+        unsigned fails;                 // failed captures of this key; from the second on the key runs eagerly for good
         hipGraph_t graph;
         hipGraphExec_t exec;
     };
@@ -229,9 +231,24 @@ struct azh_constellation {
     // 2 = fp64 arithmetic rounded at the store everywhere
     int f32_mode = 0;
     bool fast_path = true; // use the branch-free uniform-grid step where it applies (azh_set_fast_path)
+    // host route of calls of a few points (host_step.h): the element columns the DEVICE initialised, mirrored on the host.
+    // Small handles (what Satrec / sgp4_init make): the whole table, fetched with the status words when the handle is made;
+    // catalogs: one column per satellite asked for, fetched on first use (at most kHostCols of them, oldest replaced).
+    std::vector<double> h_el;                            // [AZ_NUM_FIELDS][n_pad] or empty
+    std::vector<std::pair<size_t, std::vector<double>>> h_cols; // (satellite, AZ_NUM_FIELDS contiguous doubles)
+    size_t h_cols_next = 0;
 };
 
 namespace {
+
+constexpr size_t kHostMirrorPad = 64; // handles of up to 64 satellites mirror their whole element table on the host
+constexpr size_t kHostCols = 256;     // cached columns of larger handles
+// calls of at most this many points take the host route (azh_set_host_points; 0 switches it off)
+std::atomic<size_t> g_host_points{[] {
+    const char *e = getenv("ASTROZ_AMD_HOST_POINTS");
+    return e ? (size_t)strtoull(e, nullptr, 10) : size_t(64);
+}()};
+inline size_t host_points() { return azhost::cpu_ok() ? g_host_points.load(std::memory_order_relaxed) : 0; }
 
 // internal return code: the launch set cannot be captured yet (a plan, the seeds or a scratch buffer must be built first)
 constexpr int32_t AZ_RC_EAGER = 0x7a5eca9;
@@ -345,6 +362,13 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
         hipLaunchKernelGGL(k_init, dim3((unsigned)(np / 64)), dim3(64), 0, c->s_main, d_raw, n, np, c->g, c->d_el, c->d_flags);
         if (!hip_ok(hipGetLastError(), "k_init launch")) { rc = AZ_ERR_HIP; break; }
         c->h_flags.resize(n);
+        if (np <= kHostMirrorPad) { // (host route of few-point calls: the initialised columns travel back with the status words)
+            c->h_el.resize((size_t)AZ_NUM_FIELDS * np);
+            if (!hip_ok(hipMemcpyAsync(c->h_el.data(), c->d_el, sizeof(double) * c->h_el.size(), hipMemcpyDeviceToHost, c->s_main), "D2H el")) {
+                rc = AZ_ERR_HIP;
+                break;
+            }
+        }
         if (!hip_ok(hipMemcpyAsync(c->h_flags.data(), c->d_flags, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->s_main), "D2H flags") ||
             !hip_ok(hipStreamSynchronize(c->s_main), "sync(init)")) {
             rc = AZ_ERR_HIP;
@@ -983,6 +1007,7 @@ int32_t prepare_deep(azh_constellation *c, PropArgs &d, hipStream_t st, bool row
     const unsigned n_tiles = (n_times + seed_tile - 1) / seed_tile;
     if (!c->seeds_valid || c->seeds_tile != seed_tile || c->seeds_rows != rows) {
         if (c->capturing) return AZ_RC_EAGER;
+        drop_graphs(c); // (captured launch sets hold the old seed table / its layout)
         if (c->d_seeds.ensure((size_t)n_tiles * 3 * c->n_sdp4) != AZ_OK) return AZ_ERR_HIP;
         if (c->d_node_cache.p == nullptr) {
             if (c->d_node_cache.ensure(3 * c->n_pad) != AZ_OK) return AZ_ERR_HIP;
@@ -1007,6 +1032,7 @@ int32_t ensure_plan(azh_constellation *c, PropArgs &a, const FastShape &shape, h
     const unsigned n_seg = (a.n_times + std::min(shape.tile_c, shape.tile_e) - 1) / std::min(shape.tile_c, shape.tile_e);
     if (!pl.valid || pl.tile_c != shape.tile_c || pl.tile_e != shape.tile_e || pl.n_list != n_list || pl.mixed32 != shape.mixed32) {
         if (c->capturing) return AZ_RC_EAGER;
+        drop_graphs(c); // (captured launch sets hold this plan's buffers and counters)
         // static items: at most one per (slot, segment); dynamic ones: only waves of eccentric members file them, at most one
         // per 64-point iteration
         const size_t items = (size_t)n_list * n_seg + ((size_t)a.n_times + 63) / 64 * (c->n_sgp4 - c->n_circ);
@@ -1128,7 +1154,10 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
     const size_t scratch_per = scratch_rows * n_times * 3, scratch_words = f32 ? (scratch_per + 1) / 2 : scratch_per; // in doubles
     auto ensure_scratch = [&](hipStream_t user) -> int32_t {
         if (c->capturing && c->d_deep_tmp.cap < scratch_words * (d_vel ? 2 : 1)) return AZ_RC_EAGER;
-        if (c->d_deep_tmp.cap < scratch_words * (d_vel ? 2 : 1)) HIP_TRY(hipStreamSynchronize(user));
+        if (c->d_deep_tmp.cap < scratch_words * (d_vel ? 2 : 1)) {
+            HIP_TRY(hipStreamSynchronize(user));
+            drop_graphs(c); // (captured launch sets hold the old scratch pointer: ADVICE r05)
+        }
         if (c->d_deep_tmp.ensure(scratch_words * (d_vel ? 2 : 1)) != AZ_OK) return AZ_ERR_HIP;
         a.tmp_pos = c->d_deep_tmp.p;
         a.tmp_vel = d_vel ? c->d_deep_tmp.p + scratch_words : nullptr;
@@ -1235,6 +1264,7 @@ int32_t launch_cached(azh_constellation *c, double *d_pos, double *d_vel, int la
     for (auto &g : c->graphs)
         if (g.pos == d_pos && g.vel == d_vel && g.err == d_err && g.layout == layout && g.f32 == f32 && g.stride == stride &&
             g.row_lo == row_lo && g.row_hi == row_hi && g.st == st) {
+            if (g.fails >= 2) return launch_all(c, d_pos, d_vel, layout, stride, d_err, st, f32, row_lo, row_hi); // (uncapturable key)
             if (g.exec && g.sig_before == sig) { hit = &g; break; }
             if (!g.exec && g.sig_before == sig) pending = &g;
         }
@@ -1250,7 +1280,7 @@ int32_t launch_cached(azh_constellation *c, double *d_pos, double *d_vel, int la
         const int32_t rc = launch_all(c, d_pos, d_vel, layout, stride, d_err, st, f32, row_lo, row_hi);
         if (rc == AZ_OK) {
             try {
-                c->graphs.push_back({d_pos, d_vel, d_err, layout, f32, stride, row_lo, row_hi, st, sig, plan_sig(c), c->last_path, 1u, nullptr, nullptr});
+                c->graphs.push_back({d_pos, d_vel, d_err, layout, f32, stride, row_lo, row_hi, st, sig, plan_sig(c), c->last_path, 1u, 0u, nullptr, nullptr});
             } catch (const std::bad_alloc &) {
             }
         }
@@ -1273,8 +1303,9 @@ int32_t launch_cached(azh_constellation *c, double *d_pos, double *d_vel, int la
         (void)hipGetLastError();
         if (graph) (void)hipGraphDestroy(graph);
         for (unsigned k = 0; k < 4; ++k) c->plan[k].parity = parity0[k]; // (nothing ran)
-        pending->seen = 0;
-        pending->sig_before = ~0u; // never captured again
+        // the entry stays: one more attempt when this parity comes round again (a plan or the seeds may have had to be built
+        // first), then the key runs eagerly for good -- no BeginCapture / EndCapture pair on every other call
+        pending->fails += 1;
         if (rc != AZ_OK && rc != AZ_RC_EAGER) return rc;
         return launch_all(c, d_pos, d_vel, layout, stride, d_err, st, f32, row_lo, row_hi);
     }
@@ -1570,12 +1601,50 @@ constexpr size_t kOneStage = 16384;
 constexpr size_t kSmallOut = size_t(512) << 10; // bytes of results a host-returning constellation call lets its kernels write to pinned host memory directly
 constexpr size_t kOneZeroCopy = AZ_ONE_ZERO_COPY_MAX; // points the kernel exchanges with the pinned buffer directly
 
+// the element column of one satellite on the host (table, padded length, column index), or nullptr when it cannot be fetched
+const double *host_column(azh_constellation *c, size_t sat, size_t &n_pad, size_t &col)
+{
+    if (!c->h_el.empty()) {
+        n_pad = c->n_pad;
+        col = sat;
+        return c->h_el.data();
+    }
+    n_pad = 1;
+    col = 0;
+    for (auto &e : c->h_cols)
+        if (e.first == sat) return e.second.data();
+    if (set_device(c) != AZ_OK) return nullptr;
+    std::vector<double> f(AZ_NUM_FIELDS);
+    if (!hip_ok(hipMemcpy2D(f.data(), sizeof(double), c->d_el + sat, sizeof(double) * c->n_pad, sizeof(double), AZ_NUM_FIELDS,
+                            hipMemcpyDeviceToHost), "D2H column"))
+        return nullptr;
+    if (c->h_cols.size() < kHostCols) {
+        c->h_cols.emplace_back(sat, std::move(f));
+        return c->h_cols.back().second.data();
+    }
+    auto &slot = c->h_cols[c->h_cols_next++ % kHostCols];
+    slot.first = sat;
+    slot.second = std::move(f);
+    return slot.second.data();
+}
+
 // one satellite x n times.  interleaved = 1: out6 is n x 6 (x,y,z,vx,vy,vz; c_api batch layout); otherwise
 // pos (n x 3), vel (n x 3, optional), err (n, optional).
 int32_t run_one_satellite(azh_constellation *c, size_t sat, const double *tsince, size_t n, int interleaved,
                           double *out6, double *pos, double *vel, uint8_t *err)
 {
     if (n > 0xffffffffu) return AZ_ERR_VALUE;
+    if (n <= host_points() && sat < c->n) {
+        // a handful of points: the same step source on the calling thread, from the device-initialised column (host_step.h) --
+        // no launch, no synchronize: 0.1-0.2 us per point against 20 us per call
+        size_t np = 0, col = 0;
+        if (const double *el = host_column(c, sat, np, col)) {
+            azhost::propagate_points(el, np, col, c->h_flags[sat], c->g, tsince, n, interleaved, out6, pos, vel, err);
+            c->last_path = AZH_PATH_HOST_STEP;
+            c->one_segments = 0;
+            return AZ_OK;
+        }
+    }
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
     hipStream_t st = c->s_main;
     if (c->d_one_t.ensure(n) != AZ_OK || c->d_one_o.ensure(6 * n) != AZ_OK || c->d_one_e.ensure(n) != AZ_OK) return AZ_ERR_HIP;
@@ -1887,6 +1956,8 @@ int32_t azh_set_f32_arithmetic(azh_constellation *c, int32_t enabled)
 }
 
 void azh_set_host_copy_threads(int32_t n) { g_host_copy_threads.store(n < 0 ? -1 : n, std::memory_order_relaxed); }
+void azh_set_host_points(size_t n) { g_host_points.store(n, std::memory_order_relaxed); }
+size_t azh_get_host_points(void) { return host_points(); }
 
 int32_t azh_host_alloc(size_t bytes, void **out)
 {
@@ -2368,6 +2439,10 @@ static int32_t azh_propagate_host_impl(azh_constellation *c, const double *times
         if (offsets)
             for (auto &t : ts) t += offsets[0];
         c->last_path = 0; // (none of the constellation kernel families)
+        // nothing is staged on this route: the cached-input entry points must not find an older grid
+        c->cached_n_times = 0;
+        c->staged_valid = false;
+        c->timed = false;
         return run_one_satellite(c, 0, ts.data(), n_times, 0, nullptr, pos, vel, err);
     }
     // A few satellites (what Satrec / SatrecArray([sat]) / a c_api client make): the kernels write straight into a pinned host

@@ -118,6 +118,8 @@ pub extern "c" fn azh_set_f32_arithmetic(h: ?*Handle, enabled: i32) i32; // bool
 pub extern "c" fn azh_set_fast_path(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_set_tile_kernel(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_set_graphs(h: ?*Handle, enabled: i32) i32; // hipGraph replay of repeated cached-input launch sets (default off; pays for multi-window pipelines)
+pub extern "c" fn azh_set_host_points(n: usize) void; // one-satellite calls of at most n points run the library's step on the calling thread (default 64)
+pub extern "c" fn azh_get_host_points() usize;
 pub extern "c" fn azh_set_host_copy_threads(n: i32) void; // host threads behind the pinned staging of host-returning copies (-1 auto, 0 = direct pageable copies)
 // result arrays the DMA engines write directly (pinned, pooled inside the library): a Zig host allocates `positions` / `velocities`
 // here instead of from its allocator, and azh_propagate_host lands in them at the link rate (no staging hop)

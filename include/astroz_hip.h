@@ -357,6 +357,14 @@ int32_t azh_set_graphs(azh_constellation *c, int32_t enabled);
  * link.  A direct copy into FRESH pageable arrays pays the runtime's first-time pinning of the range (config 2: 55 ms instead
  * of the link's 17).  -1 automatic (default: 6), 0 = direct pageable copies. */
 void azh_set_host_copy_threads(int32_t n);
+/* One-satellite host-pointer calls of at most n points (azh_propagate_one_host, sgp4_propagate, sgp4_propagate_batch, and
+ * azh_propagate_host on a one-satellite handle; default 64, environment ASTROZ_AMD_HOST_POINTS, 0 = never) do not launch a
+ * kernel: the library evaluates its own per-point step (the source k_one_satellite compiles, astroz_amd/csrc/host_step.h) on
+ * the calling thread, from the element column the DEVICE initialised -- what the reference's scalar call is
+ * (bindings/python/src/satrec.zig L169-201: 0.4 us; a launch + a synchronize is 20 us).  Results agree with the kernels' to
+ * rounding (tests/test_gpu_round6.py: 1e-9 km / 1e-12 km/s); azh_last_path reports AZH_PATH_HOST_STEP.  Process-wide. */
+void azh_set_host_points(size_t n);
+size_t azh_get_host_points(void);
 /* Result arrays the DMA engines can write: pinned host memory from a pool inside the library.  A host-returning call
  * (azh_propagate_host, azh_propagate_jd_host, azh_group_propagate_host, azh_propagate_one_host) whose pos / vel arrays were
  * allocated here skips the staging hop: the device-to-host copy lands in them at the link rate (config 2's 932 MB: 16.4 ms
@@ -387,6 +395,7 @@ double azh_last_kernel_ms(azh_constellation *c);
 #define AZH_PATH_DEEP_ROWS 16u    /* k_rows_deep: lane = time deep-space rows */
 #define AZH_PATH_COLS_FAST 64u     /* k_cols_fast: lane = satellite, branch-free, time-major runs of 64 catalog rows */
 #define AZH_PATH_QUASI_UNIFORM 32u /* the staged grid is quasi-uniform: the fast kernels ran in their DELTA form */
+#define AZH_PATH_HOST_STEP 128u   /* no kernel: a one-satellite call of at most azh_get_host_points() points, evaluated on the calling thread */
 uint32_t azh_last_path(const azh_constellation *c);
 /* the most recent one-satellite call of this handle (azh_propagate_one_host / _device; sgp4_propagate / _batch through their
  * handles): the number of 1,024-point segments the branch-free kernel was launched on (0: the series was short, interleaved,

@@ -22,7 +22,8 @@ def build(defs=()):
     os.makedirs(OUT, exist_ok=True)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-save-temps",
            "-I", os.path.join(ROOT, "include"), "-o", os.path.join(OUT, "lib.so"),
-           os.path.join(ROOT, "astroz_amd", "csrc", "astroz_hip.hip"), os.path.join(ROOT, "astroz_amd", "csrc", "tle_host.cpp")]
+           os.path.join(ROOT, "astroz_amd", "csrc", "astroz_hip.hip"), os.path.join(ROOT, "astroz_amd", "csrc", "tle_host.cpp"),
+           "-x", "none", os.path.join(ROOT, "astroz_amd", "host_step.o")]  # (built by __graft_entry__.build())
     cmd += ["-D" + d for d in defs]
     subprocess.run(cmd, cwd=OUT, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 

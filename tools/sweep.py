@@ -19,7 +19,8 @@ def build(specs):
         out = os.path.join(VAR, "lib_%s.so" % name)
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread"] + [f for f in flags.split(",") if f] + [
             "-Rpass-analysis=kernel-resource-usage", "-I", os.path.join(ROOT, "include"), "-o", out,
-            os.path.join(ROOT, "astroz_amd/csrc/astroz_hip.hip"), os.path.join(ROOT, "astroz_amd/csrc/tle_host.cpp")]
+            os.path.join(ROOT, "astroz_amd/csrc/astroz_hip.hip"), os.path.join(ROOT, "astroz_amd/csrc/tle_host.cpp"),
+            "-x", "none", os.path.join(ROOT, "astroz_amd/host_step.o")]  # (built by __graft_entry__.build())
         procs.append((name, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
     for name, pr in procs:
         _, err = pr.communicate()
