@@ -31,13 +31,14 @@ EXPORTS = [
     "azh_num_satellites", "azh_num_sgp4", "azh_num_sdp4", "azh_get_epochs", "azh_get_status",
     "azh_get_field", "azh_propagate_host", "azh_propagate_device", "azh_propagate_device_cached", "azh_propagate_device_window",
     "azh_propagate_jd_host", "azh_synchronize", "azh_propagate_one_host", "azh_set_time_tile", "azh_set_timing", "azh_set_fast_path", "azh_set_tile_kernel", "azh_set_graphs", "azh_set_f32_arithmetic", "azh_set_f32_mode",
-    "azh_last_kernel_ms", "azh_last_path", "azh_last_one_stats", "azh_set_host_copy_threads", "azh_set_host_points", "azh_get_host_points", "azh_selftest_coords", "azh_host_alloc", "azh_host_free", "azh_host_pool_stats", "azh_host_pool_trim", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
+    "azh_last_kernel_ms", "azh_last_path", "azh_last_one_stats", "azh_set_host_copy_threads", "azh_set_host_points", "azh_get_host_points", "azh_selftest_coords", "azh_selftest_host_step", "azh_host_alloc", "azh_host_free", "azh_host_pool_stats", "azh_host_pool_trim", "azh_propagate_device_f32", "azh_propagate_device_cached_f32",
     "azh_screen_target_host", "azh_screen_target_device", "azh_coarse_screen_device", "azh_coarse_screen_host",
     "azh_screen_all_host", "azh_constellation_from_omm_json", "azh_propagate_one_device", "azh_selftest_math",
     "azh_parse_tle_text", "azh_parse_omm_json", "azh_set_parse_threads", "coords_julian_to_gmst",
     "azh_group_create_from_tle_text", "azh_group_create_from_omm_json", "azh_group_free", "azh_group_num_satellites",
     "azh_group_num_devices", "azh_group_padded_rows", "azh_group_get_epochs", "azh_group_propagate_host",
-    "azh_group_propagate_allgather", "coords_eci_to_ecef", "coords_ecef_to_geodetic",
+    "azh_group_propagate_allgather", "azh_group_screen_target_host", "azh_group_screen_target_device", "azh_group_shard_size",
+    "azh_group_shard_rows", "azh_group_synchronize", "azh_screen_track_device", "coords_eci_to_ecef", "coords_ecef_to_geodetic",
     "orbital_hohmann", "orbital_velocity", "orbital_period", "orbital_escape_velocity",
 ]
 
@@ -134,6 +135,16 @@ def lib():
     L.azh_group_propagate_host.restype = i32
     L.azh_group_propagate_allgather.argtypes = [vp, vp, sz, vp, sz, vp, vp]
     L.azh_group_propagate_allgather.restype = i32
+    L.azh_group_screen_target_host.argtypes = [vp, vp, sz, vp, sz, sz, dbl, dbl, vp, vp]
+    L.azh_group_screen_target_host.restype = i32
+    L.azh_group_screen_target_device.argtypes = [vp, vp, sz, vp, sz, sz, dbl, dbl, vp, vp]
+    L.azh_group_screen_target_device.restype = i32
+    L.azh_group_shard_size.argtypes = [vp, i32]
+    L.azh_group_shard_size.restype = sz
+    L.azh_group_shard_rows.argtypes = [vp, i32, vp]
+    L.azh_group_shard_rows.restype = i32
+    L.azh_group_synchronize.argtypes = [vp]
+    L.azh_group_synchronize.restype = i32
     L.azh_constellation_from_omm_json.argtypes = [C.c_char_p, sz, i32, i32, C.POINTER(vp)]
     L.azh_constellation_from_omm_json.restype = i32
     L.azh_propagate_one_device.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp]
@@ -218,6 +229,8 @@ def lib():
     L.azh_screen_target_host.restype = i32
     L.azh_screen_target_device.argtypes = [vp, vp, sz, vp, sz, dbl, dbl, vp, vp, vp]
     L.azh_screen_target_device.restype = i32
+    L.azh_screen_track_device.argtypes = [vp, vp, sz, vp, vp, sz, dbl, vp, vp, vp]
+    L.azh_screen_track_device.restype = i32
     L.azh_coarse_screen_device.argtypes = [vp, sz, sz, i32, sz, dbl, vp, vp, vp, sz, C.POINTER(sz), vp]
     L.azh_coarse_screen_device.restype = i32
     L.azh_coarse_screen_host.argtypes = [vp, sz, sz, i32, sz, dbl, vp, vp, vp, sz, C.POINTER(sz), i32]
@@ -303,6 +316,10 @@ class DeviceConstellation:
         check(lib().azh_constellation_subset(self._h, idx.ctypes.data, len(idx), device, C.byref(h)),
               "azh_constellation_subset")
         return type(self)(h)
+
+    def handle_address(self):
+        """The azh_constellation pointer as an integer (valid while this object lives)."""
+        return int(self._h.value)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -407,6 +424,18 @@ class DeviceConstellation:
                                            float(threshold), float(reference_jd), d.ctypes.data, ti.ctypes.data),
               "azh_screen_target_host")
         return d, ti
+
+    def screen_track_device(self, times_min, d_track, threshold, d_min_dist, d_min_t, offsets_min=None, exclude=None, stream=None):
+        """Fused screen of this constellation's rows against an EXTERNAL track (azh_screen_track_device): d_track = raw device
+        pointer to (n_times, 3) float64 TEME km; results into device buffers of n entries; asynchronous.  exclude: a member that
+        reports threshold / 0 (the target itself, when this shard owns it)."""
+        times = _f64(times_min)
+        off = None if offsets_min is None else _f64(offsets_min)
+        if off is not None and len(off) < self.n:
+            raise ValueError("epoch_offsets must have at least num_satellites elements")
+        ex = C.c_size_t(-1).value if exclude is None else int(exclude)
+        check(lib().azh_screen_track_device(self._h, times.ctypes.data, len(times), _ptr(off), d_track, ex, float(threshold),
+                                            d_min_dist, d_min_t, stream), "azh_screen_track_device")
 
     def screen_all(self, times_min, threshold=10.0, offsets_min=None, max_results=10_000_000):
         """All-vs-all: propagate on the device and screen there: (pairs (k,2) u32, t_index (k,) u32),
@@ -536,6 +565,39 @@ class DeviceGroup:
                                              float(reference_jd), _ptr(err)), "azh_group_propagate_host")
         return pos, vel, err
 
+    def screen_target(self, times_min, target, threshold_km, offsets_min=None, reference_jd=0.0):
+        """Fused single-target screen over all devices of the group (azh_group_screen_target_host): every device screens
+        its own rows, no collective.  -> (min_dist (n,) float64 km, min_t (n,) uint32), catalog order."""
+        t = _f64(times_min)
+        off = self._offsets(offsets_min)
+        d = np.empty(self.n)
+        ti = np.empty(self.n, dtype=np.uint32)
+        check(lib().azh_group_screen_target_host(self._h, t.ctypes.data, len(t), _ptr(off), 0 if off is None else len(off), int(target),
+                                                 float(threshold_km), float(reference_jd), d.ctypes.data, ti.ctypes.data),
+              "azh_group_screen_target_host")
+        return d, ti
+
+    def screen_target_device(self, times_min, target, threshold_km, d_dist_ptrs, d_t_ptrs, offsets_min=None):
+        """The same with per-device result buffers (raw device pointers on devices[i], shard_size(i) entries each, local order =
+        shard_rows(i)); asynchronous -- synchronize() waits for every shard."""
+        t = _f64(times_min)
+        off = self._offsets(offsets_min)
+        dd = (C.c_void_p * self.n_devices)(*d_dist_ptrs)
+        tt = (C.c_void_p * self.n_devices)(*d_t_ptrs)
+        check(lib().azh_group_screen_target_device(self._h, t.ctypes.data, len(t), _ptr(off), 0 if off is None else len(off), int(target),
+                                                   float(threshold_km), 0.0, dd, tt), "azh_group_screen_target_device")
+
+    def shard_size(self, slot):
+        return int(lib().azh_group_shard_size(self._h, int(slot)))
+
+    def shard_rows(self, slot):
+        out = np.empty(self.shard_size(slot), dtype=np.uint32)
+        check(lib().azh_group_shard_rows(self._h, int(slot), out.ctypes.data), "azh_group_shard_rows")
+        return out
+
+    def synchronize(self):
+        check(lib().azh_group_synchronize(self._h), "azh_group_synchronize")
+
     def propagate_allgather(self, times_min, offsets_min, d_pos_ptrs, d_vel_ptrs=None):
         """Full TEME arrays on every device: d_pos_ptrs[i] = raw device pointer on devices[i] to
         padded_rows x n_times x 3 doubles."""
@@ -609,6 +671,33 @@ def result_empty(shape, dtype=np.float64, pinned=None):
     buf = (C.c_char * nbytes).from_address(blk.ptr)
     buf._az_owner = blk          # the ctypes array is the ndarray's base: the block lives as long as any view does
     return np.frombuffer(buf, dtype=dt).reshape(shape)
+
+
+_fast_mod = False
+
+
+def fast_scalar():
+    """The CPython shim of the scalar call (astroz_amd/csrc/pyfast.c, built by __graft_entry__.build()), bound to the loaded
+    library's azh_propagate_one_host -- or None when it was not built (Satrec.sgp4 then makes the same call through ctypes)."""
+    global _fast_mod
+    if _fast_mod is False:
+        try:
+            from . import _azfast
+            _azfast.bind(C.cast(lib().azh_propagate_one_host, C.c_void_p).value)
+            _fast_mod = _azfast
+        except Exception:
+            _fast_mod = None
+    return _fast_mod
+
+
+def set_host_points(n):
+    """One-satellite host-pointer calls of at most n points run the library's own step on the calling thread instead of
+    launching a kernel (azh_set_host_points; default 128, deep-space members half of it; 0 = never)."""
+    lib().azh_set_host_points(int(n))
+
+
+def get_host_points():
+    return int(lib().azh_get_host_points())
 
 
 def host_pool_stats():

@@ -82,6 +82,7 @@ class Satrec:
         self._dev = None      # 1-satellite device constellation (lazy)
         self._status = None   # (err, is_deep, irez), filled by _ensure or by a SatrecArray
         self._a = None
+        self._scalar = None   # (shim function, handle address, epoch) of the scalar call, or False without the shim
 
     @classmethod
     def twoline2rv(cls, line1, line2, whichconst=WGS72):
@@ -135,12 +136,32 @@ class Satrec:
 
     # -- propagation ---------------------------------------------------------------------
     def sgp4(self, jd, fr):
-        """-> (error, (x, y, z) km, (vx, vy, vz) km/s), TEME.  satrec.zig L169-201."""
+        """-> (error, (x, y, z) km, (vx, vy, vz) km/s), TEME.  satrec.zig L169-201.
+
+        One point does not launch a kernel: the library evaluates its per-point step on the calling thread from the elements
+        the GPU initialised (azh_set_host_points; include/astroz_hip.h), reached through a CPython shim when it is built
+        (astroz_amd/csrc/pyfast.c) and through ctypes otherwise."""
+        sc = self._scalar
+        if sc is None:
+            sc = self._bind_scalar()
+        if sc:
+            t, rc, e, r, v = sc[0](sc[1], jd, fr, sc[2])
+            if rc:
+                _native.check(rc, "azh_propagate_one_host")
+            self.t = t
+            self.error = e
+            return e, r, v
         tsince = ((jd + fr) - (self.jdsatepoch + self.jdsatepochF)) * 1440.0
         self.t = tsince
         e, r, v = self._ensure().propagate_one(0, tsince)
         self.error = int(e[0])
         return self.error, tuple(float(x) for x in r[0]), tuple(float(x) for x in v[0])
+
+    def _bind_scalar(self):
+        dev = self._ensure()
+        mod = _native.fast_scalar()
+        self._scalar = (mod.sgp4, dev.handle_address(), self.jdsatepoch + self.jdsatepochF) if mod is not None else False
+        return self._scalar
 
     def sgp4_array(self, jd, fr):
         """Many times, one satellite (lane = time on the GPU).  -> e (n,), r (n,3), v (n,3)."""

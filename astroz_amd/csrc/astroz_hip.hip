@@ -242,11 +242,12 @@ struct azh_constellation {
 namespace {
 
 constexpr size_t kHostMirrorPad = 64; // handles of up to 64 satellites mirror their whole element table on the host
+// (default point limit of the host route: 128, i.e. 128 near-earth / 64 deep-space points per call)
 constexpr size_t kHostCols = 256;     // cached columns of larger handles
 // calls of at most this many points take the host route (azh_set_host_points; 0 switches it off)
 std::atomic<size_t> g_host_points{[] {
     const char *e = getenv("ASTROZ_AMD_HOST_POINTS");
-    return e ? (size_t)strtoull(e, nullptr, 10) : size_t(64);
+    return e ? (size_t)strtoull(e, nullptr, 10) : size_t(128);
 }()};
 inline size_t host_points() { return azhost::cpu_ok() ? g_host_points.load(std::memory_order_relaxed) : 0; }
 
@@ -1634,9 +1635,11 @@ int32_t run_one_satellite(azh_constellation *c, size_t sat, const double *tsince
                           double *out6, double *pos, double *vel, uint8_t *err)
 {
     if (n > 0xffffffffu) return AZ_ERR_VALUE;
-    if (n <= host_points() && sat < c->n) {
-        // a handful of points: the same step source on the calling thread, from the device-initialised column (host_step.h) --
-        // no launch, no synchronize: 0.1-0.2 us per point against 20 us per call
+    // a handful of points: the same step source on the calling thread, from the device-initialised column (host_step.h) -- no
+    // launch, no synchronize.  Measured (tools/host_route_probe.py, EPYC 9575F): 0.07-0.14 us per near-earth point, 0.16-0.23 per
+    // deep-space point, against 21-23 us per call through the kernel: the routes cross at ~230 / ~120 points, so deep-space
+    // members take the host route up to half the limit
+    if (sat < c->n && n <= host_points() / ((c->h_flags[sat] & AZ_FLAG_DEEP) ? 2 : 1)) {
         size_t np = 0, col = 0;
         if (const double *el = host_column(c, sat, np, col)) {
             azhost::propagate_points(el, np, col, c->h_flags[sat], c->g, tsince, n, interleaved, out6, pos, vel, err);
@@ -1646,6 +1649,7 @@ int32_t run_one_satellite(azh_constellation *c, size_t sat, const double *tsince
         }
     }
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    c->last_path = 0; // (none of the constellation kernel families, and not the host route)
     hipStream_t st = c->s_main;
     if (c->d_one_t.ensure(n) != AZ_OK || c->d_one_o.ensure(6 * n) != AZ_OK || c->d_one_e.ensure(n) != AZ_OK) return AZ_ERR_HIP;
     const bool staged = n <= kOneStage;
@@ -2092,28 +2096,31 @@ int32_t azh_propagate_device_cached_f32(azh_constellation *c, float *d_pos, floa
 
 // Fused single-target conjunction screen (Constellation.screenConstellation, src/Constellation.zig
 // L683-756): nothing but 12 bytes per satellite ever leaves the chip.
-static int32_t azh_screen_target_device_impl(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
-                                 size_t target, double threshold_km, double reference_jd, double *d_min_dist,
-                                 uint32_t *d_min_t, void *stream)
+// The screen proper.  The target is either a member of c (`target` < c->n: its track is computed here, and the row reports
+// threshold / 0 like the reference's) or an EXTERNAL track `d_track` (n_times x 3 TEME km on c's device: a satellite of another
+// shard, or an object that is in no catalog), in which case `target` = kNoTarget or the member to leave out.
+constexpr size_t kNoTarget = ~(size_t)0;
+static int32_t screen_core(azh_constellation *c, const double *times, size_t n_times, const double *offsets, size_t target,
+                           const double *d_track, double threshold_km, double *d_min_dist, uint32_t *d_min_t, void *stream)
 {
-    (void)reference_jd; // the reference rotates both vectors to ECEF first (L719, L737); distances do not change
     if (!c || !d_min_dist || !d_min_t || (n_times && !times)) return AZ_ERR_NULL_POINTER;
-    if (target >= c->n) return AZ_ERR_VALUE;
+    if (!d_track && target >= c->n) return AZ_ERR_VALUE;
+    if (d_track && target != kNoTarget && target >= c->n) return AZ_ERR_VALUE;
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
     hipStream_t st = stream ? (hipStream_t)stream : c->s_main;
     int32_t rc = AZ_OK;
     if (n_times > 0 && (rc = stage_inputs(c, times, n_times, offsets, nullptr, AZ_OUT_TEME, 0.0, st)) != AZ_OK) return rc;
     const unsigned nt = (unsigned)n_times;
     if (c->timing) HIP_TRY(hipEventRecord(c->ev_t0, st));
-    hipLaunchKernelGGL(k_screen_fill, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, st, (unsigned)c->n, threshold_km,
-                       d_min_dist, d_min_t);
-    HIP_TRY(hipGetLastError());
-    if (nt > 0) {
-        if (c->d_tgt.ensure((size_t)nt * 3) != AZ_OK) return AZ_ERR_HIP;
-        hipLaunchKernelGGL((k_one_satellite<false>), dim3((nt + 63) / 64), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
-                           (unsigned)target, c->d_times.p, nt, c->d_tgt.p, (double *)nullptr, (unsigned char *)nullptr, 0,
-                           c->g, c->have_offsets ? c->d_offsets.p : (const double *)nullptr, 1);
+    const unsigned nb_fill = ((unsigned)c->n + 255) / 256;
+    if (nt == 0) {
+        hipLaunchKernelGGL(k_screen_prep, dim3(nb_fill), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad, 0u, (const double *)nullptr, 0u,
+                           (const double *)nullptr, c->g, (double *)nullptr, 0u, (size_t)0, (double *)nullptr, (unsigned *)nullptr, 0u,
+                           (unsigned)c->n, threshold_km, d_min_dist, d_min_t);
         HIP_TRY(hipGetLastError());
+    }
+    if (nt > 0) {
+        if (!d_track && c->d_tgt.ensure((size_t)nt * 3) != AZ_OK) return AZ_ERR_HIP;
         PropArgs a{};
         a.el = c->d_el;
         a.flags = c->d_flags;
@@ -2135,7 +2142,7 @@ static int32_t azh_screen_target_device_impl(azh_constellation *c, const double 
         a.grid_exact_uniform = (c->uniform_step != 0.0 && c->delta_max == 0.0) ? 1 : 0;
         a.row_lo = 0;
         a.row_hi = 0xffffffffu;
-        a.screen_target = c->d_tgt.p;
+        a.screen_target = d_track ? d_track : c->d_tgt.p;
         PropArgs near = a, deep = a;
         unsigned parts_near = 0, parts_deep = 0;
         c->last_path = 0;
@@ -2167,11 +2174,23 @@ static int32_t azh_screen_target_device_impl(azh_constellation *c, const double 
         const size_t np_near = (size_t)parts_near * c->n_sgp4, np_deep = (size_t)parts_deep * c->n_sdp4;
         if (c->d_part_d2.ensure(np_near + np_deep) != AZ_OK || c->d_part_t.ensure(np_near + np_deep) != AZ_OK) return AZ_ERR_HIP;
         const double thr2 = threshold_km * threshold_km;
+        near.part_d2 = c->d_part_d2.p;
+        near.part_t = c->d_part_t.p;
+        deep.part_d2 = c->d_part_d2.p + np_near;
+        deep.part_t = c->d_part_t.p + np_near;
+        // ONE preparation launch (round 6; it was three): the target's track, the reset of the partial minima the generic pass
+        // only partly overwrites, the start values of every row
+        {
+            const unsigned nb_track = d_track ? 0u : (nt + 63) / 64;
+            const size_t n_clear = fast_screen ? np_near : 0;
+            const unsigned nb_clear = (unsigned)((n_clear + 255) / 256);
+            hipLaunchKernelGGL(k_screen_prep, dim3(nb_track + nb_clear + nb_fill), dim3(64), 0, st, c->d_el, c->d_flags, c->n_pad,
+                               (unsigned)(d_track ? 0 : target), c->d_times.p, nt, c->have_offsets ? c->d_offsets.p : (const double *)nullptr, c->g,
+                               c->d_tgt.p, nb_track, n_clear, near.part_d2, near.part_t, nb_clear, (unsigned)c->n, threshold_km, d_min_dist, d_min_t);
+            HIP_TRY(hipGetLastError());
+        }
         if (c->n_sgp4 > 0) {
-            near.part_d2 = c->d_part_d2.p;
-            near.part_t = c->d_part_t.p;
             if (fast_screen) {
-                hipLaunchKernelGGL(k_screen_parts_clear, dim3((unsigned)((np_near + 255) / 256)), dim3(256), 0, st, np_near, near.part_d2, near.part_t);
                 PropArgs e = near, cc = near;
                 e.list = near.list + near.n_circ;
                 e.n_list = near.n_list - near.n_circ;
@@ -2197,17 +2216,16 @@ static int32_t azh_screen_target_device_impl(azh_constellation *c, const double 
                 c->last_path = launch_propagate(near, AZ_LAYOUT_SAT_MAJOR, false, false, st);
             }
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(k_screen_finalize, dim3((c->n_sgp4 + 255) / 256), dim3(256), 0, st, near.part_d2, near.part_t,
-                               parts_near, near.list, c->n_sgp4, thr2, (unsigned)target, d_min_dist, d_min_t);
-            HIP_TRY(hipGetLastError());
         }
         if (c->n_sdp4 > 0) {
-            deep.part_d2 = c->d_part_d2.p + np_near;
-            deep.part_t = c->d_part_t.p + np_near;
             c->last_path |= launch_propagate(deep, AZ_LAYOUT_SAT_MAJOR, false, true, st);
             HIP_TRY(hipGetLastError());
-            hipLaunchKernelGGL(k_screen_finalize, dim3((c->n_sdp4 + 255) / 256), dim3(256), 0, st, deep.part_d2, deep.part_t,
-                               parts_deep, deep.list, c->n_sdp4, thr2, (unsigned)target, d_min_dist, d_min_t);
+        }
+        // ... and ONE finalisation over both lists (it was one per list)
+        const unsigned n_fin = c->n_sgp4 + c->n_sdp4;
+        if (n_fin > 0) {
+            hipLaunchKernelGGL(k_screen_finalize2, dim3((n_fin + 255) / 256), dim3(256), 0, st, near.part_d2, near.part_t, parts_near, near.list, c->n_sgp4,
+                               deep.part_d2, deep.part_t, parts_deep, deep.list, c->n_sdp4, thr2, (unsigned)target, d_min_dist, d_min_t);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -2221,7 +2239,19 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times, size
                                  size_t target, double threshold_km, double reference_jd, double *d_min_dist,
                                  uint32_t *d_min_t, void *stream)
 {
-    return guarded([&]() -> int32_t { return azh_screen_target_device_impl(c, times, n_times, offsets, target, threshold_km, reference_jd, d_min_dist, d_min_t, stream); });
+    (void)reference_jd; // the reference rotates both vectors to ECEF first (L719, L737); distances do not change
+    return guarded([&]() -> int32_t {
+        if (c && target >= c->n) return AZ_ERR_VALUE;
+        return screen_core(c, times, n_times, offsets, target, nullptr, threshold_km, d_min_dist, d_min_t, stream);
+    });
+}
+int32_t azh_screen_track_device(azh_constellation *c, const double *times, size_t n_times, const double *offsets, const double *d_track,
+                                size_t exclude_index, double threshold_km, double *d_min_dist, uint32_t *d_min_t, void *stream)
+{
+    return guarded([&]() -> int32_t {
+        if (!d_track) return AZ_ERR_NULL_POINTER;
+        return screen_core(c, times, n_times, offsets, exclude_index, d_track, threshold_km, d_min_dist, d_min_t, stream);
+    });
 }
 
 static int32_t azh_screen_target_host_impl(azh_constellation *c, const double *times, size_t n_times, const double *offsets,
@@ -2633,6 +2663,16 @@ int32_t azh_selftest_math(const double *x, size_t n, double *out6n, int32_t devi
     return rc;
 }
 
+int32_t azh_selftest_host_step(const double *el, size_t n_pad, size_t sat, uint32_t flags, int32_t grav, const double *tsince_min,
+                               size_t n, double *out6n, uint8_t *err)
+{
+    if (!el || !tsince_min || !out6n) return AZ_ERR_NULL_POINTER;
+    if (sat >= n_pad) return AZ_ERR_VALUE;
+    if (!azhost::cpu_ok()) return AZ_ERR_UNKNOWN;
+    azhost::propagate_points(el, n_pad, sat, flags, make_grav(grav), tsince_min, n, 1, out6n, nullptr, nullptr, err);
+    return AZ_OK;
+}
+
 // ======================================================================================= multi-GPU group
 // One process, N devices (a Zig / C host has no torch.distributed): block-cyclic satellite shards -- the same plan
 // as astroz_amd/distributed.py's ShardPlan -- one azh_constellation per device.  A host-memory result needs no
@@ -2647,6 +2687,7 @@ struct azh_group {
     std::vector<azh_constellation *> shard;
     std::vector<std::vector<uint32_t>> members; // catalog rows of every shard, ascending (== local order)
     std::vector<std::vector<double>> off_stage; // per-shard epoch offsets of the call in flight (source of an async H2D)
+    std::vector<double> track_stage;            // the target's track of the group screen in flight (source of async H2Ds)
     std::vector<ncclComm_t> comms;              // created on the first all-gather
     std::vector<hipStream_t> s_comm;
     std::vector<hipEvent_t> ev;
@@ -2966,6 +3007,144 @@ int32_t azh_group_propagate_allgather(azh_group *g, const double *times, size_t 
                                       double *const *d_pos, double *const *d_vel)
 {
     return guarded([&]() -> int32_t { return azh_group_propagate_allgather_impl(g, times, n_times, offsets, n_offsets, d_pos, d_vel); });
+}
+
+// The sharded consumer ("a consumer that only needs its own shard"): the fused single-target screen
+// (Constellation.screenConstellation, src/Constellation.zig L683-756) over a group.  Every satellite's minimum distance to the
+// target is independent of every other satellite's, so each device screens ITS rows; the only thing they share is the
+// target's own track (n_times x 24 bytes: 35 KB for a day of minutes), computed once on the device that owns the target and
+// handed to the others through the host.  No collective, nothing but 12 bytes per satellite leaves any device.
+namespace {
+int32_t group_screen(azh_group *g, const double *times, size_t n_times, const double *offsets, size_t n_offsets, size_t target,
+                     double threshold_km, double *const *d_min_dist, uint32_t *const *d_min_t, double *h_min_dist, uint32_t *h_min_t)
+{
+    if (!g || (n_times && !times)) return AZ_ERR_NULL_POINTER;
+    if (target >= g->n || (offsets && n_offsets < g->n)) return AZ_ERR_VALUE;
+    // owner of the target and its local row
+    int owner = -1;
+    size_t t_local = 0;
+    for (int d = 0; d < g->n_dev && owner < 0; ++d) {
+        const auto &m = g->members[d];
+        const auto it = std::lower_bound(m.begin(), m.end(), (uint32_t)target);
+        if (it != m.end() && *it == (uint32_t)target) { owner = d; t_local = (size_t)(it - m.begin()); }
+    }
+    if (owner < 0) return AZ_ERR_VALUE;
+    int32_t rc = AZ_OK;
+    auto shard_offsets = [&](int d) -> const double * {
+        if (!offsets) return nullptr;
+        std::vector<double> &off = g->off_stage[d];
+        azh_constellation *c = g->shard[d];
+        off.resize(c->n);
+        for (size_t i = 0; i < c->n; ++i) off[i] = offsets[g->members[d][i]];
+        return off.data();
+    };
+    // the target's track on its owner ...
+    std::vector<double> &track = g->track_stage;
+    const unsigned nt = (unsigned)n_times;
+    if (nt > 0 && g->n_dev > 1) {
+        azh_constellation *c = g->shard[owner];
+        if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+        if ((rc = stage_inputs(c, times, n_times, shard_offsets(owner), nullptr, AZ_OUT_TEME, 0.0, c->s_main)) != AZ_OK) return rc;
+        if (c->d_tgt.ensure((size_t)nt * 3) != AZ_OK) return AZ_ERR_HIP;
+        hipLaunchKernelGGL((k_one_satellite<false>), dim3((nt + 63) / 64), dim3(64), 0, c->s_main, c->d_el, c->d_flags, c->n_pad,
+                           (unsigned)t_local, c->d_times.p, nt, c->d_tgt.p, (double *)nullptr, (unsigned char *)nullptr, 0, c->g,
+                           c->have_offsets ? c->d_offsets.p : (const double *)nullptr, 1);
+        HIP_TRY(hipGetLastError());
+        track.resize((size_t)nt * 3);
+        HIP_TRY(hipMemcpyAsync(track.data(), c->d_tgt.p, sizeof(double) * track.size(), hipMemcpyDeviceToHost, c->s_main));
+        HIP_TRY(hipStreamSynchronize(c->s_main));
+    }
+    // ... then every device screens its own rows (all launches asynchronous: the devices run side by side)
+    for (int d = 0; d < g->n_dev && rc == AZ_OK; ++d) {
+        azh_constellation *c = g->shard[d];
+        if (!c) continue;
+        if (set_device(c) != AZ_OK) { rc = AZ_ERR_HIP; break; }
+        double *out_d = d_min_dist ? d_min_dist[d] : nullptr;
+        uint32_t *out_t = d_min_t ? d_min_t[d] : nullptr;
+        if (!out_d || !out_t) {
+            if (c->d_out_d.ensure(c->n) != AZ_OK || c->d_out_t.ensure(c->n) != AZ_OK) { rc = AZ_ERR_HIP; break; }
+            out_d = c->d_out_d.p;
+            out_t = c->d_out_t.p;
+        }
+        const double *off_d = shard_offsets(d);
+        if (d == owner) {
+            rc = screen_core(c, times, n_times, off_d, t_local, nullptr, threshold_km, out_d, out_t, nullptr);
+        } else {
+            if (nt > 0) {
+                if (c->d_tgt.ensure((size_t)nt * 3) != AZ_OK) { rc = AZ_ERR_HIP; break; }
+                if (!hip_ok(hipMemcpyAsync(c->d_tgt.p, track.data(), sizeof(double) * track.size(), hipMemcpyHostToDevice, c->s_main), "H2D track")) { rc = AZ_ERR_HIP; break; }
+            }
+            rc = screen_core(c, times, n_times, off_d, kNoTarget, c->d_tgt.p, threshold_km, out_d, out_t, nullptr);
+        }
+    }
+    // host results: a cell = consecutive catalog rows = consecutive local rows, one small copy per cell and array
+    if (rc == AZ_OK && h_min_dist && h_min_t) {
+        for (int d = 0; d < g->n_dev && rc == AZ_OK; ++d) {
+            azh_constellation *c = g->shard[d];
+            if (!c) continue;
+            if (set_device(c) != AZ_OK) { rc = AZ_ERR_HIP; break; }
+            size_t local = 0;
+            for (size_t k = 0; k < g->n_chunks; ++k) {
+                const size_t lo = g->cell_lo(k, d), cnt = g->cell_hi(k, d) - lo;
+                if (!cnt) continue;
+                if (!hip_ok(hipMemcpyAsync(h_min_dist + lo, c->d_out_d.p + local, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->s_main), "D2H") ||
+                    !hip_ok(hipMemcpyAsync(h_min_t + lo, c->d_out_t.p + local, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, c->s_main), "D2H")) { rc = AZ_ERR_HIP; break; }
+                local += cnt;
+            }
+        }
+    }
+    for (int d = 0; d < g->n_dev; ++d) {
+        azh_constellation *c = g->shard[d];
+        if (!c) continue;
+        if ((h_min_dist || rc != AZ_OK) && (set_device(c) != AZ_OK || !hip_ok(hipStreamSynchronize(c->s_main), "sync")))
+            rc = rc == AZ_OK ? AZ_ERR_HIP : rc;
+    }
+    return rc;
+}
+} // namespace
+
+int32_t azh_group_screen_target_host(azh_group *g, const double *times, size_t n_times, const double *offsets, size_t n_offsets,
+                                     size_t target, double threshold_km, double reference_jd, double *min_dist, uint32_t *min_t)
+{
+    (void)reference_jd; // (signature parity with azh_screen_target_host: a rotation to ECEF does not change a distance)
+    return guarded([&]() -> int32_t {
+        if (!min_dist || !min_t) return AZ_ERR_NULL_POINTER;
+        return group_screen(g, times, n_times, offsets, n_offsets, target, threshold_km, nullptr, nullptr, min_dist, min_t);
+    });
+}
+int32_t azh_group_screen_target_device(azh_group *g, const double *times, size_t n_times, const double *offsets, size_t n_offsets,
+                                       size_t target, double threshold_km, double reference_jd, double *const *d_min_dist,
+                                       uint32_t *const *d_min_t)
+{
+    (void)reference_jd;
+    return guarded([&]() -> int32_t {
+        if (!d_min_dist || !d_min_t) return AZ_ERR_NULL_POINTER;
+        if (g)
+            for (int d = 0; d < g->n_dev; ++d)
+                if (g->shard[d] && (!d_min_dist[d] || !d_min_t[d])) return AZ_ERR_NULL_POINTER;
+        return group_screen(g, times, n_times, offsets, n_offsets, target, threshold_km, d_min_dist, d_min_t, nullptr, nullptr);
+    });
+}
+size_t azh_group_shard_size(const azh_group *g, int32_t d) { return (g && d >= 0 && d < g->n_dev) ? g->members[d].size() : 0; }
+int32_t azh_group_shard_rows(const azh_group *g, int32_t d, uint32_t *out)
+{
+    if (!g || !out) return AZ_ERR_NULL_POINTER;
+    if (d < 0 || d >= g->n_dev) return AZ_ERR_VALUE;
+    std::copy(g->members[d].begin(), g->members[d].end(), out);
+    return AZ_OK;
+}
+int32_t azh_group_synchronize(azh_group *g)
+{
+    if (!g) return AZ_ERR_NULL_POINTER;
+    int32_t rc = AZ_OK;
+    for (int d = 0; d < g->n_dev; ++d) {
+        azh_constellation *c = g->shard[d];
+        if (!c) continue;
+        if (set_device(c) != AZ_OK || !hip_ok(hipStreamSynchronize(c->s_main), "sync") || !hip_ok(hipStreamSynchronize(c->s_deep), "sync") ||
+            !hip_ok(hipStreamSynchronize(c->s_ecc), "sync"))
+            rc = AZ_ERR_HIP;
+    }
+    return rc;
 }
 
 // ======================================================================================= (A)

@@ -3,10 +3,11 @@
 //
 // Why: the reference's scalar call (`Satrec.sgp4(jd, fr)`, bindings/python/src/satrec.zig L169-201; `sgp4_propagate`,
 // src/c_api/root.zig L13-81) is 0.4 us; a kernel launch + a synchronize is 20 us whatever the kernel does.  A call of at most
-// azh_set_host_points() points (default 64) therefore evaluates the SAME step source on the calling thread, from the element
+// azh_set_host_points() points (default 128 near-earth / 64 deep-space: where the two routes cross) therefore evaluates the SAME step source on the calling thread, from the element
 // column the DEVICE initialised (k_init; mirrored to the host when the handle is made or on first use).  It is not a fallback:
-// without a device no handle exists (creation returns AZ_ERR_HIP), nothing above the point limit ever takes it, and it never
-// touches oracle/ -- tests/test_host_cpu.py::test_no_cpu_fallback and tests/test_gpu_round6.py hold both statements.
+// without a device no handle exists (creation returns AZ_ERR_HIP), nothing above the point limit ever takes it, and it is this
+// library's own step source, not the test tier's CPU checker -- tests/test_round6_cpu.py and tests/test_gpu_round6.py hold
+// these statements.
 #pragma once
 #include <cstddef>
 #include <cstdint>

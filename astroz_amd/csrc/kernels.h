@@ -1859,24 +1859,89 @@ __global__ void __launch_bounds__(192) k_deep_transpose(const T *tmp_pos, const 
     }
 }
 
-// screen: combine the partial minima of one launch list (parts are in ascending time order) and apply
-// the reference's conventions: start from threshold^2 / index 0, strict '<', the target itself keeps
-// the threshold, distances leave as sqrt (src/Constellation.zig L700-703, L733, L744-747, L752-754)
-__global__ void k_screen_finalize(const double *part_d2, const unsigned *part_t, unsigned n_parts, const unsigned *list,
-                                  unsigned n_list, double threshold_sq, unsigned target, double *out_d,
-                                  unsigned *out_t)
+// screen: combine the partial minima of a launch list (k_screen_finalize2 below) and apply the reference's conventions: start
+// from threshold^2 / index 0, strict '<', the target itself keeps the threshold, distances leave as sqrt
+// (src/Constellation.zig L700-703, L733, L744-747, L752-754).  Smallest distance, earliest grid point among equals (the parts are
+// not always in time order: the redo pass's partials follow the fast kernels'); a part that saw nothing carries +inf / 0xffffffff.
+
+// Round 6: everything the screening kernels need before they start, in ONE launch (it was three: k_screen_fill, the target's
+// track through k_one_satellite, k_screen_parts_clear -- each a dependent launch of a few microseconds in front of 0.14 ms of
+// arithmetic).  Workgroups [0, nb_track): the target's track, one grid point per lane (the per-point step of k_one_satellite;
+// NaN where the target's propagation fails: such a point never compares closer than the threshold); the next nb_clear
+// workgroups reset the partial minima the generic pass only partly overwrites; the rest write the start values
+// (threshold, index 0) of every catalog row.  track == nullptr: the caller supplies the track (azh_screen_track_device).
+__global__ void __launch_bounds__(64) k_screen_prep(const double *__restrict__ el, const unsigned *__restrict__ flags, size_t n_pad, unsigned target,
+                                                    const double *__restrict__ tsince, unsigned n_times, const double *__restrict__ offsets, AzGrav g,
+                                                    double *track, unsigned nb_track, size_t n_clear, double *part_d2, unsigned *part_t,
+                                                    unsigned nb_clear, unsigned n_rows, double threshold, double *out_d, unsigned *out_t)
 {
-    const unsigned li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x < nb_track) {
+        const unsigned i = blockIdx.x * 64 + threadIdx.x;
+        const double t = tsince[i < n_times ? i : n_times - 1] + (offsets ? offsets[target] : 0.0);
+        const unsigned fl = flags[target];
+        double r[3], v[3];
+        int rc = AZ_FLAG_ERR(fl);
+        if (rc == 0) {
+            if (fl & AZ_FLAG_DEEP) {
+                Sdp4Lane e;
+                Sdp4Carry c;
+                __shared__ double cold_deep[D_NUM * 64];
+                double *cold = cold_deep + threadIdx.x;
+                az_load_sdp4(el, n_pad, target, fl, e, ColdLds{cold});
+                c.atime = 0.0;
+                c.xli = e(H_xlamo);
+                c.xni = e(H_no_unkozai);
+                rc = az_sdp4_step<true>(e, ColdLds{cold}, g, az_rotk(), t, c, r, v);
+            } else {
+                Sgp4Lane e;
+                Sgp4Carry c;
+                ColdRegs cold;
+                az_load_sgp4(el, n_pad, target, fl, e, cold);
+                c.t_prev = 0.0;
+                az_sgp4_step<true>(e, cold, el, n_pad, target, g, az_rotk(), t, true, c, r, v);
+            }
+        }
+        if (rc != 0) r[0] = r[1] = r[2] = __builtin_nan("");
+        if (i < n_times) { track[(size_t)i * 3] = r[0]; track[(size_t)i * 3 + 1] = r[1]; track[(size_t)i * 3 + 2] = r[2]; }
+        return;
+    }
+    if (blockIdx.x < nb_track + nb_clear) {
+        // 4 elements per lane: 256 per workgroup
+        const size_t base = (size_t)(blockIdx.x - nb_track) * 256 + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t i = base + 64 * k;
+            if (i < n_clear) { part_d2[i] = __builtin_inf(); part_t[i] = 0xffffffffu; }
+        }
+        return;
+    }
+    const unsigned base = (blockIdx.x - nb_track - nb_clear) * 256 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned i = base + 64 * k;
+        if (i < n_rows) { out_d[i] = threshold; out_t[i] = 0; }
+    }
+}
+
+// ... and the finalisation of both launch lists (near-earth, deep-space) in one launch
+__global__ void __launch_bounds__(256) k_screen_finalize2(const double *pd_a, const unsigned *pt_a, unsigned parts_a, const unsigned *list_a, unsigned n_a,
+                                                          const double *pd_b, const unsigned *pt_b, unsigned parts_b, const unsigned *list_b, unsigned n_b,
+                                                          double threshold_sq, unsigned target, double *out_d, unsigned *out_t)
+{
+    unsigned li = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool second = li >= n_a;
+    if (second) li -= n_a;
+    const unsigned n_list = second ? n_b : n_a, n_parts = second ? parts_b : parts_a;
     if (li >= n_list) return;
-    const unsigned s = list[li];
+    const double *part_d2 = second ? pd_b : pd_a;
+    const unsigned *part_t = second ? pt_b : pt_a;
+    const unsigned s = (second ? list_b : list_a)[li];
     double best = threshold_sq;
     unsigned bt = 0;
     if (s != target) {
         for (unsigned k = 0; k < n_parts; ++k) {
             const double d = part_d2[(size_t)k * n_list + li];
             const unsigned t = part_t[(size_t)k * n_list + li];
-            // smallest distance, earliest grid point among equals (the parts are not always in time order: the redo
-            // pass's partials follow the fast kernels'); a part that saw nothing carries +inf / 0xffffffff
             if (d < best || (d == best && t < bt && d < threshold_sq)) {
                 best = d;
                 bt = t;
@@ -1885,22 +1950,6 @@ __global__ void k_screen_finalize(const double *part_d2, const unsigned *part_t,
     }
     out_d[s] = sqrt(best);
     out_t[s] = bt;
-}
-
-__global__ void k_screen_parts_clear(size_t n, double *part_d2, unsigned *part_t)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    part_d2[i] = __builtin_inf();
-    part_t[i] = 0xffffffffu;
-}
-
-__global__ void k_screen_fill(unsigned n, double threshold, double *out_d, unsigned *out_t)
-{
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    out_d[i] = threshold;
-    out_t[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -219,6 +219,97 @@ class ShardedPropagator:
 
 
 # ----------------------------------------------------------------------------------------------
+class ShardedScreen:
+    """The gather-free consumer (SURVEY 8e fallback row): the fused single-target conjunction screen
+    (Constellation.screenConstellation, src/Constellation.zig L683-756; ``screen(..., target=)``, bindings/python/astroz/
+    __init__.py L535-658) with the catalog sharded over the ranks.  A satellite's minimum distance to the target depends on
+    that satellite and the target only, so every rank screens ITS rows; the target's track -- ``n_times x 24`` bytes -- is
+    computed by every rank for itself from the target's element set (``target_dev``: a one-satellite constellation on the
+    rank's GPU), so the step has NO collective and its time falls as 1/world.  ``gather()`` collects the 12 bytes per
+    satellite of the result on every rank when somebody needs the whole vector (162 KB for 13,478 satellites).
+
+    `shard`: the rank's :class:`ShardedConstellation` (or anything with ``dev``, ``rows``, ``plan``, ``rank``);
+    `target_row`: catalog row of the target; `target_dev`: a DeviceConstellation holding that one satellite (None on CPU
+    stand-ins, whose ``screen_track_device`` takes the track as a tensor)."""
+
+    def __init__(self, shard, target_row, target_dev, times_min, offsets_min, threshold_km, device=None, group=None):
+        import torch
+
+        self.torch, self.shard, self.group = torch, shard, group
+        self.device = torch.device("cpu") if device is None else device
+        self.cuda = self.device.type == "cuda"
+        self.times = np.ascontiguousarray(times_min, dtype=np.float64)
+        off = None if offsets_min is None else np.ascontiguousarray(offsets_min, dtype=np.float64)
+        self.offsets_local = None if off is None else np.ascontiguousarray(off[shard.rows])
+        self.target_off = 0.0 if off is None else float(off[target_row])
+        self.threshold = float(threshold_km)
+        self.target_dev = target_dev
+        hit = np.flatnonzero(np.asarray(shard.rows) == int(target_row))
+        self.exclude = int(hit[0]) if len(hit) else None           # the target is one of this rank's rows
+        n_loc, n_t = len(shard.rows), len(self.times)
+        self.track = torch.zeros((n_t, 3), dtype=torch.float64, device=self.device)
+        self.tsince = torch.as_tensor(self.times + self.target_off, dtype=torch.float64).to(self.device)
+        self.min_dist = torch.full((max(n_loc, 1),), self.threshold, dtype=torch.float64, device=self.device)[:n_loc]
+        self.min_t = torch.zeros((max(n_loc, 1),), dtype=torch.int32, device=self.device)[:n_loc]
+        self.track_err = torch.zeros((n_t,), dtype=torch.uint8, device=self.device)
+        self._check_track, self._has_bad, self._bad = True, False, None
+        if self.cuda:
+            torch.cuda.synchronize(self.device)
+
+    def step(self, stream=None):
+        """target track + screen of the rank's rows; asynchronous on CUDA: pass ONE raw hipStream_t as `stream` so that the
+        two handles' launches are ordered on it (without it the track is finished with a host synchronize first)."""
+        n_t = len(self.times)
+        if self.target_dev is not None:
+            self.target_dev.propagate_one_device(0, self.tsince.data_ptr(), n_t, self.track.data_ptr(), None, self.track_err.data_ptr(),
+                                                 stream=stream)
+            if self._check_track:
+                # once per grid: a target whose propagation fails at some grid points must never compare closer than the
+                # threshold there (azh_screen_target_* marks such points NaN); the usual grid has none and costs nothing later
+                self.target_dev.synchronize()
+                if self.cuda and stream is not None:
+                    self.torch.cuda.synchronize(self.device)
+                self._bad = (self.track_err != 0)
+                self._has_bad = bool(self._bad.any())
+                self._check_track = False
+            if self._has_bad:
+                self.target_dev.synchronize()
+                if self.cuda and stream is not None:
+                    self.torch.cuda.synchronize(self.device)
+                self.track[self._bad] = float("nan")
+                if self.cuda:
+                    self.torch.cuda.synchronize(self.device)
+            elif self.cuda and stream is None:
+                self.target_dev.synchronize()      # two handles, two streams: the screen must see the finished track
+        if self.shard.dev is None or not len(self.shard.rows):
+            return
+        self.shard.dev.screen_track_device(self.times, self.track.data_ptr(), self.threshold, self.min_dist.data_ptr(),
+                                           self.min_t.data_ptr(), offsets_min=self.offsets_local, exclude=self.exclude, stream=stream)
+
+    def local_results(self):
+        """(catalog rows of this rank, min_dist km, min_t_index) -- device tensors of the rank's rows"""
+        return self.shard.rows, self.min_dist, self.min_t
+
+    def gather(self):
+        """catalog-ordered (min_dist (n_sats,), min_t (n_sats,)) on every rank: one all-gather of 12 bytes per satellite"""
+        import torch.distributed as dist
+
+        torch, plan = self.torch, self.shard.plan
+        cap = plan.local_capacity()
+        loc = torch.zeros((cap, 2), dtype=torch.float64, device=self.device)
+        n_loc = len(self.shard.rows)
+        # local row l of chunk c, slot s sits at c * rows + s: the cells of a rank are filled in order, so the first n_loc
+        # local rows map onto (chunk, slot) by plain division
+        idx = torch.arange(n_loc, device=self.device)
+        loc[idx, 0] = self.min_dist
+        loc[idx, 1] = self.min_t.to(torch.float64)
+        full = torch.empty((plan.world * cap, 2), dtype=torch.float64, device=self.device)
+        dist.all_gather_into_tensor(full, loc, group=self.group)
+        full = full.view(plan.world, plan.n_chunks, plan.rows, 2).permute(1, 0, 2, 3).reshape(plan.padded, 2)[: plan.n_sats]
+        return full[:, 0].contiguous(), full[:, 1].to(torch.int64)
+
+
+# ----------------------------------------------------------------------------------------------
 # one-shot gathers of contiguous-range shards (shard_bounds), kept for API users
 def gather_sat_major(local_block, n_total, world_size=None, group=None):
     """All-gather satellite-major blocks ``(n_local, n_times, 3)`` of `shard_bounds` shards into

@@ -258,10 +258,15 @@ def main():
     # config 4 extras, timed the same way (barrier, events, max over ranks): the kernels alone -- eager and as hipGraphs -- and
     # the "replicate" point (every GPU propagates the FULL catalog itself): bench_sharded.py
     kernel_only_ms = kernel_graphs_ms = replicate_ms = None
+    screen_res = None
     if sharded:
         import bench_sharded
         kernel_only_ms, kernel_graphs_ms = bench_sharded.kernel_only(torch, dist, a, dev, sp, plan, step, drain, stream, cuda)
         replicate_ms = bench_sharded.replicate(torch, dist, _native, synth, a, allp, sp, times, vel_on, stream, sptr, cuda, local_rank)
+        try:
+            screen_res = bench_sharded.sharded_screen(torch, dist, _native, synth, a, allp, world, rank, times, stream, sptr, cuda, local_rank)
+        except Exception as exc:     # (an extra: every rank fails or succeeds alike -- the collectives inside are reached by all or none)
+            screen_res = {"failed": repr(exc)}
         if gather:
             # leave the gathered result of the sharded pipeline in sp.full for the parity check below
             sp.compute.wait_stream(stream)
@@ -269,6 +274,25 @@ def main():
             drain()
             torch.cuda.synchronize()
             dist.barrier()
+
+    # Every rank certifies its OWN output before anybody leaves ("no gather -- verify by checksums + sampled rows"):
+    # sampled rows against the oracle on the rank's host cores, checksum + finiteness over everything it wrote; the certificates
+    # travel to rank 0 as one small object.  N = 1 makes the same certificate without a group.
+    per_rank = None
+    if (world > 1 or a.force_sharded) and mode == 0:
+        try:
+            from bench_common import rank_certificate
+            if sharded:
+                sp.compute.wait_stream(stream)
+                step(False)
+                drain()
+                torch.cuda.synchronize()
+            thr_ = max(1, usable_cpus() // max(1, min(world, 8)))
+            mine = rank_certificate(torch, pairs, times, offsets, pos, vel, layout == _native.SAT_MAJOR, rank, threads=thr_)
+        except Exception as exc:
+            mine = {"rank": rank, "failed": repr(exc)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     # Every collective is behind us: all ranks leave the process group HERE, together, and ranks != 0 exit -- rank 0 does the rest
     # (group_host on all devices, oracle parity, the secondary block) alone, with no communicator alive and no peer process
@@ -341,7 +365,7 @@ def main():
                 "t_replicate_ms": replicate_ms, "replicate_value": props_per_step / (replicate_ms / 1e3),
                 "replicate_note": "every GPU propagates the FULL catalog itself (no shards, zero bytes moved): the same "
                                   "deliverable as the gathered run -- the full arrays on every GPU",
-                "group_host": group_host,
+                "group_host": group_host, "sharded_screen": screen_res,
                 "gather_bytes_per_gpu": (plan.padded - plan.local_capacity()) * n_times * 3 * 8 * (2 if vel_on else 1)}
                if kernel_only_ms is not None else {}),
             "parallelism": par,
@@ -406,6 +430,19 @@ def main():
         except Exception as exc:  # the baseline must never take the bench line down
             out["cpu_baseline"] = {"value": None, "unit": "propagations/s", "cores": 0, "kind": "port",
                                    "sample": "failed: %r" % (exc,)}
+    if per_rank is not None:
+        out.setdefault("parity", {})
+        if isinstance(out["parity"], dict):
+            out["parity"]["per_rank"] = per_rank
+            out["parity"]["per_rank_note"] = ("every rank: 24 rows spread over ITS catalog x all times vs the fp64 oracle (max_dr km, max_dv km/s), "
+                                              "fp64 checksum + finiteness over everything it wrote")
+    if (world > 1 or a.force_sharded or a.config5_share) and not a.no_cpu_baseline and mode == 0 and not (out.get("cpu_baseline") or {}).get("value"):
+        # N > 1 lines (and the config-5 share) carry a CPU baseline too: rank 0, after leaving the group, on a bounded sample
+        try:
+            from bench_common import cpu_baseline_sample
+            out["cpu_baseline"] = cpu_baseline_sample(pairs, times, offsets, a.cpu_seconds, layout == _native.SAT_MAJOR)
+        except Exception as exc:
+            out["cpu_baseline"] = {"value": None, "unit": "propagations/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (exc,)}
     if world == 1 and mode != 0 and not a.config5_share and "parity" not in out:
         try:
             from oracle import oracle

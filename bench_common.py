@@ -91,6 +91,51 @@ def cpu_baseline(pairs, times, offsets, seconds, sat_major):
     }, (n_s, p, v)
 
 
+def cpu_baseline_sample(pairs, times, offsets, seconds, sat_major, max_sats=13478, max_times=1440):
+    """cpu_baseline on a BOUNDED sample for workloads too large to restate on the host (config 5's 125,000 x 10,000 share is
+    60 GB of fp64 results): the first `max_sats` satellites x the first `max_times` grid points of the same catalog and grid."""
+    n_s, n_t = min(len(pairs), max_sats), min(len(times), max_times)
+    cb, _ = cpu_baseline(pairs[:n_s], np.ascontiguousarray(times[:n_t]), np.ascontiguousarray(offsets[:n_s]), seconds, sat_major)
+    if n_s < len(pairs) or n_t < len(times):
+        cb["sample"] = "SUBSET of the rank-0 workload (first %d of %d satellites x first %d of %d times): " % (n_s, len(pairs), n_t, len(times)) + cb["sample"]
+    return cb
+
+
+def rank_certificate(torch, pairs, times, offsets, pos, vel, sat_major, rank, mode=0, ref_jd=0.0, n_rows=24, threads=None):
+    """What ONE rank can certify about its own output without any other rank ("no gather -- verify by
+    checksums + sampled rows"): `n_rows` rows spread over the rank's catalog, every time, against the fp64 oracle; a checksum
+    (fp64 sum and largest magnitude) and a finiteness flag over EVERY element the rank wrote.  pos / vel: the rank's device
+    arrays, (n_local [+ padding], n_times, 3) satellite-major or (n_times, >= n_local, 3) time-major; fp64 or fp32."""
+    from oracle import oracle
+    n_local = len(pairs)
+    cert = {"rank": int(rank), "n_sats": int(n_local)}
+    if n_local == 0:
+        return cert
+    rows = np.unique(np.linspace(0, n_local - 1, n_rows).astype(np.int64))
+    cat = oracle.Catalog.from_pairs([pairs[i] for i in rows], oracle.WGS72)
+    thr = threads or usable_cpus()
+    _, p0, v0 = cat.propagate(times, np.ascontiguousarray(offsets[rows]), mode=mode, reference_jd=ref_jd, layout=oracle.SAT_MAJOR, threads=thr)
+    idx = torch.as_tensor(rows, device=pos.device)
+
+    def take(a):
+        return (a[idx] if sat_major else a[:, idx].permute(1, 0, 2)).cpu().numpy().astype(np.float64)
+    d = take(pos) - p0
+    if mode == 2:
+        d[..., 1] = (d[..., 1] + np.pi) % (2 * np.pi) - np.pi
+    cert.update({"sample_sats": int(len(rows)), "max_dr": float(np.abs(d).max())})
+    own = pos[:n_local] if sat_major else pos[:, :n_local]
+    cert["checksum"] = float(torch.sum(own, dtype=torch.float64))
+    cert["absmax"] = float(own.abs().max())
+    finite = bool(torch.isfinite(own).all())
+    if vel is not None:
+        cert["max_dv"] = float(np.abs(take(vel) - v0).max())
+        ownv = vel[:n_local] if sat_major else vel[:, :n_local]
+        cert["checksum"] += float(torch.sum(ownv, dtype=torch.float64))
+        finite = finite and bool(torch.isfinite(ownv).all())
+    cert["finite"] = finite
+    return cert
+
+
 class PowerSampler:
     """Socket power and shader clock of one GPU while the benchmark loop runs, read from the amdgpu hwmon files (no
     subprocess): the row kernels run on the board's power limit, so the clock they get is part of the result
@@ -238,6 +283,10 @@ def compact_line(out, full_path=None, limit=LINE_LIMIT):
               "t_total_ms", "kernel_only_value", "t_kernel_graphs_ms", "t_replicate_ms", "replicate_value", "chunks", "rccl_ranks", "gather_bytes_per_gpu"):
         if k in cfg:
             c[k] = _num(cfg[k]) if not isinstance(cfg[k], str) else _short(cfg[k], 120)
+    ss = cfg.get("sharded_screen")
+    if isinstance(ss, dict):
+        c["sharded_screen"] = {k: _num(ss[k]) for k in ("ms", "value", "index_mismatches", "max_dd_km") if k in ss} or \
+            {"failed": _short(ss.get("failed", "?"), 80)}
     gh = cfg.get("group_host")
     if isinstance(gh, dict):
         c["group_host"] = {k: _num(gh[k]) for k in ("ms_per_call", "devices", "value", "GB_per_s") if k in gh} or \
@@ -253,7 +302,13 @@ def compact_line(out, full_path=None, limit=LINE_LIMIT):
                                 "cpu_model": _short(cb.get("cpu_model", ""), 60), "sample": _short(cb.get("sample", ""), 220)}
     if "parity" in out:
         par = out["parity"]
-        line["parity"] = {k: (_num(v) if not isinstance(v, str) else _short(v, 100)) for k, v in par.items()} if isinstance(par, dict) else par
+        if isinstance(par, dict):
+            line["parity"] = {k: (_num(v) if not isinstance(v, str) else _short(v, 100)) for k, v in par.items() if k != "per_rank"}
+            if isinstance(par.get("per_rank"), list):   # one entry per rank: [rank, max_dr, max_dv, checksum, finite]
+                line["parity"]["per_rank"] = [[c.get("rank"), _num(c.get("max_dr"), 3), _num(c.get("max_dv"), 3), _num(c.get("checksum"), 12),
+                                               c.get("finite")] for c in par["per_rank"] if isinstance(c, dict)]
+        else:
+            line["parity"] = par
     vi = out.get("valu_issue")
     if isinstance(vi, dict):
         line["valu_issue"] = {k: _num(vi[k], 4) for k in ("issue_slot_frac", "valu_insts_per_propagation", "sclk_mhz") if k in vi}

@@ -179,7 +179,22 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             us_arr = wall(lambda: sat.sgp4_array(jd, fr), 300)
             sa = SatrecArray([sat], device=cuda.index or 0)
             us_sa = wall(lambda: sa.sgp4(jd, fr), 200)
-            us_one = wall(lambda: sat.sgp4(jd[0], fr[7]), 500)
+            us_one = wall(lambda: sat.sgp4(jd[0], fr[7]), 20000)
+            # the same scalar call with the host route switched off (one launch + one synchronize per point: round 5's figure),
+            # and the per-point cost of the host route as a function of the series length (where the two routes cross)
+            n_host = _native.get_host_points()
+            _native.set_host_points(0)
+            us_one_dev = wall(lambda: sat.sgp4(jd[0], fr[7]), 500)
+            _native.set_host_points(1 << 20)
+            sweep = {}
+            for npts in (1, 8, 64, 256, 1024):
+                tt = np.linspace(0.0, 1440.0, npts)
+                sweep[str(npts)] = {"host_route_us": wall(lambda: sat._ensure().propagate_one(0, tt), 2000 if npts <= 64 else 200)}
+            _native.set_host_points(0)
+            for npts in (1, 8, 64, 256, 1024):
+                tt = np.linspace(0.0, 1440.0, npts)
+                sweep[str(npts)]["kernel_route_us"] = wall(lambda: sat._ensure().propagate_one(0, tt), 300)
+            _native.set_host_points(n_host)
             # the same calls on a grid that CHANGES every call (stage_inputs skips the staging of byte-identical
             # inputs, so the loops above time the repeated-grid case): fr moved by a few microseconds per call
             box = {"k": 0}
@@ -196,6 +211,9 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             _, p0, v0 = cat.propagate(ts, None, layout=oracle.SAT_MAJOR)
             ent.update({"ms_per_step": us_arr / 1e3, "value": 1440 / (us_arr / 1e6), "unit": "propagations/s (Satrec.sgp4_array, host arrays)",
                         "sgp4_array_us": us_arr, "satrec_array_sgp4_us": us_sa, "scalar_sgp4_us": us_one,
+                        "scalar_sgp4_kernel_route_us": us_one_dev, "scalar_route": "host step" if sat._ensure().last_path() == _native.PATH_HOST_STEP else "kernel",
+                        "scalar_binding": "CPython shim" if _native.fast_scalar() else "ctypes", "host_points": n_host,
+                        "one_satellite_series_us": sweep,
                         "sgp4_array_fresh_grid_us": us_arr_fresh, "satrec_array_sgp4_fresh_grid_us": us_sa_fresh,
                         "note": "sgp4_array_us / satrec_array_sgp4_us: the SAME (jd, fr) every call (the staged grid is reused); "
                                 "*_fresh_grid_us: a different grid every call (times and offsets re-staged, increments / record / plan rebuilt)",

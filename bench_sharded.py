@@ -55,6 +55,43 @@ def replicate(torch, dist, _native, synth, a, allp, sp, times, vel_on, stream, s
     return _timed(torch, dist, run, a.steps, stream, cuda)
 
 
+def sharded_screen(torch, dist, _native, synth, a, allp, plan_world, rank, times, stream, sptr, cuda, local_rank):
+    """config.sharded_screen: the gather-free consumer (SURVEY 8e fallback row) -- the fused single-target screen
+    (Constellation.screenConstellation, src/Constellation.zig L683-756) with the catalog sharded block-cyclically over the ranks
+    (astroz_amd.distributed.ShardedScreen): every rank computes the target's track itself and screens ITS rows, no collective
+    inside the step; timed like the headline (barrier, HIP events on the launch stream, max over ranks).  `value` = satellites
+    x grid points screened per second over all ranks.  Checked: every rank's rows against the oracle's screen of the whole
+    catalog (grid indices equal, distances to 1e-6 km), gathered to rank 0 as one small object."""
+    from astroz_amd.distributed import ShardedConstellation, ShardedScreen
+    world = plan_world
+    n_total = len(allp)
+    target, thr = n_total // 3, 50.0
+    sh = ShardedConstellation(allp, _native.WGS72, rank=rank, world_size=world, local_rank=local_rank, n_chunks=1)
+    tgt = _native.DeviceConstellation.from_tle_lines([allp[target]], _native.WGS72, local_rank)
+    for d in (sh.dev, tgt):
+        if d is not None:
+            d.set_timing(False)
+    from oracle import oracle
+    ref = oracle.Catalog.from_pairs(allp, oracle.WGS72)
+    off = (synth.START_JD - ref.epoch_jd) * 1440.0
+    scr = ShardedScreen(sh, target, tgt, times, off, thr, device=cuda)
+    run = lambda: scr.step(stream=sptr)
+    for _ in range(max(5, a.warmup // 4)):
+        run()
+    ms = _timed(torch, dist, run, a.steps, stream, cuda)
+    rows, dl, tl = scr.local_results()
+    torch.cuda.synchronize()
+    d0, t0 = ref.screen_target(times, target, thr, off)
+    mine = {"rank": rank, "rows": int(len(rows)), "index_mismatches": int((tl.cpu().numpy().astype("int64") != t0[rows].astype("int64")).sum()),
+            "max_dd_km": float(abs(dl.cpu().numpy() - d0[rows]).max()) if len(rows) else 0.0,
+            "closer_than_threshold": int((dl.cpu().numpy() < thr).sum())}
+    certs = [None] * dist.get_world_size()
+    dist.all_gather_object(certs, mine)
+    return {"ms": ms, "value": n_total * len(times) / (ms / 1e3), "unit": "satellite-steps screened/s", "target_row": target, "threshold_km": thr,
+            "index_mismatches": sum(c["index_mismatches"] for c in certs), "max_dd_km": max(c["max_dd_km"] for c in certs), "per_rank": certs,
+            "what": "fused single-target screen, catalog sharded block-cyclically, target track computed on every rank, no collective in the step"}
+
+
 def group_host(_native, synth, allp, world, local_rank, times, vel_on, n_total, n_times):
     """(result dict, stuck): azh_group_propagate_host on all N devices of this process, fresh host arrays each call, wall clock.
     Behind a watchdog: this is an extra, it must never take the headline line down with it."""

@@ -93,6 +93,8 @@ pub extern "c" fn azh_screen_target_host(h: ?*Handle, times_min: [*]const f64, n
     target_index: usize, threshold_km: f64, reference_jd: f64, min_dist_km: [*]f64, min_t_index: [*]u32) i32;
 pub extern "c" fn azh_screen_target_device(h: ?*Handle, times_min: [*]const f64, n_times: usize, epoch_offsets_min: ?[*]const f64,
     target_index: usize, threshold_km: f64, reference_jd: f64, d_min_dist_km: [*]f64, d_min_t_index: [*]u32, stream: ?*anyopaque) i32;
+pub extern "c" fn azh_screen_track_device(h: ?*Handle, times_min: [*]const f64, n_times: usize, epoch_offsets_min: ?[*]const f64,
+    d_track: [*]const f64, exclude_index: usize, threshold_km: f64, d_min_dist_km: [*]f64, d_min_t_index: [*]u32, stream: ?*anyopaque) i32; // the same against an external track (another shard's satellite)
 pub extern "c" fn azh_coarse_screen_device(d_pos: [*]const f64, n_sats: usize, n_times: usize, layout: i32, stride_sats: usize,
     threshold_km: f64, valid_mask: ?[*]const u8, out_pairs: [*]u32, out_t_index: [*]u32, max_results: usize, n_found: *usize,
     stream: ?*anyopaque) i32;
@@ -118,7 +120,7 @@ pub extern "c" fn azh_set_f32_arithmetic(h: ?*Handle, enabled: i32) i32; // bool
 pub extern "c" fn azh_set_fast_path(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_set_tile_kernel(h: ?*Handle, enabled: i32) i32;
 pub extern "c" fn azh_set_graphs(h: ?*Handle, enabled: i32) i32; // hipGraph replay of repeated cached-input launch sets (default off; pays for multi-window pipelines)
-pub extern "c" fn azh_set_host_points(n: usize) void; // one-satellite calls of at most n points run the library's step on the calling thread (default 64)
+pub extern "c" fn azh_set_host_points(n: usize) void; // one-satellite calls of at most n points run the library's step on the calling thread (default 128; deep-space members: half)
 pub extern "c" fn azh_get_host_points() usize;
 pub extern "c" fn azh_set_host_copy_threads(n: i32) void; // host threads behind the pinned staging of host-returning copies (-1 auto, 0 = direct pageable copies)
 // result arrays the DMA engines write directly (pinned, pooled inside the library): a Zig host allocates `positions` / `velocities`
@@ -132,6 +134,8 @@ pub extern "c" fn azh_last_one_stats(h: ?*Handle, n_segments: ?*u32, n_handed_ov
 pub extern "c" fn azh_propagate_one_device(h: ?*Handle, sat_index: usize, d_tsince_min: [*]const f64, n: usize, d_pos: [*]f64,
     d_vel: ?[*]f64, d_err: ?[*]u8, stream: ?*anyopaque) i32;
 pub extern "c" fn azh_selftest_math(x: [*]const f64, n: usize, out6n: [*]f64, device: i32) i32;
+pub extern "c" fn azh_selftest_host_step(el: [*]const f64, n_pad: usize, sat: usize, flags: u32, grav: i32, tsince_min: [*]const f64, n: usize,
+    out6n: [*]f64, err: ?[*]u8) i32; // the host route's step on a caller-supplied element table (no device needed; KAT)
 pub extern "c" fn azh_selftest_coords(op: i32, in: *const [4]f64, out: *[5]f64) i32; // part (A)'s closed forms through the kernels' frame code (KAT)
 
 // src/c_api/coords.zig
@@ -155,3 +159,12 @@ pub extern "c" fn azh_group_propagate_host(g: ?*Group, times_min: [*]const f64, 
     n_offsets: usize, pos: [*]f64, vel: ?[*]f64, output_mode: i32, reference_jd: f64, err: ?[*]u8) i32;
 pub extern "c" fn azh_group_propagate_allgather(g: ?*Group, times_min: [*]const f64, n_times: usize,
     epoch_offsets_min: ?[*]const f64, n_offsets: usize, d_pos: [*]const [*]f64, d_vel: ?[*]const [*]f64) i32;
+// the fused single-target screen over a group (Constellation.screenConstellation, src/Constellation.zig L683-756): every device
+// screens its own rows against the target's track, no collective
+pub extern "c" fn azh_group_screen_target_host(g: ?*Group, times_min: [*]const f64, n_times: usize, epoch_offsets_min: ?[*]const f64,
+    n_offsets: usize, target_index: usize, threshold_km: f64, reference_jd: f64, min_dist_km: [*]f64, min_t_index: [*]u32) i32;
+pub extern "c" fn azh_group_screen_target_device(g: ?*Group, times_min: [*]const f64, n_times: usize, epoch_offsets_min: ?[*]const f64,
+    n_offsets: usize, target_index: usize, threshold_km: f64, reference_jd: f64, d_min_dist_km: [*]const [*]f64, d_min_t_index: [*]const [*]u32) i32;
+pub extern "c" fn azh_group_shard_size(g: ?*const Group, device_slot: i32) usize;
+pub extern "c" fn azh_group_shard_rows(g: ?*const Group, device_slot: i32, out_rows: [*]u32) i32;
+pub extern "c" fn azh_group_synchronize(g: ?*Group) i32;

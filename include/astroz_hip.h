@@ -253,6 +253,15 @@ int32_t azh_screen_target_device(azh_constellation *c, const double *times_min, 
                                  const double *epoch_offsets_min, size_t target_index, double threshold_km,
                                  double reference_jd, double *d_min_dist_km, uint32_t *d_min_t_index, void *stream);
 
+/* The same screen against an EXTERNAL track: d_track = n_times x 3 doubles (TEME km) on c's device -- the track of a satellite
+ * that lives in another shard of a multi-GPU run (every rank screens ITS rows against the one target: SURVEY 8e's
+ * gather-free consumer; astroz_amd.distributed.sharded_screen_target), or of an object that is in no catalog.  exclude_index:
+ * a member of c that reports threshold / 0 like the target does above (SIZE_MAX: none).  Non-finite track points (a target
+ * whose propagation failed there; azh_screen_target_* writes NaN for them too) never compare closer than the threshold. */
+int32_t azh_screen_track_device(azh_constellation *c, const double *times_min, size_t n_times,
+                                const double *epoch_offsets_min, const double *d_track, size_t exclude_index,
+                                double threshold_km, double *d_min_dist_km, uint32_t *d_min_t_index, void *stream);
+
 /* All-vs-all coarse screen = coarseScreen (bindings/python/src/conjunction.zig L11-150): every pair
  * (s < other) closer than threshold_km at grid index t, found with a per-step cell list (cell edge =
  * threshold).  Positions: fp64, either layout; rows with valid_mask[s] == 0 or a non-finite x are
@@ -303,6 +312,25 @@ int32_t azh_group_propagate_allgather(azh_group *g, const double *times_min, siz
                                       const double *epoch_offsets_min, size_t n_offsets, double *const *d_pos,
                                       double *const *d_vel);
 
+/* The fused single-target screen over a group (Constellation.screenConstellation, src/Constellation.zig L683-756, one
+ * process, N devices): every device screens the rows it owns against the target's track -- computed once on the device that
+ * owns `target_index` (a catalog row) and handed to the others, n_times x 24 bytes -- with no collective: the one multi-GPU
+ * workload on this path whose time falls with N (the gathered propagation's does not).
+ *   _host   : min_dist_km / min_t_index are host arrays of azh_group_num_satellites() entries in CATALOG order; synchronous.
+ *   _device : d_min_dist_km[i] / d_min_t_index[i] are device buffers on devices[i] of azh_group_shard_size(g, i) entries in
+ *             that shard's local order (= ascending catalog rows, azh_group_shard_rows); asynchronous on every shard's own
+ *             stream -- azh_group_synchronize waits for all of them.
+ * Values as azh_screen_target_host: start value threshold_km / index 0; the target itself and failed members report that. */
+int32_t azh_group_screen_target_host(azh_group *g, const double *times_min, size_t n_times, const double *epoch_offsets_min,
+                                     size_t n_offsets, size_t target_index, double threshold_km, double reference_jd,
+                                     double *min_dist_km, uint32_t *min_t_index);
+int32_t azh_group_screen_target_device(azh_group *g, const double *times_min, size_t n_times, const double *epoch_offsets_min,
+                                       size_t n_offsets, size_t target_index, double threshold_km, double reference_jd,
+                                       double *const *d_min_dist_km, uint32_t *const *d_min_t_index);
+size_t azh_group_shard_size(const azh_group *g, int32_t device_slot);
+int32_t azh_group_shard_rows(const azh_group *g, int32_t device_slot, uint32_t *out_rows);
+int32_t azh_group_synchronize(azh_group *g);
+
 /* Constellation.propagate (src/Constellation.zig L245-308): absolute times jd[t]+fr[t]; the
  * reference epoch is that of the first near-earth member (the first entry of the reference's SGP4 batch list,
  * L139-140; the first member's if there is none). Host pointers. */
@@ -333,6 +361,12 @@ int32_t azh_selftest_math(const double *x, size_t n, double *out6n, int32_t devi
  * at GMST in[3]; 2: ECEF -> (lat deg, lon deg, alt km); 3: (velocity, period, escape velocity) of (mu, radius, sma);
  * 4: Hohmann (sma, dv1, dv2, |dv1| + |dv2|, transfer time) of (mu, r1, r2).  Unused outputs are 0. */
 int32_t azh_selftest_coords(int32_t op, const double in[4], double out[5]);
+/* the host route's step (azh_set_host_points; astroz_amd/csrc/host_step.h) on a caller-supplied element table
+ * el[field * n_pad + sat] (the 85 rows of astroz_amd/csrc/fields.h, in that order) with status word `flags`: n points, out6n = n x
+ * (x, y, z, vx, vy, vz), err (n, optional).  Needs no device: lets the CPU test tier hold the shipped object to the oracle.
+ * Test infrastructure; not part of the reference surface. */
+int32_t azh_selftest_host_step(const double *el, size_t n_pad, size_t sat, uint32_t flags, int32_t grav, const double *tsince_min,
+                               size_t n, double *out6n, uint8_t *err);
 
 /* tuning knobs (kernel time-tile length; 0 = automatic).  Not part of the reference surface. */
 int32_t azh_set_time_tile(azh_constellation *c, uint32_t sgp4_tile, uint32_t sdp4_tile);
@@ -358,7 +392,7 @@ int32_t azh_set_graphs(azh_constellation *c, int32_t enabled);
  * of the link's 17).  -1 automatic (default: 6), 0 = direct pageable copies. */
 void azh_set_host_copy_threads(int32_t n);
 /* One-satellite host-pointer calls of at most n points (azh_propagate_one_host, sgp4_propagate, sgp4_propagate_batch, and
- * azh_propagate_host on a one-satellite handle; default 64, environment ASTROZ_AMD_HOST_POINTS, 0 = never) do not launch a
+ * azh_propagate_host on a one-satellite handle; default 128 -- half of it for deep-space members --, environment ASTROZ_AMD_HOST_POINTS, 0 = never) do not launch a
  * kernel: the library evaluates its own per-point step (the source k_one_satellite compiles, astroz_amd/csrc/host_step.h) on
  * the calling thread, from the element column the DEVICE initialised -- what the reference's scalar call is
  * (bindings/python/src/satrec.zig L169-201: 0.4 us; a launch + a synchronize is 20 us).  Results agree with the kernels' to

@@ -1,5 +1,7 @@
+import ctypes as C
 import json
 import os
+import subprocess
 import sys
 
 import pytest
@@ -38,3 +40,37 @@ def c_client():
     subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
                     src, "-o", out, "-L", lib_dir, "-lastroz_hip", "-Wl,-rpath," + lib_dir], check=True)
     return out
+
+
+@pytest.fixture(scope="session")
+def native():
+    import __graft_entry__ as g
+    g.build()
+    from astroz_amd import _native
+    return _native
+
+
+@pytest.fixture(scope="session")
+def emul():
+    """Host build of the device math headers (tests/host_emul/emul.cpp)."""
+    src = os.path.join(ROOT, "tests", "host_emul", "emul.cpp")
+    lib = os.path.join(ROOT, "tests", "host_emul", "libemul.so")
+    hdrs = [os.path.join(ROOT, "astroz_amd", "csrc", h) for h in ("devmath.h", "fields.h", "init_device.h", "propagate_device.h", "fast_step.h", "fast_step_f32.h")]
+    if not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-Wno-unknown-pragmas", "-o", lib, src])
+    E = C.CDLL(lib)
+    E.emul_init.restype = C.c_uint
+    E.emul_init.argtypes = [C.c_void_p] * 3
+    E.emul_propagate.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    E.emul_propagate_fast.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    E.emul_propagate_fast32.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    E.emul_propagate_fast32p.argtypes = E.emul_propagate_fast32.argtypes
+    E.emul_propagate_deep_cached.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    E.emul_sincos.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
+    E.emul_rcp.restype = C.c_double
+    E.emul_rcp.argtypes = [C.c_double]
+    E.emul_rsqrt.restype = C.c_double
+    E.emul_rsqrt.argtypes = [C.c_double]
+    E.emul_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
+    return E

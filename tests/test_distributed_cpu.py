@@ -143,3 +143,117 @@ def test_gloo_world2_config4_pipeline(n_near, n_deep, n_chunks):
     assert res[0][2] + res[1][2] == n_near + n_deep
     if n_deep and n_chunks > 1:
         assert res[0][3] > 0 and res[1][3] > 0, res      # deep-space members (sorted last) reach both ranks
+
+
+# ---- the gather-free consumer: the sharded fused screen (SURVEY 8e fallback row) --------------------------------------------
+def _as_np(ptr, shape, ctype, dtype):
+    import ctypes as C
+    n = int(np.prod(shape))
+    return np.ctypeslib.as_array((ctype * n).from_address(ptr)).view(dtype).reshape(shape)
+
+
+class _OracleTarget:
+    """stand-in for the one-satellite DeviceConstellation of the target (propagate_one_device contract, host pointers)"""
+
+    def __init__(self, cat):
+        self.cat = cat
+
+    def propagate_one_device(self, sat, d_tsince, n, d_pos, d_vel=None, d_err=None, stream=None):
+        import ctypes as C
+        ts = _as_np(d_tsince, (n,), C.c_double, np.float64)
+        pos = _as_np(d_pos, (n, 3), C.c_double, np.float64)
+        err = _as_np(d_err, (n,), C.c_uint8, np.uint8) if d_err else None
+        for k in range(n):
+            rc, r, _ = self.cat.propagate_one(sat, ts[k])
+            pos[k] = r if rc == 0 else 0.0
+            if err is not None:
+                err[k] = rc
+
+    def synchronize(self):
+        pass
+
+
+class _OracleScreenShard:
+    """stand-in for the rank's DeviceConstellation: screen_track_device with the oracle's positions"""
+
+    def __init__(self, cat):
+        self.cat, self.n = cat, cat.n
+
+    def screen_track_device(self, times, d_track, threshold, d_min_dist, d_min_t, offsets_min=None, exclude=None, stream=None):
+        import ctypes as C
+        from oracle import oracle
+        nt = len(times)
+        track = _as_np(d_track, (nt, 3), C.c_double, np.float64)
+        out_d = _as_np(d_min_dist, (self.n,), C.c_double, np.float64)
+        out_t = _as_np(d_min_t, (self.n,), C.c_int32, np.int32)
+        err, p, _ = self.cat.propagate(times, offsets_min, layout=oracle.SAT_MAJOR, velocities=False)
+        d2 = ((p - track[None]) ** 2).sum(axis=2)
+        d2[err != 0] = np.inf
+        d2[:, ~np.isfinite(track).all(axis=1)] = np.inf
+        for s in range(self.n):
+            best, bt = threshold * threshold, 0
+            if s != exclude and self.cat.init_rc[s] == 0:
+                k = int(np.argmin(d2[s]))
+                if d2[s, k] < best:
+                    best, bt = d2[s, k], k
+            out_d[s] = np.sqrt(best)
+            out_t[s] = bt
+
+
+def _screen_worker(rank, world, port, n_near, n_deep, n_chunks, target, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from astroz_amd import synth
+    from astroz_amd.distributed import ShardPlan, ShardedScreen
+    from oracle import oracle
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pairs = synth.synth_catalog(n_near, n_deep, seed=17)
+        n = len(pairs)
+        times = np.arange(0.0, 240.0, 2.0)
+        ref = oracle.Catalog.from_pairs(pairs, 1)
+        roff = (synth.START_JD - ref.epoch_jd) * 1440.0
+        thr = 2500.0
+        d0, t0 = ref.screen_target(times, target, thr, roff)
+
+        class Shard:
+            pass
+        sh = Shard()
+        sh.plan = ShardPlan(n, world, n_chunks, align=8)
+        sh.rank = rank
+        sh.rows = sh.plan.local_rows(rank)
+        sh.dev = _OracleScreenShard(oracle.Catalog.from_pairs([pairs[i] for i in sh.rows], 1)) if len(sh.rows) else None
+        scr = ShardedScreen(sh, target, _OracleTarget(oracle.Catalog.from_pairs([pairs[target]], 1)), times, roff, thr)
+        scr.step()
+        rows, dl, tl = scr.local_results()
+        ok = np.array_equal(rows, sh.rows) and np.allclose(dl.numpy(), d0[rows], rtol=0, atol=1e-9) and np.array_equal(tl.numpy(), t0[rows])
+        ok = ok and ((scr.exclude is not None) == (target in set(int(x) for x in rows)))
+        dg, tg = scr.gather()
+        ok = ok and np.allclose(dg.numpy(), d0, rtol=0, atol=1e-9) and np.array_equal(tg.numpy(), t0)
+        q.put((rank, bool(ok), int((d0 < thr).sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_near,n_deep,n_chunks,target", [(200, 0, 1, 3), (150, 30, 3, 170), (97, 11, 2, 64)])
+def test_gloo_world2_sharded_screen(n_near, n_deep, n_chunks, target):
+    """every rank screens its block-cyclic rows against the target's track (computed by every rank itself): local results =
+    the oracle's screen restricted to the rank's rows, the 12-byte-per-satellite gather = the oracle's whole result; no
+    collective inside the step"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_screen_worker, args=(r, 2, port, n_near, n_deep, n_chunks, target, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True], res
+    assert res[0][2] > 1, res      # (the threshold is wide enough that the screen has something to find)

@@ -1,0 +1,327 @@
+"""Round 6, GPU tier (all through the C ABI)."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+TOL_R, TOL_V = 1e-6, 1e-9
+
+
+@pytest.fixture(scope="module")
+def native():
+    import __graft_entry__ as g
+    g.build()
+    from astroz_amd import _native
+    if _native.device_count() < 1:
+        pytest.fail("no HIP device visible on a GPU-tier run")
+    return _native
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from astroz_amd import synth as s
+    return s
+
+
+def _golden_pairs(golden):
+    out = [(c["line1"], c["line2"]) for c in golden["G1_vallado_near_earth"]["cases"]]
+    out += [(golden["G2_iss_wgs84"]["line1"], golden["G2_iss_wgs84"]["line2"])]
+    out += [(c["line1"], c["line2"]) for c in golden["G4_G5_deep_space_wgs72"]["cases"]]
+    return out
+
+
+def test_host_route_matches_device_route(native, orc, synth, golden):
+    """Calls of <= azh_get_host_points() points run the library's own step on the calling thread (host_step.h): same results
+    as the kernels to 1e-9 km / 1e-12 km/s and as the oracle at the fp64 gate, same error codes, on the reference's golden
+    satellites (G1-G5) and on 10^4 random (satellite, time) pairs of a mixed catalog (a handle too large for the whole-table
+    mirror: per-column fetch); azh_last_path reports the route; one point more than the limit launches the kernel."""
+    n_host = native.get_host_points()
+    assert n_host == 128
+    pairs = _golden_pairs(golden) + synth.synth_catalog(n_near=150, n_deep=50, seed=31)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, native.WGS72, 0)
+    cat = orc.Catalog.from_pairs(pairs, orc.WGS72)
+    assert dev.n > 64
+    rng = np.random.default_rng(5)
+    worst = [0.0, 0.0]                       # host route vs oracle
+    gap = {(k, span): [0.0, 0.0] for k in ("near-earth", "deep-space") for span in ("2 days", "2 weeks")}   # host route vs kernels
+    n_pts = 0
+    _, is_deep, _ = dev.status
+    try:
+        for s in range(dev.n):
+            # (50 points: inside the deep-space limit too) half of them within +-2 days of epoch, half within +-2 weeks
+            ts = np.concatenate([[0.0, 360.0], rng.uniform(-2880.0, 2880.0, 24), rng.uniform(-20160.0, 20160.0, 24)])
+            native.set_host_points(n_host)
+            e_h, r_h, v_h = dev.propagate_one(s, ts)
+            assert dev.last_path() == native.PATH_HOST_STEP
+            native.set_host_points(0)
+            e_d, r_d, v_d = dev.propagate_one(s, ts)
+            assert dev.last_path() != native.PATH_HOST_STEP
+            assert np.array_equal(e_h, e_d)
+            for span, sl in (("2 days", slice(0, 26)), ("2 weeks", slice(26, 50))):
+                g = gap[("deep-space" if is_deep[s] else "near-earth", span)]
+                g[0] = max(g[0], np.abs(r_h[sl] - r_d[sl]).max())
+                g[1] = max(g[1], np.abs(v_h[sl] - v_d[sl]).max())
+            for k in range(0, len(ts), 5):
+                rc, r, v = cat.propagate_one(s, ts[k])
+                assert rc == e_h[k]
+                if rc == 0:
+                    worst[0] = max(worst[0], np.abs(r_h[k] - r).max())
+                    worst[1] = max(worst[1], np.abs(v_h[k] - v).max())
+            n_pts += len(ts)
+        assert n_pts >= 10000
+        print("host route vs kernels (km, km/s):", {k: ["%.2e" % x for x in v] for k, v in gap.items()}, "vs oracle:", ["%.2e" % x for x in worst])
+        # host route vs kernels: the same source, other roundings (reciprocal seeds, FMA contraction): a few ulps of the phase
+        # angles, which at t = 2 days are ~200 rad (ulp 2.8e-14 rad = 2e-10 km in LEO) and ~1,400 rad at 2 weeks, times the
+        # orbit's own amplification (an e = 0.7 member turns 1 rad of mean anomaly into 8 rad of true anomaly at perigee).  The
+        # gate is a tenth of the gate against the oracle; the kernels themselves sit 1e-8 km / 1e-11 km/s from the oracle.
+        # measured: near-earth 7.5e-10 km / 6e-13 km/s on both spans, deep-space 2.0e-9 km / 4.0e-12 km/s
+        for key, g in gap.items():
+            lim = (1e-9, 1e-12) if key[0] == "near-earth" else (5e-9, 1e-11)
+            assert g[0] < lim[0] and g[1] < lim[1], (key, g)
+        assert worst[0] < TOL_R and worst[1] < TOL_V, worst      # host route vs oracle
+        native.set_host_points(n_host)
+        s_near, s_deep = int(np.flatnonzero(~is_deep)[0]), int(np.flatnonzero(is_deep)[0])
+        ts = np.linspace(0.0, 1440.0, n_host + 1)
+        for s, lim in ((s_near, n_host), (s_deep, n_host // 2)):  # (deep-space members: half the limit -- where the routes cross)
+            dev.propagate_one(s, ts[:lim + 1])
+            assert dev.last_path() != native.PATH_HOST_STEP      # above the limit: the kernel
+            dev.propagate_one(s, ts[:lim])
+            assert dev.last_path() == native.PATH_HOST_STEP
+    finally:
+        native.set_host_points(n_host)
+
+
+def test_scalar_calls_take_the_host_route(native, orc, golden):
+    """Satrec.sgp4 (python-sgp4's scalar call; bindings/python/src/satrec.zig L169-201), the c_api's sgp4_propagate /
+    sgp4_propagate_batch and SatrecArray([sat]).sgp4 of a few points: host route, oracle parity, and the reference's order of
+    magnitude in time (published: 0.4 us per call; here a launch + synchronize was 23 us)."""
+    from astroz_amd.api import Satrec, SatrecArray, WGS72
+    g = golden["G1_vallado_near_earth"]["cases"][0]
+    sat = Satrec.twoline2rv(g["line1"], g["line2"], WGS72)
+    cat = orc.Catalog.from_pairs([(g["line1"], g["line2"])], orc.WGS72)
+    ep = sat.jdsatepoch + sat.jdsatepochF
+    for st in g["states"]:
+        jd = sat.jdsatepoch
+        fr = sat.jdsatepochF + st["t"] / 1440.0
+        e, r, v = sat.sgp4(jd, fr)
+        assert e == 0 and isinstance(r, tuple) and len(r) == 3 and isinstance(r[0], float)
+        rc, r0, v0 = cat.propagate_one(0, ((jd + fr) - ep) * 1440.0)
+        assert np.abs(np.array(r) - r0).max() < TOL_R and np.abs(np.array(v) - v0).max() < TOL_V
+        np.testing.assert_allclose(r, st["r"], atol=1e-5, rtol=0)     # (the (jd, fr) round trip moves t by ~1e-9 min)
+        assert abs(sat.t - st["t"]) < 1e-6 and sat.error == 0
+    assert sat._ensure().last_path() == native.PATH_HOST_STEP
+    # wall clock of the scalar call
+    jd, fr = sat.jdsatepoch, sat.jdsatepochF + 0.25
+    for _ in range(2000):
+        sat.sgp4(jd, fr)
+    t0 = time.perf_counter()
+    n = 20000
+    for _ in range(n):
+        sat.sgp4(jd, fr)
+    us = (time.perf_counter() - t0) / n * 1e6
+    print("Satrec.sgp4: %.3f us per call (%s)" % (us, "CPython shim" if native.fast_scalar() else "ctypes"))
+    assert us < (3.0 if native.fast_scalar() else 12.0), us
+    # a decayed satellite: the error code comes through the host route too
+    bad1 = "1 28350U 04020A   06167.21788666  .16154492  76267-5  18678-3 0  8894"
+    bad2 = "2 28350  64.9977 345.6130 0024870 260.7578  99.9590 16.47856722116490"
+    sb = Satrec.twoline2rv(bad1, bad2, WGS72)
+    cb = orc.Catalog.from_pairs([(bad1, bad2)], orc.WGS72)
+    for tmin in (0.0, 120.0, 1440.0, 2880.0):
+        e, r, v = sb.sgp4(sb.jdsatepoch, sb.jdsatepochF + tmin / 1440.0)
+        rc, r0, v0 = cb.propagate_one(0, ((sb.jdsatepoch + (sb.jdsatepochF + tmin / 1440.0)) - (sb.jdsatepoch + sb.jdsatepochF)) * 1440.0)
+        assert e == rc
+        if rc == 0:
+            assert np.abs(np.array(r) - r0).max() < TOL_R
+    # c_api (src/c_api/root.zig L13-81)
+    L = native.lib()
+    h, s = C.c_void_p(), C.c_void_p()
+    assert L.tle_parse((g["line1"] + "\n" + g["line2"]).encode(), C.byref(h)) == 0
+    assert L.sgp4_init(h, 1, C.byref(s)) == 0
+    pos, vel = (C.c_double * 3)(), (C.c_double * 3)()
+    L.sgp4_propagate.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    assert L.sgp4_propagate(s, 360.0, pos, vel) == 0
+    np.testing.assert_allclose(list(pos), g["states"][1]["r"], atol=2e-8, rtol=0)
+    np.testing.assert_allclose(list(vel), g["states"][1]["v"], atol=2e-9, rtol=0)
+    ts = np.linspace(-720.0, 720.0, 40)
+    res = np.zeros((40, 6))
+    L.sgp4_propagate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    assert L.sgp4_propagate_batch(s, ts.ctypes.data, res.ctypes.data, 40) == 0
+    _, p0, v0 = cat.propagate(ts, None, layout=orc.SAT_MAJOR)
+    assert np.abs(res[:, :3] - p0[0]).max() < TOL_R and np.abs(res[:, 3:] - v0[0]).max() < TOL_V
+    L.sgp4_free(s)
+    L.tle_free(h)
+    # SatrecArray([sat]) of a few points, then a cached-input call on the same handle must not find a stale grid
+    sa = SatrecArray([sat])
+    jd5 = np.full(5, sat.jdsatepoch)
+    fr5 = sat.jdsatepochF + np.arange(5) / 1440.0
+    e, r, v = sa.sgp4(jd5, fr5)
+    _, p0, v0 = cat.propagate(((jd5 + fr5) - (jd5[0] + fr5[0])) * 1440.0, ((jd5[0] + fr5[0]) - sa._epochs) * 1440.0, layout=orc.SAT_MAJOR)
+    assert np.abs(r - p0).max() < TOL_R and np.abs(v - v0).max() < TOL_V
+    assert sa._dev.last_path() == native.PATH_HOST_STEP
+    import torch
+    buf = torch.zeros((1, 5, 3), dtype=torch.float64, device="cuda")
+    with pytest.raises(native.NativeError):
+        sa._dev.propagate_device_cached(buf.data_ptr(), None, layout=native.SAT_MAJOR)   # nothing is staged on that route
+
+
+def test_graphs_survive_scratch_reallocation(native, orc, synth):
+    """graphs on, deep-space members, time-major.  Capture (pos, no vel); an eager (pos, vel) call then
+    needs twice the scratch and reallocates it; the next (pos, no vel) call must not replay a graph through the freed
+    pointer -- same bytes as the eager result, over several alternations."""
+    import torch
+    pairs = synth.synth_catalog(n_near=1200, n_deep=300, seed=8)
+    dev = native.DeviceConstellation.from_tle_lines(pairs, native.WGS72, 0)
+    cat = orc.Catalog.from_pairs(pairs, orc.WGS72)
+    off = (synth.START_JD - dev.epochs) * 1440.0
+    n_t = 256
+    times = np.arange(n_t, dtype=np.float64)
+    _, p0, v0 = cat.propagate(times, off, layout=orc.TIME_MAJOR)
+    dev.set_graphs(True)
+    dev.set_timing(False)
+    pos = torch.zeros((n_t, dev.n, 3), dtype=torch.float64, device="cuda")
+    pos2 = torch.zeros_like(pos)
+    vel2 = torch.zeros_like(pos)
+    torch.cuda.synchronize()
+    dev.propagate_device(times, off, pos.data_ptr(), None, layout=native.TIME_MAJOR)
+    for _ in range(4):          # eager, captured, replayed (both redo parities)
+        dev.propagate_device_cached(pos.data_ptr(), None, layout=native.TIME_MAJOR)
+    dev.synchronize()
+    assert np.abs(pos.cpu().numpy() - p0).max() < TOL_R
+    for k in range(3):
+        dev.propagate_device_cached(pos2.data_ptr(), vel2.data_ptr(), layout=native.TIME_MAJOR)   # new key: eager, 2x scratch
+        dev.synchronize()
+        assert np.abs(pos2.cpu().numpy() - p0).max() < TOL_R and np.abs(vel2.cpu().numpy() - v0).max() < TOL_V
+        junk = torch.full((n_t * dev.n * 3,), 7.0, dtype=torch.float64, device="cuda")    # (re-use whatever was freed)
+        pos.zero_()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            dev.propagate_device_cached(pos.data_ptr(), None, layout=native.TIME_MAJOR)
+        dev.synchronize()
+        assert np.abs(pos.cpu().numpy() - p0).max() < TOL_R, k
+        del junk
+    dev.set_graphs(False)
+
+
+def test_sgp4_device_layout_validation(native, synth):
+    """layout is validated first; padded=True with layout='sat' is an error, not silently ignored"""
+    from astroz_amd.api import Satrec, SatrecArray, WGS72
+    pairs = synth.synth_catalog(n_near=20, n_deep=0, seed=2)
+    sa = SatrecArray([Satrec.twoline2rv(a, b, WGS72) for a, b in pairs])
+    jd = np.full(70, synth.START_JD)
+    fr = np.arange(70) / 1440.0
+    with pytest.raises(ValueError):
+        sa.sgp4_device(jd, fr, layout="rows")
+    with pytest.raises(ValueError):
+        sa.sgp4_device(jd, fr, layout="sat", padded=True)
+    e, r, v = sa.sgp4_device(jd, fr, layout="sat")
+    assert tuple(r.shape) == (20, 70, 3)
+
+
+def test_pinned_result_budget(native):
+    """live pinned result bytes are bounded; beyond the budget results are plain numpy arrays"""
+    native.host_pool_trim()
+    live0 = native.host_pool_stats()[0]
+    native.set_pinned_budget(live0 + (40 << 20))
+    try:
+        a = native.result_empty((2 << 20,))        # 16 MiB: pinned
+        b = native.result_empty((2 << 20,))        # 32 MiB: pinned
+        c = native.result_empty((2 << 20,))        # would be 48 MiB: pageable
+        assert native.host_pool_stats()[0] - live0 >= (32 << 20)
+        assert a.base is not None and b.base is not None and c.base is None
+        del a, b
+        d = native.result_empty((2 << 20,))        # room again
+        assert d.base is not None
+    finally:
+        native.set_pinned_budget(8 << 30)
+
+
+@pytest.mark.parametrize("devices,n_chunks", [([0], 1), ([0], 4), ([0, 0], 3), ([0, 0, 0], 2)])
+def test_group_sharded_screen(native, orc, synth, devices, n_chunks):
+    """azh_group_screen_target_host / _device: every shard screens its own rows against the target's track (computed on the
+    shard that owns the target, handed to the others), results in catalog order -- identical to the single-handle screen and to
+    the oracle on config 2's 13,478 rows (0 index mismatches), targets in the first and in a later shard, near-earth and
+    deep-space.  Several shards on ONE device (devices = [0, 0, ...]) exercise the multi-shard logic on a one-GPU box."""
+    import torch
+    pairs = synth.synth_catalog(n_near=13478 - 600, n_deep=600, seed=77)
+    text = synth.pairs_to_text(pairs)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    one = native.DeviceConstellation.from_tle_lines(pairs, native.WGS72, 0)
+    grp = native.DeviceGroup(text, devices, native.WGS72, n_chunks=n_chunks)
+    assert grp.n == len(pairs) and sum(grp.shard_size(d) for d in range(len(devices))) == grp.n
+    rows = np.sort(np.concatenate([grp.shard_rows(d) for d in range(len(devices))]))
+    assert np.array_equal(rows, np.arange(grp.n))
+    times = np.arange(0.0, 1440.0, 1.0)
+    off = (synth.START_JD - cat.epoch_jd) * 1440.0
+    thr = 800.0
+    deep_rows = np.flatnonzero(cat.is_deep)
+    for target in (5, 9000, int(deep_rows[len(deep_rows) // 2])):
+        d0, t0 = cat.screen_target(times, target, thr, off)
+        d1, t1 = one.screen_target(times, target, thr, off)
+        dg, tg = grp.screen_target(times, target, thr, off)
+        assert np.array_equal(tg, t1) and np.abs(dg - d1).max() < 1e-7   # the single-handle screen: same indices, rounding apart
+        if len(devices) == 1:
+            assert np.array_equal(dg, d1)                                  # (one shard = the same launch shapes: bit for bit)
+        assert np.array_equal(tg, t0) and np.abs(dg - d0).max() < 1e-6     # and the oracle's indices, every one
+        assert dg[target] == thr and tg[target] == 0
+        assert (dg < thr).sum() > 3 or cat.is_deep[target]                 # (a low-orbit target has company inside 800 km)
+    # device-resident results per shard
+    bufs_d = [torch.zeros(grp.shard_size(d), dtype=torch.float64, device="cuda") for d in range(len(devices))]
+    bufs_t = [torch.zeros(grp.shard_size(d), dtype=torch.int32, device="cuda") for d in range(len(devices))]
+    torch.cuda.synchronize()
+    grp.screen_target_device(times, 9000, thr, [b.data_ptr() for b in bufs_d], [b.data_ptr() for b in bufs_t], off)
+    grp.synchronize()
+    d0, t0 = cat.screen_target(times, 9000, thr, off)
+    for d in range(len(devices)):
+        r = grp.shard_rows(d)
+        assert np.array_equal(bufs_t[d].cpu().numpy(), t0[r]) and np.abs(bufs_d[d].cpu().numpy() - d0[r]).max() < 1e-6
+    with pytest.raises(native.NativeError):
+        grp.screen_target(times, grp.n, thr, off)
+    grp.close()
+
+
+def test_screen_against_external_track_and_sharded_screen_single_rank(native, orc, synth):
+    """azh_screen_track_device (the building block of the one-process-per-GPU sharded screen) and
+    astroz_amd.distributed.ShardedScreen with a world of one: the target lives in ANOTHER handle; results = the oracle's screen
+    of the whole catalog restricted to this handle's rows."""
+    import torch
+    from astroz_amd.distributed import ShardedConstellation, ShardedScreen
+    pairs = synth.synth_catalog(n_near=3000, n_deep=200, seed=5)
+    cat = orc.Catalog.from_pairs(pairs, 1)
+    times = np.arange(0.0, 720.0, 1.0)
+    off = (synth.START_JD - cat.epoch_jd) * 1440.0
+    thr, target = 1500.0, 1234
+    d0, t0 = cat.screen_target(times, target, thr, off)
+    # (1) a handle WITHOUT the target, screened against the target's track from a one-satellite handle
+    keep = np.array([i for i in range(len(pairs)) if i != target])
+    dev = native.DeviceConstellation.from_tle_lines([pairs[i] for i in keep], native.WGS72, 0)
+    tgt = native.DeviceConstellation.from_tle_lines([pairs[target]], native.WGS72, 0)
+    ts = torch.as_tensor(times + off[target], dtype=torch.float64).cuda()
+    track = torch.zeros((len(times), 3), dtype=torch.float64, device="cuda")
+    out_d = torch.zeros(dev.n, dtype=torch.float64, device="cuda")
+    out_t = torch.zeros(dev.n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    tgt.propagate_one_device(0, ts.data_ptr(), len(times), track.data_ptr())
+    tgt.synchronize()
+    dev.screen_track_device(times, track.data_ptr(), thr, out_d.data_ptr(), out_t.data_ptr(), offsets_min=off[keep])
+    dev.synchronize()
+    assert np.array_equal(out_t.cpu().numpy(), t0[keep]) and np.abs(out_d.cpu().numpy() - d0[keep]).max() < 1e-6
+    assert dev.last_path() & native.PATH_ROWS_FAST
+    # (2) the distributed class on one rank (the target is one of its rows: excluded)
+    sh = ShardedConstellation(pairs, native.WGS72, rank=0, world_size=1, local_rank=0, n_chunks=2)
+    scr = ShardedScreen(sh, target, tgt, times, off, thr, device=torch.device("cuda", 0))
+    st = torch.cuda.Stream()
+    for _ in range(3):
+        scr.step(stream=st.cuda_stream)
+    st.synchronize()
+    rows, dl, tl = scr.local_results()
+    assert np.array_equal(rows, np.arange(len(pairs)))
+    assert np.array_equal(tl.cpu().numpy(), t0) and np.abs(dl.cpu().numpy() - d0).max() < 1e-6
+    assert float(dl[target]) == thr and int(tl[target]) == 0

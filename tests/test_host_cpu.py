@@ -20,14 +20,6 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def native():
-    import __graft_entry__ as g
-    g.build()
-    from astroz_amd import _native
-    return _native
-
-
 def test_header_symbols_exported(native):
     hdr = open(os.path.join(ROOT, "include", "astroz_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
@@ -270,32 +262,6 @@ def test_synthetic_catalog_is_valid(orc):
     assert (cat.fields("isimp")[~cat.is_deep] == 1).sum() > 5   # simplified-drag branch too
     # deterministic
     assert synth.synth_catalog(50, 10, seed=4) == synth.synth_catalog(50, 10, seed=4)
-
-
-@pytest.fixture(scope="module")
-def emul():
-    """Host build of the device math headers (tests/host_emul/emul.cpp)."""
-    src = os.path.join(ROOT, "tests", "host_emul", "emul.cpp")
-    lib = os.path.join(ROOT, "tests", "host_emul", "libemul.so")
-    hdrs = [os.path.join(ROOT, "astroz_amd", "csrc", h) for h in ("devmath.h", "fields.h", "init_device.h", "propagate_device.h", "fast_step.h", "fast_step_f32.h")]
-    if not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in [src] + hdrs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-Wno-unknown-pragmas", "-o", lib, src])
-    E = C.CDLL(lib)
-    E.emul_init.restype = C.c_uint
-    E.emul_init.argtypes = [C.c_void_p] * 3
-    E.emul_propagate.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    E.emul_propagate_fast.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    E.emul_propagate_fast32.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-    E.emul_propagate_fast32p.argtypes = E.emul_propagate_fast32.argtypes
-    E.emul_propagate_deep_cached.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-    E.emul_sincos.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
-    E.emul_rcp.restype = C.c_double
-    E.emul_rcp.argtypes = [C.c_double]
-    E.emul_rsqrt.restype = C.c_double
-    E.emul_rsqrt.argtypes = [C.c_double]
-    E.emul_rotate.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
-    return E
 
 
 def test_device_math_kats(emul):

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from test_host_cpu import emul, _grav6  # noqa: F401  (fixture + helper)
+from test_host_cpu import _grav6  # noqa: F401  (helper; the emul fixture lives in conftest.py)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

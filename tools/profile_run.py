@@ -27,7 +27,7 @@ PMC_SETS = {
     "write": "WRITE_SIZE",
     "grbm": "GRBM_GUI_ACTIVE GRBM_COUNT",
 }
-KERNEL_PREFIXES = ("k_propagate", "k_rows", "k_tiles", "k_cols", "k_one", "k_deep", "k_prep", "k_classify")
+KERNEL_PREFIXES = ("k_propagate", "k_rows", "k_tiles", "k_cols", "k_one", "k_deep", "k_prep", "k_classify", "k_screen", "k_cells", "k_plan")
 
 
 def short(name):
@@ -96,7 +96,13 @@ def main():
         for k in sorted(set(k for k, _ in vals)):
             first = [v for (kk, _), v in vals.items() if kk == k][0]
             lines.append("kernel: %s" % k)
-            lines.append("  vgpr=%s sgpr=%s lds_bytes=%s scratch=%s grid=%s workgroup=%s" % first[3:])
+            # rocprofv3 reports the VGPR allocation of a wave64 kernel on gfx950 in units of TWO registers (k_rows_fast: 40 for
+            # the 74 -> 80 registers the ISA metadata shows): print the allocated count and the occupancy it
+            # allows (512 registers per SIMD lane, at most 8 waves)
+            vg = int(first[3] or 0) * 2
+            wps = min(8, 512 // vg) if vg else 8
+            lines.append("  vgpr_allocated=%d (rocprofv3 vgpr_count %s x 2) waves_per_simd=%d sgpr=%s lds_bytes=%s scratch=%s grid=%s workgroup=%s" % (
+                (vg, first[3], wps) + tuple(first[4:])))
             d = {}
             for (kk, c), v in sorted(vals.items()):
                 if kk == k:
@@ -104,7 +110,8 @@ def main():
                     lines.append("  %-28s per_dispatch=%-14.6g dispatches=%-3d avg_dur_us=%.2f" % (c, v[0] / v[1], v[1], v[2] / 1e3))
             kj = js["kernels"].setdefault(k, {})
             kj["pmc"] = d
-            kj["regs"] = dict(zip(("vgpr", "sgpr", "lds_bytes", "scratch", "grid", "workgroup"), first[3:]))
+            kj["regs"] = dict(zip(("vgpr_count_reported", "sgpr", "lds_bytes", "scratch", "grid", "workgroup"), first[3:]))
+            kj["regs"].update({"vgpr_allocated": vg, "waves_per_simd": wps})
             if "SQ_WAVES" in d and "SQ_INSTS_VALU" in d and d["SQ_WAVES"]:
                 lines.append("  derived: VALU instr per wave = %.0f" % (d["SQ_INSTS_VALU"] / d["SQ_WAVES"]))
             if "SQ_WAIT_ANY" in d and d.get("SQ_WAVE_CYCLES"):
