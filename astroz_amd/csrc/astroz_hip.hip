@@ -2260,6 +2260,33 @@ static int32_t azh_screen_target_host_impl(azh_constellation *c, const double *t
 {
     if (!c || !min_dist || !min_t) return AZ_ERR_NULL_POINTER;
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
+    // results of up to kSmallOut bytes (43,000 satellites): the finalisation kernel writes them into a pinned host buffer of the
+    // handle ITSELF (device-addressable, coherent) and one synchronize ends the call -- two pageable device-to-host copies of
+    // a hundred KB cost 15-20 us each behind a 0.18-ms screen
+    const size_t small_total = c->n * (sizeof(double) + sizeof(uint32_t)) + 64;
+    if (small_total <= kSmallOut) {
+        if (c->h_small_cap < small_total) {
+            HIP_TRY(hipStreamSynchronize(c->s_main));
+            if (c->h_small) (void)hipHostFree(c->h_small);
+            c->h_small = nullptr;
+            c->h_small_cap = 0;
+            size_t cap = 65536;
+            while (cap < small_total) cap *= 2;
+            HIP_TRY(hipHostMalloc(&c->h_small, cap, hipHostMallocDefault));
+            c->h_small_cap = cap;
+        }
+        double *hd = static_cast<double *>(c->h_small);
+        uint32_t *ht = reinterpret_cast<uint32_t *>(hd + ((c->n + 7) & ~size_t(7)));
+        double *dd = nullptr;
+        HIP_TRY(hipHostGetDevicePointer((void **)&dd, hd, 0));
+        uint32_t *dt = reinterpret_cast<uint32_t *>(dd + (reinterpret_cast<double *>(ht) - hd));
+        int32_t rc = azh_screen_target_device(c, times, n_times, offsets, target, threshold_km, reference_jd, dd, dt, nullptr);
+        if (rc != AZ_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(c->s_main));
+        memcpy(min_dist, hd, sizeof(double) * c->n);
+        memcpy(min_t, ht, sizeof(uint32_t) * c->n);
+        return AZ_OK;
+    }
     if (c->d_out_d.ensure(c->n) != AZ_OK || c->d_out_t.ensure(c->n) != AZ_OK) return AZ_ERR_HIP;
     int32_t rc = azh_screen_target_device(c, times, n_times, offsets, target, threshold_km, reference_jd, c->d_out_d.p,
                                           c->d_out_t.p, nullptr);
@@ -2299,28 +2326,44 @@ int32_t coarse_screen(const double *d_pos, size_t n_sats, size_t n_times, int32_
     while (bits < 24 && ((size_t)1 << bits) < 2 * n_sats) ++bits;
     const size_t table = (size_t)1 << bits;
     const unsigned chunk = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n_times, 64), ((size_t)1 << 25) / (table + n_sats)));
-    unsigned *d_head = nullptr, *d_next = nullptr, *d_pairs = nullptr, *d_t = nullptr;
-    unsigned long long *d_count = nullptr;
-    uint8_t *d_valid = nullptr;
+    // Scratch of the screen: grow-only buffers per device, kept between calls (round 6: five hipMalloc / hipFree pairs per call
+    // -- 16 MB of tables, and 120 MB of result space for the Python default of 10^7 results -- were 1 ms of a 1.8-ms call,
+    // profiles/r06_screen_all.txt).  One screen at a time per device (the mutex is held for the whole call).
+    int dev_id = 0;
+    HIP_TRY(hipGetDevice(&dev_id));
+    struct Scratch {
+        std::mutex mu;
+        DevBuf<unsigned> head, next, pairs, t;
+        DevBuf<unsigned long long> count;
+        DevBuf<uint8_t> valid;
+    };
+    static std::mutex table_mu;
+    static std::map<int, std::unique_ptr<Scratch>> per_device;
+    Scratch *S = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(table_mu);
+        auto &slot = per_device[dev_id];
+        if (!slot) slot.reset(new Scratch());
+        S = slot.get();
+    }
+    std::lock_guard<std::mutex> lock(S->mu);
     int32_t rc = AZ_OK;
     std::vector<uint32_t> hp, ht;
-    size_t cap = std::max<size_t>(max_results, 1 << 16);
+    // result space on the device: room for 2^20 pairs to begin with (a day of a 13,478-satellite catalog at 10 km: ~2,500); a
+    // screen that finds more runs once more with room for all of them
+    size_t cap = std::max<size_t>(std::min<size_t>(max_results, (size_t)1 << 20), 1 << 16);
     unsigned long long total = 0;
     do {
-        if (!hip_ok(hipMalloc((void **)&d_head, sizeof(unsigned) * table * chunk), "hipMalloc(head)") ||
-            !hip_ok(hipMalloc((void **)&d_next, sizeof(unsigned) * n_sats * chunk), "hipMalloc(next)") ||
-            !hip_ok(hipMalloc((void **)&d_count, sizeof(unsigned long long)), "hipMalloc(count)")) { rc = AZ_ERR_HIP; break; }
+        if (S->head.ensure(table * chunk) != AZ_OK || S->next.ensure(n_sats * chunk) != AZ_OK || S->count.ensure(1) != AZ_OK) { rc = AZ_ERR_HIP; break; }
+        uint8_t *d_valid = nullptr;
         if (valid_mask) {
-            if (!hip_ok(hipMalloc((void **)&d_valid, n_sats), "hipMalloc(valid)") ||
-                !hip_ok(hipMemcpyAsync(d_valid, valid_mask, n_sats, hipMemcpyHostToDevice, st), "H2D valid")) { rc = AZ_ERR_HIP; break; }
+            if (S->valid.ensure(n_sats) != AZ_OK ||
+                !hip_ok(hipMemcpyAsync(S->valid.p, valid_mask, n_sats, hipMemcpyHostToDevice, st), "H2D valid")) { rc = AZ_ERR_HIP; break; }
+            d_valid = S->valid.p;
         }
         for (int pass = 0; pass < 2 && rc == AZ_OK; ++pass) {
-            if (d_pairs) (void)hipFree(d_pairs);
-            if (d_t) (void)hipFree(d_t);
-            d_pairs = d_t = nullptr;
-            if (!hip_ok(hipMalloc((void **)&d_pairs, sizeof(unsigned) * 2 * cap), "hipMalloc(pairs)") ||
-                !hip_ok(hipMalloc((void **)&d_t, sizeof(unsigned) * cap), "hipMalloc(t)") ||
-                !hip_ok(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), st), "memset count")) { rc = AZ_ERR_HIP; break; }
+            if (S->pairs.ensure(2 * cap) != AZ_OK || S->t.ensure(cap) != AZ_OK ||
+                !hip_ok(hipMemsetAsync(S->count.p, 0, sizeof(unsigned long long), st), "memset count")) { rc = AZ_ERR_HIP; break; }
             CellArgs a{};
             a.pos = d_pos;
             a.n_sats = (unsigned)n_sats;
@@ -2331,24 +2374,25 @@ int32_t coarse_screen(const double *d_pos, size_t n_sats, size_t n_times, int32_
             a.inv_cell = 1.0 / threshold_km;
             a.thr2 = threshold_km * threshold_km;
             a.table_mask = (unsigned)(table - 1);
-            a.head = d_head;
-            a.next = d_next;
-            a.out_pairs = d_pairs;
-            a.out_t = d_t;
-            a.count = d_count;
+            a.head = S->head.p;
+            a.next = S->next.p;
+            a.out_pairs = S->pairs.p;
+            a.out_t = S->t.p;
+            a.count = S->count.p;
             a.max_results = cap;
             a.skip_zero = skip_zero;
             for (size_t t0 = 0; t0 < n_times && rc == AZ_OK; t0 += chunk) {
                 a.t0 = (unsigned)t0;
                 a.n_steps = (unsigned)std::min<size_t>(chunk, n_times - t0);
-                if (!hip_ok(hipMemsetAsync(d_head, 0xff, sizeof(unsigned) * table * a.n_steps, st), "memset head")) { rc = AZ_ERR_HIP; break; }
-                dim3 grid((unsigned)((n_sats + 255) / 256), a.n_steps);
+                if (!hip_ok(hipMemsetAsync(S->head.p, 0xff, sizeof(unsigned) * table * a.n_steps, st), "memset head")) { rc = AZ_ERR_HIP; break; }
+                // every step's workgroups on one XCD (az_cells_slot): 8 x groups x ceil(n_steps / 8) workgroups
+                dim3 grid(8u * (unsigned)((n_sats + 255) / 256) * ((a.n_steps + 7u) / 8u));
                 hipLaunchKernelGGL(k_cells_build, grid, dim3(256), 0, st, a);
                 hipLaunchKernelGGL(k_cells_probe, grid, dim3(256), 0, st, a);
                 if (!hip_ok(hipGetLastError(), "k_cells")) { rc = AZ_ERR_HIP; break; }
             }
             if (rc != AZ_OK) break;
-            if (!hip_ok(hipMemcpyAsync(&total, d_count, sizeof(total), hipMemcpyDeviceToHost, st), "D2H count") ||
+            if (!hip_ok(hipMemcpyAsync(&total, S->count.p, sizeof(total), hipMemcpyDeviceToHost, st), "D2H count") ||
                 !hip_ok(hipStreamSynchronize(st), "sync(screen)")) { rc = AZ_ERR_HIP; break; }
             if (total <= cap) break;
             cap = (size_t)total; // the result buffer overflowed: one more pass with room for everything
@@ -2358,8 +2402,9 @@ int32_t coarse_screen(const double *d_pos, size_t n_sats, size_t n_times, int32_
         hp.resize(2 * got);
         ht.resize(got);
         if (got) {
-            if (!hip_ok(hipMemcpy(hp.data(), d_pairs, sizeof(uint32_t) * 2 * got, hipMemcpyDeviceToHost), "D2H pairs") ||
-                !hip_ok(hipMemcpy(ht.data(), d_t, sizeof(uint32_t) * got, hipMemcpyDeviceToHost), "D2H t")) { rc = AZ_ERR_HIP; break; }
+            if (!hip_ok(hipMemcpyAsync(hp.data(), S->pairs.p, sizeof(uint32_t) * 2 * got, hipMemcpyDeviceToHost, st), "D2H pairs") ||
+                !hip_ok(hipMemcpyAsync(ht.data(), S->t.p, sizeof(uint32_t) * got, hipMemcpyDeviceToHost, st), "D2H t") ||
+                !hip_ok(hipStreamSynchronize(st), "sync(screen)")) { rc = AZ_ERR_HIP; break; }
         }
         std::vector<size_t> order(got);
         for (size_t i = 0; i < got; ++i) order[i] = i;
@@ -2377,12 +2422,6 @@ int32_t coarse_screen(const double *d_pos, size_t n_sats, size_t n_times, int32_
         *n_found = keep;
     } while (0);
     if (rc != AZ_OK) (void)hipStreamSynchronize(st);
-    if (d_head) (void)hipFree(d_head);
-    if (d_next) (void)hipFree(d_next);
-    if (d_pairs) (void)hipFree(d_pairs);
-    if (d_t) (void)hipFree(d_t);
-    if (d_count) (void)hipFree(d_count);
-    if (d_valid) (void)hipFree(d_valid);
     return rc;
 }
 } // namespace
@@ -2426,8 +2465,10 @@ static int32_t azh_screen_all_host_impl(azh_constellation *c, const double *time
     *n_found = 0;
     if (n_times == 0) return AZ_OK;
     if (set_device(c) != AZ_OK) return AZ_ERR_HIP;
-    double *d_pos = nullptr;
-    HIP_TRY(hipMalloc((void **)&d_pos, sizeof(double) * 3 * c->n * n_times));
+    // (the handle's grow-only result buffer: no 39-MB hipMalloc / hipFree pair per call)
+    if (c->d_host_pos.cap < 3 * c->n * n_times) HIP_TRY(hipStreamSynchronize(c->s_main));
+    if (c->d_host_pos.ensure(3 * c->n * n_times) != AZ_OK) return AZ_ERR_HIP;
+    double *d_pos = c->d_host_pos.p;
     int32_t rc = azh_propagate_device(c, times, n_times, offsets, d_pos, nullptr, AZ_OUT_TEME, 0.0, nullptr,
                                       AZ_LAYOUT_TIME_MAJOR, 0, nullptr, nullptr);
     // rows the propagator zero-filled (failed init, failed deep-space step) are skipped: a satellite
@@ -2436,7 +2477,6 @@ static int32_t azh_screen_all_host_impl(azh_constellation *c, const double *time
         rc = coarse_screen(d_pos, c->n, n_times, AZ_LAYOUT_TIME_MAJOR, 0, threshold_km, nullptr, out_pairs, out_t,
                            max_results, n_found, c->s_main, 1);
     (void)hipStreamSynchronize(c->s_main);
-    (void)hipFree(d_pos);
     return rc;
 }
 int32_t azh_screen_all_host(azh_constellation *c, const double *times, size_t n_times, const double *offsets,

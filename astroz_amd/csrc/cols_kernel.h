@@ -69,7 +69,7 @@ __device__ __forceinline__ double az_sload(const double *q)
 
 // grid: x = groups of 64 catalog rows (padded to a multiple of 8: XCD-aware, az_xcd_row), y = time segments of p.tile points
 template <bool VEL, int FRAME, int DELTA> // FRAME: 0 TEME, 1 ECEF, 2 geodetic positions (+ ECEF velocities); DELTA: 0 exact grid, 2 quasi-uniform (fp64 deviations)
-__global__ void __launch_bounds__(64, AZ_COLS_WAVES) k_cols_fast(PropArgs p)
+__global__ void __launch_bounds__(64, (FRAME == 2 && VEL) ? 2 : AZ_COLS_WAVES) k_cols_fast(PropArgs p) // (geodetic + velocities: 2 waves/SIMD, no spill)
 {
     constexpr unsigned NA = VEL ? 2u : 1u;
     __shared__ __attribute__((aligned(16))) double col_lds[CL_NUM * 64];

@@ -239,7 +239,9 @@ __device__ __forceinline__ void az_tm_flush(const double *L, double *row, size_t
 // FRAME = false: TEME output, no epilogue code at all (keeps its registers and SGPRs out of the
 // hot kernel); FRAME = true: ECEF / geodetic chosen at run time by p.mode.
 template <int LAYOUT, bool VEL, bool DEEP, bool FRAME, bool SCREEN = false>
-__global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (FRAME ? 1 : (DEEP ? AZ_DEEP_WAVES : 3)))) k_propagate(PropArgs p)
+// (round 6: the time-major deep-space instantiations -- grids shorter than 32 points only, everything longer takes k_rows_deep --
+// get a whole SIMD's registers: at two waves they spilled 12-28 bytes for nothing)
+__global__ void __launch_bounds__(AZ_BLOCK, (AZ_MIN_WAVES > 1 ? AZ_MIN_WAVES : (FRAME ? 1 : (DEEP ? (LAYOUT == 1 ? 1 : AZ_DEEP_WAVES) : 3)))) k_propagate(PropArgs p)
 {
     constexpr int WAVES = AZ_BLOCK / 64;
     // deep-space lists are never runs of consecutive rows: no time-major staging (LDS is needed for
@@ -2013,11 +2015,24 @@ __device__ __forceinline__ bool az_cell_of(const CellArgs &a, unsigned s, unsign
     return true;
 }
 
+// Workgroup -> (satellite group, step) with every STEP on ONE XCD (round 6): workgroups are dealt to the XCDs round-robin by their
+// flat index, so with a (groups, steps) grid every XCD touched every step's bucket table -- 60 tables x 256 KB per chunk -- and
+// none of them stayed in its 4-MB L2: k_cells_probe fetched 2.45 GB per dispatch for 38 MB of distinct data (profiles/
+// r06_screen_all.txt, first block).  Flat index f: XCD = f mod 8 takes steps k = 8 m + XCD, one after the other, so the tables
+// an XCD's L2 holds at any time are the one or two steps it is working on.  Grid: 8 * groups * ceil(n_steps / 8) workgroups.
+__device__ __forceinline__ bool az_cells_slot(const CellArgs &a, unsigned &s, unsigned &k)
+{
+    const unsigned groups = (a.n_sats + 255u) / 256u;
+    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    k = (j / groups) * 8u + xcd;
+    s = (j % groups) * 256u + threadIdx.x;
+    return k < a.n_steps && s < a.n_sats;
+}
+
 __global__ void __launch_bounds__(256) k_cells_build(CellArgs a)
 {
-    const unsigned s = blockIdx.x * 256 + threadIdx.x;
-    const unsigned k = blockIdx.y;
-    if (s >= a.n_sats) return;
+    unsigned s, k;
+    if (!az_cells_slot(a, s, k)) return;
     double r[3];
     int c[3];
     if (!az_cell_of(a, s, a.t0 + k, r, c)) return;
@@ -2027,9 +2042,8 @@ __global__ void __launch_bounds__(256) k_cells_build(CellArgs a)
 
 __global__ void __launch_bounds__(256) k_cells_probe(CellArgs a)
 {
-    const unsigned s = blockIdx.x * 256 + threadIdx.x;
-    const unsigned k = blockIdx.y;
-    if (s >= a.n_sats) return;
+    unsigned s, k;
+    if (!az_cells_slot(a, s, k)) return;
     const unsigned t = a.t0 + k;
     double r[3];
     int c[3];

@@ -279,7 +279,8 @@ def main():
     # sampled rows against the oracle on the rank's host cores, checksum + finiteness over everything it wrote; the certificates
     # travel to rank 0 as one small object.  N = 1 makes the same certificate without a group.
     per_rank = None
-    if (world > 1 or a.force_sharded) and mode == 0:
+    grouped = world > 1 or a.force_sharded
+    if (grouped or a.config5_share) and mode == 0:
         try:
             from bench_common import rank_certificate
             if sharded:
@@ -291,8 +292,10 @@ def main():
             mine = rank_certificate(torch, pairs, times, offsets, pos, vel, layout == _native.SAT_MAJOR, rank, threads=thr_)
         except Exception as exc:
             mine = {"rank": rank, "failed": repr(exc)}
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
+        per_rank = [mine]
+        if grouped:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
 
     # Every collective is behind us: all ranks leave the process group HERE, together, and ranks != 0 exit -- rank 0 does the rest
     # (group_host on all devices, oracle parity, the secondary block) alone, with no communicator alive and no peer process

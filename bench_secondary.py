@@ -180,6 +180,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             sa = SatrecArray([sat], device=cuda.index or 0)
             us_sa = wall(lambda: sa.sgp4(jd, fr), 200)
             us_one = wall(lambda: sat.sgp4(jd[0], fr[7]), 20000)
+            scalar_route = "host step" if sat._ensure().last_path() == _native.PATH_HOST_STEP else "kernel"
             # the same scalar call with the host route switched off (one launch + one synchronize per point: round 5's figure),
             # and the per-point cost of the host route as a function of the series length (where the two routes cross)
             n_host = _native.get_host_points()
@@ -211,7 +212,7 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             _, p0, v0 = cat.propagate(ts, None, layout=oracle.SAT_MAJOR)
             ent.update({"ms_per_step": us_arr / 1e3, "value": 1440 / (us_arr / 1e6), "unit": "propagations/s (Satrec.sgp4_array, host arrays)",
                         "sgp4_array_us": us_arr, "satrec_array_sgp4_us": us_sa, "scalar_sgp4_us": us_one,
-                        "scalar_sgp4_kernel_route_us": us_one_dev, "scalar_route": "host step" if sat._ensure().last_path() == _native.PATH_HOST_STEP else "kernel",
+                        "scalar_sgp4_kernel_route_us": us_one_dev, "scalar_route": scalar_route,
                         "scalar_binding": "CPython shim" if _native.fast_scalar() else "ctypes", "host_points": n_host,
                         "one_satellite_series_us": sweep,
                         "sgp4_array_fresh_grid_us": us_arr_fresh, "satrec_array_sgp4_fresh_grid_us": us_sa_fresh,

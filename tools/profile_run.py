@@ -2,6 +2,7 @@
 """rocprofv3 passes around one bench.py command, summarised on the GPU box at measurement time.
 
   tools/profile_run.py <name> [--pmc] [--steps K] -- <bench.py args>
+  tools/profile_run.py <name> [--pmc] --script tools/<probe>.py -- <probe args>     (any script instead of bench.py: the screens)
 
 Writes gpurun_out/profiles/<name>.txt (+ .json): the --kernel-trace --stats table (per kernel: calls, average, total,
 share) and, with --pmc, the counter passes of the MI355X guide (separate passes, never combined with traces): SQ
@@ -46,17 +47,26 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     os.makedirs(raw, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
+    script = own[own.index("--script") + 1] if "--script" in own else None
     bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-secondary"] + bench_args
     cmd_txt = "python bench.py --no-cpu-baseline --no-secondary " + " ".join(bench_args)
-    lines = ["# rocprofv3 summary: " + name, "# command: %s --steps %s --warmup 20" % (cmd_txt, steps), ""]
+    if script:
+        bench = [sys.executable, os.path.join(ROOT, script)] + bench_args
+        cmd_txt = "python %s %s" % (script, " ".join(bench_args))
+    tail_args = [] if script else ["--steps", steps, "--warmup", "20"]
+    pmc_args = ["--calls", "3"] if script else ["--steps", "3", "--warmup", "1", "--precondition-ms", "0"]
+    lines = ["# rocprofv3 summary: " + name, "# command: %s %s" % (cmd_txt, " ".join(tail_args)), ""]
     js = {"name": name, "command": cmd_txt, "kernels": {}}
     import bench_common as bench_mod
     js["csrc_sha16"] = bench_mod.csrc_fingerprint()
     lines.append("# csrc_sha16 (sources on the box at measurement time): " + js["csrc_sha16"])
     # ---- kernel trace
     r = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", os.path.join(raw, "trace"), "-o", "trace", "--"] + bench +
-                       ["--steps", steps, "--warmup", "20"], cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+                       tail_args, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
     bl = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if script:
+        lines += ["# " + ln for ln in r.stdout.splitlines() if ln.strip()][-8:]
+        bl = []
     if bl:
         j = json.loads(bl[-1])
         js["bench_under_trace"] = {"ms_per_step": j["ms_per_step"], "value": j["value"]}
@@ -70,13 +80,13 @@ def main():
             js["kernels"].setdefault(short(nm), {})["trace"] = {"calls": calls, "avg_us": avg, "total_us": tot, "pct": pct}
     # ---- counters
     if pmc:
-        lines += ["", "## rocprofv3 --pmc (separate passes of `--steps 3 --warmup 1 --precondition-ms 0`; per-dispatch averages)"]
+        lines += ["", "## rocprofv3 --pmc (separate passes of `%s`; per-dispatch averages)" % " ".join(pmc_args)]
         vals = {}
         for tag, counters in PMC_SETS.items():
             d = os.path.join(raw, "pmc_" + tag)
             try:
                 subprocess.run(["rocprofv3", "--pmc"] + counters.split() + ["-d", d, "-o", "pmc", "--"] + bench +
-                               ["--steps", "3", "--warmup", "1", "--precondition-ms", "0"], cwd="/tmp", env=env,
+                               pmc_args, cwd="/tmp", env=env,
                                capture_output=True, text=True, timeout=300)
             except subprocess.TimeoutExpired:
                 lines.append("# pass %s timed out" % tag)
@@ -123,7 +133,7 @@ def main():
                 lines.append("  derived: HBM read traffic  = %.1f MB/dispatch (2 x FETCH_SIZE KB x 1024: the guide's gfx950 correction)" % (
                     2 * d["FETCH_SIZE"] * 1024 / 1e6))
             lines.append("")
-        step_k = [k for k in js["kernels"] if "pmc" in js["kernels"][k] and k.startswith(("k_rows", "k_tiles", "k_cols", "k_propagate"))]
+        step_k = [k for k in js["kernels"] if "pmc" in js["kernels"][k] and k.startswith(("k_rows", "k_tiles", "k_cols", "k_propagate") + (("k_screen", "k_cells") if script else ()))]
         W = sum(js["kernels"][k]["pmc"].get("WRITE_SIZE", 0.0) for k in step_k)
         F = sum(js["kernels"][k]["pmc"].get("FETCH_SIZE", 0.0) for k in step_k)
         V = sum(js["kernels"][k]["pmc"].get("SQ_INSTS_VALU", 0.0) for k in step_k)
