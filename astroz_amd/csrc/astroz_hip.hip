@@ -2503,6 +2503,34 @@ static int32_t azh_propagate_host_impl(azh_constellation *c, const double *times
     // same bytes as the one-satellite path's (n_times, 3), so the call IS azh_propagate_one_host on tsince = times + offset -- one
     // kernel that reads its times from and writes into a pinned buffer, no staging of a grid, no increment / record / plan
     // kernels: 30 us whether the grid repeats or not (through the constellation launch set: 49 us repeated, 109 us on a fresh grid)
+    // A FEW satellites x a few times (SatrecArray of a handful of records at one instant, a c_api client's tiny batch): the host
+    // route of the one-satellite calls, satellite by satellite (host_step.h; the table of a handle of <= 64 satellites is
+    // mirrored on the host) -- no staging, no launch, no synchronize.  Cost counted in near-earth points (a deep-space point = 2).
+    if (c->n > 1 && !c->h_el.empty() && mode == AZ_OUT_TEME && mask == nullptr && host_points() > 0) {
+        size_t cost = 0;
+        for (size_t sidx = 0; sidx < c->n; ++sidx) cost += n_times * ((c->h_flags[sidx] & AZ_FLAG_DEEP) ? 2 : 1);
+        if (cost <= host_points()) {
+            std::vector<double> ts(n_times), p(3 * n_times), v(3 * n_times);
+            std::vector<uint8_t> e(n_times);
+            for (size_t sidx = 0; sidx < c->n; ++sidx) {
+                const double o = offsets ? offsets[sidx] : 0.0;
+                for (size_t t = 0; t < n_times; ++t) ts[t] = times[t] + o;
+                azhost::propagate_points(c->h_el.data(), c->n_pad, sidx, c->h_flags[sidx], c->g, ts.data(), n_times, 0, nullptr, p.data(),
+                                         vel ? v.data() : nullptr, e.data());
+                for (size_t t = 0; t < n_times; ++t) {
+                    const size_t at = (layout == AZ_LAYOUT_TIME_MAJOR ? t * stride + sidx : sidx * n_times + t) * 3;
+                    memcpy(pos + at, &p[3 * t], 3 * sizeof(double));
+                    if (vel) memcpy(vel + at, &v[3 * t], 3 * sizeof(double));
+                    if (err) err[sidx * n_times + t] = e[t];
+                }
+            }
+            c->last_path = AZH_PATH_HOST_STEP;
+            c->cached_n_times = 0; // (nothing is staged on this route)
+            c->staged_valid = false;
+            c->timed = false;
+            return AZ_OK;
+        }
+    }
     if (c->n == 1 && mode == AZ_OUT_TEME && mask == nullptr && (layout == AZ_LAYOUT_SAT_MAJOR || stride <= 1) && n_times <= kOneStage &&
         AZ_FLAG_ERR(c->h_flags[0]) == 0) {
         std::vector<double> ts(times, times + n_times);

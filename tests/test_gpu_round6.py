@@ -325,3 +325,38 @@ def test_screen_against_external_track_and_sharded_screen_single_rank(native, or
     assert np.array_equal(rows, np.arange(len(pairs)))
     assert np.array_equal(tl.cpu().numpy(), t0) and np.abs(dl.cpu().numpy() - d0).max() < 1e-6
     assert float(dl[target]) == thr and int(tl[target]) == 0
+
+
+def test_few_satellites_few_times_take_the_host_route(native, orc, synth):
+    """azh_propagate_host on a handle of a few satellites x a few times (SatrecArray of a handful of records at one instant):
+    the host route satellite by satellite -- oracle parity incl. error codes of a failed member, both layouts, pos-only; one
+    point over the budget launches the kernels."""
+    pairs = synth.synth_catalog(n_near=5, n_deep=2, seed=13)
+    bad1 = "1 28350U 04020A   06167.21788666  .16154492  76267-5  18678-3 0  8894"       # decays within a day
+    bad2 = "2 28350  64.9977 345.6130 0024870 260.7578  99.9590 16.47856722116490"
+    pairs = pairs[:3] + [(bad1, bad2)] + pairs[3:]
+    dev = native.DeviceConstellation.from_tle_lines(pairs, native.WGS72, 0)
+    cat = orc.Catalog.from_pairs(pairs, orc.WGS72)
+    n = dev.n
+    off = np.linspace(-50.0, 50.0, n)
+    for n_t in (1, 7, 12):
+        times = np.linspace(0.0, 2900.0, n_t)
+        for layout, olay, shape in ((native.TIME_MAJOR, orc.TIME_MAJOR, (n_t, n, 3)), (native.SAT_MAJOR, orc.SAT_MAJOR, (n, n_t, 3))):
+            pos, vel = np.full(shape, np.nan), np.full(shape, np.nan)
+            err = np.full((n, n_t), 9, dtype=np.uint8)
+            dev.propagate_host(times, off, pos=pos, vel=vel, err=err, layout=layout)
+            assert dev.last_path() == native.PATH_HOST_STEP, n_t
+            e0, p0, v0 = cat.propagate(times, off, layout=olay)
+            assert np.array_equal(err, e0)
+            assert np.abs(pos - p0).max() < TOL_R and np.abs(vel - v0).max() < TOL_V
+        pos = np.full((n, n_t, 3), np.nan)
+        dev.propagate_host(times, None, pos=pos, layout=native.SAT_MAJOR)
+        _, p0, _ = cat.propagate(times, None, layout=orc.SAT_MAJOR, velocities=False)
+        assert np.abs(pos - p0).max() < TOL_R
+    assert (cat.propagate(np.linspace(0.0, 2900.0, 12), off, layout=orc.SAT_MAJOR)[0] != 0).any()      # (the decayed member did fail)
+    times = np.linspace(0.0, 1440.0, 20)          # 8 x 20 points (+ deep-space weight) > 128: the kernels
+    pos = np.empty((n, 20, 3))
+    dev.propagate_host(times, off, pos=pos, layout=native.SAT_MAJOR)
+    assert dev.last_path() != native.PATH_HOST_STEP
+    _, p0, _ = cat.propagate(times, off, layout=orc.SAT_MAJOR, velocities=False)
+    assert np.abs(pos - p0).max() < TOL_R
