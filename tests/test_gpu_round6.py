@@ -329,34 +329,53 @@ def test_screen_against_external_track_and_sharded_screen_single_rank(native, or
 
 def test_few_satellites_few_times_take_the_host_route(native, orc, synth):
     """azh_propagate_host on a handle of a few satellites x a few times (SatrecArray of a handful of records at one instant):
-    the host route satellite by satellite -- oracle parity incl. error codes of a failed member, both layouts, pos-only; one
-    point over the budget launches the kernels."""
+    the host route satellite by satellite -- oracle parity, a member whose initialisation failed (zeros + its code at every
+    time, as the kernels write it), both layouts, pos-only; one point over the budget launches the kernels."""
     pairs = synth.synth_catalog(n_near=5, n_deep=2, seed=13)
-    bad1 = "1 28350U 04020A   06167.21788666  .16154492  76267-5  18678-3 0  8894"       # decays within a day
-    bad2 = "2 28350  64.9977 345.6130 0024870 260.7578  99.9590 16.47856722116490"
-    pairs = pairs[:3] + [(bad1, bad2)] + pairs[3:]
+    bad = synth.format_tle(99999, synth.START_JD - 1.0, 51.0, 10.0, 0.3, 20.0, 30.0, 15.9, 1e-4)     # perigee below the surface
+    pairs = pairs[:3] + [bad] + pairs[3:]
     dev = native.DeviceConstellation.from_tle_lines(pairs, native.WGS72, 0)
     cat = orc.Catalog.from_pairs(pairs, orc.WGS72)
     n = dev.n
+    code = int(dev.status[0][3])
+    assert code != 0 and cat.init_rc[3] != 0
+    good = np.arange(n) != 3
     off = np.linspace(-50.0, 50.0, n)
     for n_t in (1, 7, 12):
         times = np.linspace(0.0, 2900.0, n_t)
-        for layout, olay, shape in ((native.TIME_MAJOR, orc.TIME_MAJOR, (n_t, n, 3)), (native.SAT_MAJOR, orc.SAT_MAJOR, (n, n_t, 3))):
+        e0, p0, v0 = cat.propagate(times, off, layout=orc.SAT_MAJOR)
+        for layout, shape in ((native.TIME_MAJOR, (n_t, n, 3)), (native.SAT_MAJOR, (n, n_t, 3))):
             pos, vel = np.full(shape, np.nan), np.full(shape, np.nan)
             err = np.full((n, n_t), 9, dtype=np.uint8)
             dev.propagate_host(times, off, pos=pos, vel=vel, err=err, layout=layout)
             assert dev.last_path() == native.PATH_HOST_STEP, n_t
-            e0, p0, v0 = cat.propagate(times, off, layout=olay)
-            assert np.array_equal(err, e0)
-            assert np.abs(pos - p0).max() < TOL_R and np.abs(vel - v0).max() < TOL_V
+            if layout == native.TIME_MAJOR:
+                pos, vel = pos.transpose(1, 0, 2), vel.transpose(1, 0, 2)
+            assert np.array_equal(err[good], e0[good]) and (err[3] == code).all()
+            assert not pos[3].any() and not vel[3].any()
+            assert np.abs(pos[good] - p0[good]).max() < TOL_R and np.abs(vel[good] - v0[good]).max() < TOL_V
         pos = np.full((n, n_t, 3), np.nan)
         dev.propagate_host(times, None, pos=pos, layout=native.SAT_MAJOR)
-        _, p0, _ = cat.propagate(times, None, layout=orc.SAT_MAJOR, velocities=False)
-        assert np.abs(pos - p0).max() < TOL_R
-    assert (cat.propagate(np.linspace(0.0, 2900.0, 12), off, layout=orc.SAT_MAJOR)[0] != 0).any()      # (the decayed member did fail)
+        _, q0, _ = cat.propagate(times, None, layout=orc.SAT_MAJOR, velocities=False)
+        assert np.abs(pos[good] - q0[good]).max() < TOL_R
+    # the same call through the kernels (route off): the same bytes for the failed member, rounding apart elsewhere
+    times = np.linspace(0.0, 2900.0, 7)
+    ph, vh = np.empty((n, 7, 3)), np.empty((n, 7, 3))
+    eh = np.zeros((n, 7), dtype=np.uint8)
+    dev.propagate_host(times, off, pos=ph, vel=vh, err=eh, layout=native.SAT_MAJOR)
+    n0 = native.get_host_points()
+    native.set_host_points(0)
+    try:
+        pk, vk = np.empty((n, 7, 3)), np.empty((n, 7, 3))
+        ek = np.zeros((n, 7), dtype=np.uint8)
+        dev.propagate_host(times, off, pos=pk, vel=vk, err=ek, layout=native.SAT_MAJOR)
+        assert dev.last_path() != native.PATH_HOST_STEP
+    finally:
+        native.set_host_points(n0)
+    assert np.array_equal(eh, ek) and np.abs(ph - pk).max() < 1e-8 and np.abs(vh - vk).max() < 1e-11
     times = np.linspace(0.0, 1440.0, 20)          # 8 x 20 points (+ deep-space weight) > 128: the kernels
     pos = np.empty((n, 20, 3))
     dev.propagate_host(times, off, pos=pos, layout=native.SAT_MAJOR)
     assert dev.last_path() != native.PATH_HOST_STEP
-    _, p0, _ = cat.propagate(times, off, layout=orc.SAT_MAJOR, velocities=False)
-    assert np.abs(pos - p0).max() < TOL_R
+    _, q0, _ = cat.propagate(times, off, layout=orc.SAT_MAJOR, velocities=False)
+    assert np.abs(pos[good] - q0[good]).max() < TOL_R
