@@ -60,8 +60,8 @@ def sharded_screen(torch, dist, _native, synth, a, allp, plan_world, rank, times
     (Constellation.screenConstellation, src/Constellation.zig L683-756) with the catalog sharded block-cyclically over the ranks
     (astroz_amd.distributed.ShardedScreen): every rank computes the target's track itself and screens ITS rows, no collective
     inside the step; timed like the headline (barrier, HIP events on the launch stream, max over ranks).  `value` = satellites
-    x grid points screened per second over all ranks.  Checked: every rank's rows against the oracle's screen of the whole
-    catalog (grid indices equal, distances to 1e-6 km), gathered to rank 0 as one small object."""
+    x grid points screened per second over all ranks.  Checked: every rank's rows against the oracle's screen of THOSE rows and the
+    target (grid indices equal, distances to 1e-6 km), gathered to rank 0 as one small object."""
     from astroz_amd.distributed import ShardedConstellation, ShardedScreen
     world = plan_world
     n_total = len(allp)
@@ -72,8 +72,11 @@ def sharded_screen(torch, dist, _native, synth, a, allp, plan_world, rank, times
         if d is not None:
             d.set_timing(False)
     from oracle import oracle
-    ref = oracle.Catalog.from_pairs(allp, oracle.WGS72)
-    off = (synth.START_JD - ref.epoch_jd) * 1440.0
+    import numpy as np
+    from astroz_amd import synth as _synth
+    # offsets of the whole catalog from the element sets' epochs (host-side text parsing only)
+    epochs = np.array([oracle.parse_lines(a_, b_).epoch_jd for a_, b_ in allp])
+    off = (_synth.START_JD - epochs) * 1440.0
     scr = ShardedScreen(sh, target, tgt, times, off, thr, device=cuda)
     run = lambda: scr.step(stream=sptr)
     for _ in range(max(5, a.warmup // 4)):
@@ -81,8 +84,14 @@ def sharded_screen(torch, dist, _native, synth, a, allp, plan_world, rank, times
     ms = _timed(torch, dist, run, a.steps, stream, cuda)
     rows, dl, tl = scr.local_results()
     torch.cuda.synchronize()
-    d0, t0 = ref.screen_target(times, target, thr, off)
-    mine = {"rank": rank, "rows": int(len(rows)), "index_mismatches": int((tl.cpu().numpy().astype("int64") != t0[rows].astype("int64")).sum()),
+    # the oracle's screen of THIS rank's rows against the target (sub-catalog: the target first, then the rank's other rows)
+    others = np.array([r for r in rows if r != target], dtype=np.int64)
+    sub = oracle.Catalog.from_pairs([allp[target]] + [allp[i] for i in others], oracle.WGS72)
+    d_sub, t_sub = sub.screen_target(times, 0, thr, np.concatenate([[off[target]], off[others]]))
+    d0 = np.full(n_total, thr)
+    t0 = np.zeros(n_total, dtype=np.int64)
+    d0[others], t0[others] = d_sub[1:], t_sub[1:]
+    mine = {"rank": rank, "rows": int(len(rows)), "index_mismatches": int((tl.cpu().numpy().astype("int64") != t0[rows]).sum()),
             "max_dd_km": float(abs(dl.cpu().numpy() - d0[rows]).max()) if len(rows) else 0.0,
             "closer_than_threshold": int((dl.cpu().numpy() < thr).sum())}
     certs = [None] * dist.get_world_size()
