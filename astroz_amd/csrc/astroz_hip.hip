@@ -2333,7 +2333,7 @@ int32_t coarse_screen(const double *d_pos, size_t n_sats, size_t n_times, int32_
     HIP_TRY(hipGetDevice(&dev_id));
     struct Scratch {
         std::mutex mu;
-        DevBuf<unsigned> head, next, pairs, t;
+        DevBuf<unsigned> head, occupied, next, pairs, t;
         DevBuf<unsigned long long> count;
         DevBuf<uint8_t> valid;
     };
@@ -2354,7 +2354,8 @@ int32_t coarse_screen(const double *d_pos, size_t n_sats, size_t n_times, int32_
     size_t cap = std::max<size_t>(std::min<size_t>(max_results, (size_t)1 << 20), 1 << 16);
     unsigned long long total = 0;
     do {
-        if (S->head.ensure(table * chunk) != AZ_OK || S->next.ensure(n_sats * chunk) != AZ_OK || S->count.ensure(1) != AZ_OK) { rc = AZ_ERR_HIP; break; }
+        if (S->head.ensure(table * chunk) != AZ_OK || S->occupied.ensure(table / 32 * chunk) != AZ_OK || S->next.ensure(n_sats * chunk) != AZ_OK ||
+            S->count.ensure(1) != AZ_OK) { rc = AZ_ERR_HIP; break; }
         uint8_t *d_valid = nullptr;
         if (valid_mask) {
             if (S->valid.ensure(n_sats) != AZ_OK ||
@@ -2375,6 +2376,7 @@ int32_t coarse_screen(const double *d_pos, size_t n_sats, size_t n_times, int32_
             a.thr2 = threshold_km * threshold_km;
             a.table_mask = (unsigned)(table - 1);
             a.head = S->head.p;
+            a.occupied = S->occupied.p;
             a.next = S->next.p;
             a.out_pairs = S->pairs.p;
             a.out_t = S->t.p;
@@ -2388,7 +2390,8 @@ int32_t coarse_screen(const double *d_pos, size_t n_sats, size_t n_times, int32_
                 // every step's workgroups on one XCD (az_cells_slot): 8 x groups x ceil(n_steps / 8) workgroups
                 dim3 grid(8u * (unsigned)((n_sats + 255) / 256) * ((a.n_steps + 7u) / 8u));
                 hipLaunchKernelGGL(k_cells_build, grid, dim3(256), 0, st, a);
-                hipLaunchKernelGGL(k_cells_probe, grid, dim3(256), 0, st, a);
+                hipLaunchKernelGGL(k_cells_bits, dim3((unsigned)(table * a.n_steps / 256)), dim3(256), 0, st, S->head.p, S->occupied.p, table * a.n_steps);
+                hipLaunchKernelGGL(k_cells_probe, grid, dim3(256), (table / 32 <= AZ_CELL_BITMAP_WORDS) ? (unsigned)(table / 32 * sizeof(unsigned)) : 0u, st, a);
                 if (!hip_ok(hipGetLastError(), "k_cells")) { rc = AZ_ERR_HIP; break; }
             }
             if (rc != AZ_OK) break;

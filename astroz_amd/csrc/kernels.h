@@ -1975,6 +1975,7 @@ struct CellArgs {
     unsigned t0, n_steps; // chunk of time steps
     unsigned table_mask;  // buckets per step - 1
     unsigned *head;       // [n_steps][table]
+    unsigned *occupied;   // [n_steps][table / 32]: one bit per bucket that holds at least one satellite (round 6)
     unsigned *next;       // [n_steps][n_sats]
     unsigned *out_pairs;  // [max][2]
     unsigned *out_t;      // [max]
@@ -2040,21 +2041,59 @@ __global__ void __launch_bounds__(256) k_cells_build(CellArgs a)
     a.next[(size_t)k * a.n_sats + s] = atomicExch(&a.head[(size_t)k * (a.table_mask + 1u) + h], s);
 }
 
+// the occupancy bitmap of a chunk's bucket tables: one lane per bucket, one ballot per wave, two words per wave (an atomicOr per
+// satellite in k_cells_build doubled that kernel: 6.6 inserts per 32-bucket word)
+__global__ void __launch_bounds__(256) k_cells_bits(const unsigned *__restrict__ head, unsigned *__restrict__ occupied, size_t n_buckets)
+{
+    const size_t b = (size_t)blockIdx.x * 256 + threadIdx.x; // (n_buckets is a multiple of 2^16)
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(b < n_buckets && head[b] != 0xffffffffu);
+    if ((threadIdx.x & 63u) == 0 && b < n_buckets) {
+        occupied[b >> 5] = (unsigned)m;
+        occupied[(b >> 5) + 1] = (unsigned)(m >> 32);
+    }
+}
+
+// AZ_CELL_BITMAP_WORDS: the largest occupancy bitmap a workgroup stages in LDS (2^18 buckets = 32 KB); larger tables (catalogs
+// beyond 131,072 satellites) read the bitmap words from global memory instead
+#define AZ_CELL_BITMAP_WORDS 8192u
 __global__ void __launch_bounds__(256) k_cells_probe(CellArgs a)
 {
+    // Round 6: the step's occupancy bitmap (one bit per bucket, 8 KB for 2^16 buckets) is staged in LDS first.  A satellite probes
+    // 27 buckets and in a sparse shell four in five of them are empty: the bit test answers those from LDS, and only occupied
+    // buckets cost a dependent random read of the head table (profiles/r06_experiments.txt D).
+    extern __shared__ unsigned bits[]; // (dynamic: table / 32 words when the table is staged, nothing otherwise)
+    const unsigned words = (a.table_mask + 1u) >> 5;
+    const bool staged = words <= AZ_CELL_BITMAP_WORDS;
     unsigned s, k;
-    if (!az_cells_slot(a, s, k)) return;
+    {
+        // (every thread of the workgroup takes part in the staging, also those beyond the catalog)
+        const unsigned groups = (a.n_sats + 255u) / 256u;
+        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        k = (j / groups) * 8u + xcd;
+        s = (j % groups) * 256u + threadIdx.x;
+        if (k >= a.n_steps) return; // (uniform per workgroup)
+        if (staged) {
+            const unsigned *src = a.occupied + (size_t)k * words;
+            for (unsigned w = threadIdx.x; w < words; w += 256u) bits[w] = src[w];
+            __syncthreads();
+        }
+    }
+    if (s >= a.n_sats) return;
     const unsigned t = a.t0 + k;
     double r[3];
     int c[3];
     if (!az_cell_of(a, s, t, r, c)) return;
     const unsigned *head = a.head + (size_t)k * (a.table_mask + 1u);
     const unsigned *next = a.next + (size_t)k * a.n_sats;
+    const unsigned *occ = a.occupied + (size_t)k * words;
     for (int dx = -1; dx <= 1; ++dx)
         for (int dy = -1; dy <= 1; ++dy)
             for (int dz = -1; dz <= 1; ++dz) {
                 const int nx = c[0] + dx, ny = c[1] + dy, nz = c[2] + dz;
-                unsigned idx = head[az_cell_hash(nx, ny, nz) & a.table_mask];
+                const unsigned h = az_cell_hash(nx, ny, nz) & a.table_mask;
+                const unsigned word = staged ? bits[h >> 5] : occ[h >> 5];
+                if (!((word >> (h & 31u)) & 1u)) continue; // an empty bucket
+                unsigned idx = head[h];
                 while (idx != 0xffffffffu) {
                     const unsigned other = idx;
                     idx = next[other];

@@ -63,42 +63,60 @@ def sharded_screen(torch, dist, _native, synth, a, allp, plan_world, rank, times
     x grid points screened per second over all ranks.  Checked: every rank's rows against the oracle's screen of THOSE rows and the
     target (grid indices equal, distances to 1e-6 km), gathered to rank 0 as one small object."""
     from astroz_amd.distributed import ShardedConstellation, ShardedScreen
+    import numpy as np
+    from oracle import oracle
     world = plan_world
     n_total = len(allp)
     target, thr = n_total // 3, 50.0
-    sh = ShardedConstellation(allp, _native.WGS72, rank=rank, world_size=world, local_rank=local_rank, n_chunks=1)
-    tgt = _native.DeviceConstellation.from_tle_lines([allp[target]], _native.WGS72, local_rank)
-    for d in (sh.dev, tgt):
-        if d is not None:
-            d.set_timing(False)
-    from oracle import oracle
-    import numpy as np
-    from astroz_amd import synth as _synth
-    # offsets of the whole catalog from the element sets' epochs (host-side text parsing only)
-    epochs = np.array([oracle.parse_lines(a_, b_).epoch_jd for a_, b_ in allp])
-    off = (_synth.START_JD - epochs) * 1440.0
-    scr = ShardedScreen(sh, target, tgt, times, off, thr, device=cuda)
-    run = lambda: scr.step(stream=sptr)
-    for _ in range(max(5, a.warmup // 4)):
-        run()
-    ms = _timed(torch, dist, run, a.steps, stream, cuda)
-    rows, dl, tl = scr.local_results()
-    torch.cuda.synchronize()
-    # the oracle's screen of THIS rank's rows against the target (sub-catalog: the target first, then the rank's other rows)
-    others = np.array([r for r in rows if r != target], dtype=np.int64)
-    sub = oracle.Catalog.from_pairs([allp[target]] + [allp[i] for i in others], oracle.WGS72)
-    d_sub, t_sub = sub.screen_target(times, 0, thr, np.concatenate([[off[target]], off[others]]))
-    d0 = np.full(n_total, thr)
-    t0 = np.zeros(n_total, dtype=np.int64)
-    d0[others], t0[others] = d_sub[1:], t_sub[1:]
-    mine = {"rank": rank, "rows": int(len(rows)), "index_mismatches": int((tl.cpu().numpy().astype("int64") != t0[rows]).sum()),
-            "max_dd_km": float(abs(dl.cpu().numpy() - d0[rows]).max()) if len(rows) else 0.0,
-            "closer_than_threshold": int((dl.cpu().numpy() < thr).sum())}
+    # Every rank reaches every collective below whatever happens on it: a failure anywhere is agreed on FIRST (one all_reduce),
+    # and then all ranks skip the timed part together -- an exception on one rank must not leave the others in a barrier.
+    err, scr, off = None, None, None
+    try:
+        sh = ShardedConstellation(allp, _native.WGS72, rank=rank, world_size=world, local_rank=local_rank, n_chunks=1)
+        tgt = _native.DeviceConstellation.from_tle_lines([allp[target]], _native.WGS72, local_rank)
+        for d in (sh.dev, tgt):
+            if d is not None:
+                d.set_timing(False)
+        # offsets of the whole catalog from the element sets' epochs (host-side text parsing only)
+        epochs = np.array([oracle.parse_lines(a_, b_).epoch_jd for a_, b_ in allp])
+        off = (synth.START_JD - epochs) * 1440.0
+        scr = ShardedScreen(sh, target, tgt, times, off, thr, device=cuda)
+        for _ in range(max(5, a.warmup // 4)):
+            scr.step(stream=sptr)
+        torch.cuda.synchronize()
+    except Exception as exc:
+        err = repr(exc)
+    ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=cuda)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok[0]) == 0:
+        return {"failed": err or "another rank failed during set-up"}
+    ms = _timed(torch, dist, lambda: scr.step(stream=sptr), a.steps, stream, cuda)
+    try:
+        rows, dl, tl = scr.local_results()
+        torch.cuda.synchronize()
+        # the oracle's screen of THIS rank's rows against the target (sub-catalog: the target first, then the rank's other rows)
+        others = np.array([r for r in rows if r != target], dtype=np.int64)
+        sub = oracle.Catalog.from_pairs([allp[target]] + [allp[i] for i in others], oracle.WGS72)
+        d_sub, t_sub = sub.screen_target(times, 0, thr, np.concatenate([[off[target]], off[others]]))
+        d0 = np.full(n_total, thr)
+        t0 = np.zeros(n_total, dtype=np.int64)
+        d0[others], t0[others] = d_sub[1:], t_sub[1:]
+        mine = {"rank": rank, "rows": int(len(rows)), "index_mismatches": int((tl.cpu().numpy().astype("int64") != t0[rows]).sum()),
+                "max_dd_km": float(abs(dl.cpu().numpy() - d0[rows]).max()) if len(rows) else 0.0,
+                "closer_than_threshold": int((dl.cpu().numpy() < thr).sum())}
+    except Exception as exc:
+        mine = {"rank": rank, "failed": repr(exc)}
     certs = [None] * dist.get_world_size()
     dist.all_gather_object(certs, mine)
-    return {"ms": ms, "value": n_total * len(times) / (ms / 1e3), "unit": "satellite-steps screened/s", "target_row": target, "threshold_km": thr,
-            "index_mismatches": sum(c["index_mismatches"] for c in certs), "max_dd_km": max(c["max_dd_km"] for c in certs), "per_rank": certs,
-            "what": "fused single-target screen, catalog sharded block-cyclically, target track computed on every rank, no collective in the step"}
+    good = [c for c in certs if isinstance(c, dict) and "failed" not in c]
+    res = {"ms": ms, "value": n_total * len(times) / (ms / 1e3), "unit": "satellite-steps screened/s", "target_row": target, "threshold_km": thr,
+           "per_rank": certs,
+           "what": "fused single-target screen, catalog sharded block-cyclically, target track computed on every rank, no collective in the step"}
+    if len(good) == len(certs):
+        res.update({"index_mismatches": sum(c["index_mismatches"] for c in good), "max_dd_km": max(c["max_dd_km"] for c in good)})
+    else:
+        res["check_failed_on_ranks"] = [c.get("rank") for c in certs if isinstance(c, dict) and "failed" in c]
+    return res
 
 
 def group_host(_native, synth, allp, world, local_rank, times, vel_on, n_total, n_times):
