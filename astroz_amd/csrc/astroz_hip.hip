@@ -3102,9 +3102,9 @@ int32_t group_screen(azh_group *g, const double *times, size_t n_times, const do
     if (owner < 0) return AZ_ERR_VALUE;
     int32_t rc = AZ_OK;
     auto shard_offsets = [&](int d) -> const double * {
-        if (!offsets) return nullptr;
-        std::vector<double> &off = g->off_stage[d];
         azh_constellation *c = g->shard[d];
+        if (!offsets || !c) return nullptr;
+        std::vector<double> &off = g->off_stage[d];
         off.resize(c->n);
         for (size_t i = 0; i < c->n; ++i) off[i] = offsets[g->members[d][i]];
         return off.data();
@@ -3125,50 +3125,80 @@ int32_t group_screen(azh_group *g, const double *times, size_t n_times, const do
         HIP_TRY(hipMemcpyAsync(track.data(), c->d_tgt.p, sizeof(double) * track.size(), hipMemcpyDeviceToHost, c->s_main));
         HIP_TRY(hipStreamSynchronize(c->s_main));
     }
-    // ... then every device screens its own rows (all launches asynchronous: the devices run side by side)
-    for (int d = 0; d < g->n_dev && rc == AZ_OK; ++d) {
+    // ... then every device screens its own rows.  One host thread per device (N > 1): a screen is half a dozen launches of a few
+    // microseconds each, and issued from ONE thread the eighth device would start 0.2 ms after the first -- longer than its
+    // whole share takes (1,685 rows: ~30 us of kernels).  Each thread stages, launches, and (host results) copies its cells
+    // into the caller's catalog-ordered arrays and waits for its own device.
+    std::vector<int32_t> rcs(g->n_dev, AZ_OK);
+    for (int d = 0; d < g->n_dev; ++d) (void)shard_offsets(d); // (fills g->off_stage[d] on this thread: no allocation races below)
+    auto work = [&](int d) -> int32_t {
         azh_constellation *c = g->shard[d];
-        if (!c) continue;
-        if (set_device(c) != AZ_OK) { rc = AZ_ERR_HIP; break; }
+        if (!c) return AZ_OK;
+        if (hipSetDevice(c->device) != hipSuccess) return AZ_ERR_HIP;
         double *out_d = d_min_dist ? d_min_dist[d] : nullptr;
         uint32_t *out_t = d_min_t ? d_min_t[d] : nullptr;
         if (!out_d || !out_t) {
-            if (c->d_out_d.ensure(c->n) != AZ_OK || c->d_out_t.ensure(c->n) != AZ_OK) { rc = AZ_ERR_HIP; break; }
+            if (c->d_out_d.ensure(c->n) != AZ_OK || c->d_out_t.ensure(c->n) != AZ_OK) return AZ_ERR_HIP;
             out_d = c->d_out_d.p;
             out_t = c->d_out_t.p;
         }
-        const double *off_d = shard_offsets(d);
+        const double *off_d = offsets ? g->off_stage[d].data() : nullptr;
+        int32_t r = AZ_OK;
         if (d == owner) {
-            rc = screen_core(c, times, n_times, off_d, t_local, nullptr, threshold_km, out_d, out_t, nullptr);
+            r = screen_core(c, times, n_times, off_d, t_local, nullptr, threshold_km, out_d, out_t, nullptr);
         } else {
             if (nt > 0) {
-                if (c->d_tgt.ensure((size_t)nt * 3) != AZ_OK) { rc = AZ_ERR_HIP; break; }
-                if (!hip_ok(hipMemcpyAsync(c->d_tgt.p, track.data(), sizeof(double) * track.size(), hipMemcpyHostToDevice, c->s_main), "H2D track")) { rc = AZ_ERR_HIP; break; }
+                if (c->d_tgt.ensure((size_t)nt * 3) != AZ_OK) return AZ_ERR_HIP;
+                if (hipMemcpyAsync(c->d_tgt.p, track.data(), sizeof(double) * track.size(), hipMemcpyHostToDevice, c->s_main) != hipSuccess) return AZ_ERR_HIP;
             }
-            rc = screen_core(c, times, n_times, off_d, kNoTarget, c->d_tgt.p, threshold_km, out_d, out_t, nullptr);
+            r = screen_core(c, times, n_times, off_d, kNoTarget, c->d_tgt.p, threshold_km, out_d, out_t, nullptr);
         }
-    }
-    // host results: a cell = consecutive catalog rows = consecutive local rows, one small copy per cell and array
-    if (rc == AZ_OK && h_min_dist && h_min_t) {
-        for (int d = 0; d < g->n_dev && rc == AZ_OK; ++d) {
-            azh_constellation *c = g->shard[d];
-            if (!c) continue;
-            if (set_device(c) != AZ_OK) { rc = AZ_ERR_HIP; break; }
+        if (r != AZ_OK) return r;
+        if (h_min_dist && h_min_t) {
+            // host results: a cell = consecutive catalog rows = consecutive local rows, one small copy per cell and array
             size_t local = 0;
             for (size_t k = 0; k < g->n_chunks; ++k) {
                 const size_t lo = g->cell_lo(k, d), cnt = g->cell_hi(k, d) - lo;
                 if (!cnt) continue;
-                if (!hip_ok(hipMemcpyAsync(h_min_dist + lo, c->d_out_d.p + local, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->s_main), "D2H") ||
-                    !hip_ok(hipMemcpyAsync(h_min_t + lo, c->d_out_t.p + local, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, c->s_main), "D2H")) { rc = AZ_ERR_HIP; break; }
+                if (hipMemcpyAsync(h_min_dist + lo, c->d_out_d.p + local, sizeof(double) * cnt, hipMemcpyDeviceToHost, c->s_main) != hipSuccess ||
+                    hipMemcpyAsync(h_min_t + lo, c->d_out_t.p + local, sizeof(uint32_t) * cnt, hipMemcpyDeviceToHost, c->s_main) != hipSuccess)
+                    return AZ_ERR_HIP;
                 local += cnt;
             }
+            if (hipStreamSynchronize(c->s_main) != hipSuccess) return AZ_ERR_HIP;
         }
+        return AZ_OK;
+    };
+    auto guarded_work = [&](int d) {
+        try {
+            rcs[d] = work(d);
+        } catch (const std::bad_alloc &) {
+            rcs[d] = AZ_ERR_ALLOC_FAILED;
+        } catch (...) {
+            rcs[d] = AZ_ERR_UNKNOWN;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int d = 1; d < g->n_dev; ++d) {
+            try {
+                th.emplace_back(guarded_work, d);
+            } catch (const std::system_error &) {
+                guarded_work(d);
+            }
+        }
+        guarded_work(0);
+        for (auto &t : th) t.join();
     }
-    for (int d = 0; d < g->n_dev; ++d) {
-        azh_constellation *c = g->shard[d];
-        if (!c) continue;
-        if ((h_min_dist || rc != AZ_OK) && (set_device(c) != AZ_OK || !hip_ok(hipStreamSynchronize(c->s_main), "sync")))
-            rc = rc == AZ_OK ? AZ_ERR_HIP : rc;
+    for (int d = 0; d < g->n_dev; ++d)
+        if (rcs[d] != AZ_OK && rc == AZ_OK) rc = rcs[d];
+    if (rc != AZ_OK) {
+        if (g_last_error.empty()) g_last_error = "sharded screen failed on a device";
+        (void)hipGetLastError();
+        for (int d = 0; d < g->n_dev; ++d) {
+            azh_constellation *c = g->shard[d];
+            if (c && set_device(c) == AZ_OK) (void)hipStreamSynchronize(c->s_main);
+        }
     }
     return rc;
 }
