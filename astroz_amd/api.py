@@ -15,6 +15,8 @@ path.  Differences from the reference that are deliberate (SURVEY.md 8a17 "quirk
 * ``jday`` is python-sgp4's exact formula (the reference's passes seconds through an f16).
 """
 import math
+import threading
+import weakref
 
 import numpy as np
 
@@ -61,12 +63,21 @@ def days2mdhms(year, days):
     return month, day, hour, minute, second
 
 
+# Satrec objects whose device-side initialisation is still pending, by gravity model (weak references).  The first one that
+# needs its handle takes ALL pending records of its gravity model along: one constellation handle, one init launch -- making a
+# handle costs ~0.4 ms (a stream, events, allocations, a launch, a synchronize) and freeing one ~0.5 ms, which a python-sgp4
+# style loop over a catalog (`[Satrec.twoline2rv(a, b) for ...]`, then `sat.sgp4(jd, fr)` for each) would pay 13,478 times.
+_PENDING = {}
+_PENDING_LOCK = threading.Lock()
+
+
 class Satrec:
     """One satellite record.  Use :meth:`twoline2rv`.
 
     TLE text is parsed on the host at construction; the element initialisation (and every
-    propagation) runs on the GPU and is performed lazily -- or in one batch when the record is
-    placed in a :class:`SatrecArray`."""
+    propagation of more than a few points) runs on the GPU and is performed lazily -- together with every other record that is
+    waiting for it (one shared handle, `_idx` = the record's row) -- or in one batch when the record is placed in a
+    :class:`SatrecArray`."""
 
     def __init__(self, line1, line2, whichconst, fields):
         self._line1 = line1
@@ -79,10 +90,16 @@ class Satrec:
         self.jdsatepochF = epoch_jd - self.jdsatepoch
         self.error = 0
         self.t = 0.0
-        self._dev = None      # 1-satellite device constellation (lazy)
+        self._dev = None      # device constellation holding this record (lazy; shared with the records initialised with it)
+        self._idx = 0         # ... and the record's row in it
         self._status = None   # (err, is_deep, irez), filled by _ensure or by a SatrecArray
         self._a = None
-        self._scalar = None   # (shim function, handle address, epoch) of the scalar call, or False without the shim
+        self._scalar = None   # (shim function, handle address, row, epoch) of the scalar call, or False without the shim
+        with _PENDING_LOCK:
+            lst = _PENDING.setdefault(self.whichconst, [])
+            lst.append(weakref.ref(self))
+            if (len(lst) & 4095) == 0:      # (records that were dropped, or initialised through somebody else's batch)
+                lst[:] = [r for r in lst if r() is not None and r()._dev is None]
 
     @classmethod
     def twoline2rv(cls, line1, line2, whichconst=WGS72):
@@ -106,12 +123,20 @@ class Satrec:
     # -- device-derived attributes (satrec.zig L432-474) ---------------------------------
     def _ensure(self):
         if self._dev is None:
-            self._dev = _native.DeviceConstellation.from_tle_lines(
-                [(self._line1, self._line2)], self.whichconst)
-            e, d, r = self._dev.status
-            self._status = (int(e[0]), bool(d[0]), int(r[0]))
-            if self._status[0]:
-                self.error = self._status[0]
+            with _PENDING_LOCK:
+                refs = _PENDING.pop(self.whichconst, [])
+            batch = [self]
+            for ref in refs:
+                s = ref()
+                if s is not None and s is not self and s._dev is None:
+                    batch.append(s)
+            dev = _native.DeviceConstellation.from_tle_lines([(s._line1, s._line2) for s in batch], self.whichconst)
+            e, d, r = dev.status
+            for i, s in enumerate(batch):
+                s._dev, s._idx = dev, i
+                s._status = (int(e[i]), bool(d[i]), int(r[i]))
+                if s._status[0]:
+                    s.error = s._status[0]
         return self._dev
 
     @property
@@ -123,7 +148,7 @@ class Satrec:
     @property
     def a(self):
         if self._a is None:
-            self._a = float(self._ensure().field("a")[0])
+            self._a = float(self._ensure().field("a")[self._idx])
         return self._a
 
     @property
@@ -145,7 +170,7 @@ class Satrec:
         if sc is None:
             sc = self._bind_scalar()
         if sc:
-            t, rc, e, r, v = sc[0](sc[1], jd, fr, sc[2])
+            t, rc, e, r, v = sc[0](sc[1], sc[2], jd, fr, sc[3])
             if rc:
                 _native.check(rc, "azh_propagate_one_host")
             self.t = t
@@ -153,14 +178,14 @@ class Satrec:
             return e, r, v
         tsince = ((jd + fr) - (self.jdsatepoch + self.jdsatepochF)) * 1440.0
         self.t = tsince
-        e, r, v = self._ensure().propagate_one(0, tsince)
+        e, r, v = self._ensure().propagate_one(self._idx, tsince)
         self.error = int(e[0])
         return self.error, tuple(float(x) for x in r[0]), tuple(float(x) for x in v[0])
 
     def _bind_scalar(self):
         dev = self._ensure()
         mod = _native.fast_scalar()
-        self._scalar = (mod.sgp4, dev.handle_address(), self.jdsatepoch + self.jdsatepochF) if mod is not None else False
+        self._scalar = (mod.sgp4, dev.handle_address(), self._idx, self.jdsatepoch + self.jdsatepochF) if mod is not None else False
         return self._scalar
 
     def sgp4_array(self, jd, fr):
@@ -168,7 +193,7 @@ class Satrec:
         jd = np.atleast_1d(np.asarray(jd, dtype=np.float64))
         fr = np.atleast_1d(np.asarray(fr, dtype=np.float64))
         tsince = ((jd + fr) - (self.jdsatepoch + self.jdsatepochF)) * 1440.0
-        e, r, v = self._ensure().propagate_one(0, tsince)
+        e, r, v = self._ensure().propagate_one(self._idx, tsince)
         return e, r, v
 
 

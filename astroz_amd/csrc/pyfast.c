@@ -20,13 +20,13 @@ static PyObject *az_bind(PyObject *self, PyObject *arg)
     Py_RETURN_NONE;
 }
 
-/* sgp4(handle, jd, fr, epoch_jd) -> (tsince_min, rc, err, (x, y, z), (vx, vy, vz));  tsince = ((jd + fr) - epoch) * 1440 as
- * satrec.zig L176-178 forms it */
+/* sgp4(handle, sat_index, jd, fr, epoch_jd) -> (tsince_min, rc, err, (x, y, z), (vx, vy, vz));  tsince = ((jd + fr) - epoch) * 1440
+ * as satrec.zig L176-178 forms it.  sat_index: the record's row in the handle (Satrec objects made together share one handle) */
 static PyObject *az_sgp4(PyObject *self, PyObject *const *args, Py_ssize_t nargs)
 {
     (void)self;
-    if (nargs != 4) {
-        PyErr_SetString(PyExc_TypeError, "sgp4(handle, jd, fr, epoch_jd)");
+    if (nargs != 5) {
+        PyErr_SetString(PyExc_TypeError, "sgp4(handle, sat_index, jd, fr, epoch_jd)");
         return NULL;
     }
     if (!g_one_host) {
@@ -34,18 +34,19 @@ static PyObject *az_sgp4(PyObject *self, PyObject *const *args, Py_ssize_t nargs
         return NULL;
     }
     void *h = PyLong_AsVoidPtr(args[0]);
-    const double jd = PyFloat_AsDouble(args[1]), fr = PyFloat_AsDouble(args[2]), ep = PyFloat_AsDouble(args[3]);
+    const size_t sat = PyLong_AsSize_t(args[1]);
+    const double jd = PyFloat_AsDouble(args[2]), fr = PyFloat_AsDouble(args[3]), ep = PyFloat_AsDouble(args[4]);
     if (PyErr_Occurred()) return NULL;
     const double t = ((jd + fr) - ep) * 1440.0;
     double r[3], v[3];
     uint8_t e = 0;
-    const int32_t rc = g_one_host(h, 0, &t, 1, r, v, &e);
+    const int32_t rc = g_one_host(h, sat, &t, 1, r, v, &e);
     return Py_BuildValue("dii(ddd)(ddd)", t, (int)rc, (int)e, r[0], r[1], r[2], v[0], v[1], v[2]);
 }
 
 static PyMethodDef methods[] = {
     {"bind", az_bind, METH_O, "bind(address of azh_propagate_one_host)"},
-    {"sgp4", (PyCFunction)(void (*)(void))az_sgp4, METH_FASTCALL, "sgp4(handle, jd, fr, epoch_jd) -> (tsince, rc, err, r, v)"},
+    {"sgp4", (PyCFunction)(void (*)(void))az_sgp4, METH_FASTCALL, "sgp4(handle, sat_index, jd, fr, epoch_jd) -> (tsince, rc, err, r, v)"},
     {NULL, NULL, 0, NULL}};
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_azfast", "scalar-call shim over libastroz_hip.so", -1, methods, NULL, NULL, NULL, NULL};
 PyMODINIT_FUNC PyInit__azfast(void) { return PyModule_Create(&moddef); }

@@ -190,11 +190,11 @@ def run_secondary(torch, _native, synth, cuda, stream, dev2, pairs2, skip=()):
             sweep = {}
             for npts in (1, 8, 64, 256, 1024):
                 tt = np.linspace(0.0, 1440.0, npts)
-                sweep[str(npts)] = {"host_route_us": wall(lambda: sat._ensure().propagate_one(0, tt), 2000 if npts <= 64 else 200)}
+                sweep[str(npts)] = {"host_route_us": wall(lambda: sat._ensure().propagate_one(sat._idx, tt), 2000 if npts <= 64 else 200)}
             _native.set_host_points(0)
             for npts in (1, 8, 64, 256, 1024):
                 tt = np.linspace(0.0, 1440.0, npts)
-                sweep[str(npts)]["kernel_route_us"] = wall(lambda: sat._ensure().propagate_one(0, tt), 300)
+                sweep[str(npts)]["kernel_route_us"] = wall(lambda: sat._ensure().propagate_one(sat._idx, tt), 300)
             _native.set_host_points(n_host)
             # the same calls on a grid that CHANGES every call (stage_inputs skips the staging of byte-identical
             # inputs, so the loops above time the repeated-grid case): fr moved by a few microseconds per call

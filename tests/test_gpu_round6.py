@@ -379,3 +379,54 @@ def test_few_satellites_few_times_take_the_host_route(native, orc, synth):
     assert dev.last_path() != native.PATH_HOST_STEP
     _, q0, _ = cat.propagate(times, off, layout=orc.SAT_MAJOR, velocities=False)
     assert np.abs(pos[good] - q0[good]).max() < TOL_R
+
+
+def test_satrecs_made_together_share_one_handle(native, orc, synth):
+    """python-sgp4's loop over a catalog: `[Satrec.twoline2rv(a, b) for ...]`, then `sat.sgp4(jd, fr)` for each.  The first
+    record that needs the device takes every pending record of its gravity model along (one handle, one init launch: a handle of
+    its own per record cost 0.4 ms to make and 0.5 ms to free); every record then answers through its own row -- oracle parity,
+    attributes, a record made later, a dropped record, a second gravity model."""
+    import gc
+    from astroz_amd.api import Satrec, WGS72, WGS84
+    gc.collect()
+    pairs = synth.synth_catalog(n_near=260, n_deep=40, seed=23)
+    cat = orc.Catalog.from_pairs(pairs, orc.WGS72)
+    sats = [Satrec.twoline2rv(a, b, WGS72) for a, b in pairs]
+    other = Satrec.twoline2rv(pairs[0][0], pairs[0][1], WGS84)          # another gravity model: its own batch
+    dropped = Satrec.twoline2rv(pairs[1][0], pairs[1][1], WGS72)
+    del dropped
+    t0 = time.perf_counter()
+    res = [s.sgp4(s.jdsatepoch, s.jdsatepochF + 0.5) for s in sats]
+    first_us = (time.perf_counter() - t0) / len(sats) * 1e6
+    assert all(s._dev is sats[0]._dev for s in sats) and sats[0]._dev.n >= len(sats)
+    assert sorted(s._idx for s in sats) == sorted(set(s._idx for s in sats))
+    assert other._dev is None
+    for i, (s, (e, r, v)) in enumerate(zip(sats, res)):
+        ts = ((s.jdsatepoch + (s.jdsatepochF + 0.5)) - (s.jdsatepoch + s.jdsatepochF)) * 1440.0
+        rc, r0, v0 = cat.propagate_one(i, ts)
+        assert e == rc
+        assert np.abs(np.array(r) - r0).max() < TOL_R and np.abs(np.array(v) - v0).max() < TOL_V
+        assert s.is_deep_space == bool(cat.is_deep[i])
+    assert abs(sats[7].a - cat.field(7, "a")) < 1e-12 * cat.field(7, "a")
+    jd_, fr_ = np.full(300, sats[5].jdsatepoch), sats[5].jdsatepochF + np.arange(300) / 1440.0
+    e, r, v = sats[5].sgp4_array(jd_, fr_)                               # kernel route, own row
+    ts_ = ((jd_ + fr_) - (sats[5].jdsatepoch + sats[5].jdsatepochF)) * 1440.0     # (the times the call forms: uniform to 4e-7 min only)
+    sub = orc.Catalog.from_pairs([pairs[5]], orc.WGS72)
+    _, p0, v0 = sub.propagate(ts_, None, layout=orc.SAT_MAJOR)
+    assert np.abs(r - p0[0]).max() < TOL_R and np.abs(v - v0[0]).max() < TOL_V
+    t0 = time.perf_counter()
+    for s in sats:
+        s.sgp4(s.jdsatepoch, s.jdsatepochF + 0.25)
+    again_us = (time.perf_counter() - t0) / len(sats) * 1e6
+    print("300 records made together: first scalar call %.1f us per record (incl. the shared handle), later calls %.2f us" % (first_us, again_us))
+    assert first_us < 100.0 and again_us < 5.0
+    late = Satrec.twoline2rv(pairs[3][0], pairs[3][1], WGS72)           # made after the batch: its own handle
+    e, r, v = late.sgp4(late.jdsatepoch, late.jdsatepochF + 0.5)
+    assert late._dev is not sats[0]._dev and late._idx == 0
+    assert np.abs(np.array(r) - np.array(res[3][1])).max() < 1e-9
+    e84, r84, _ = other.sgp4(other.jdsatepoch, other.jdsatepochF + 0.5)
+    assert other._dev is not sats[0]._dev and e84 == 0 and 1e-4 < np.abs(np.array(r84) - np.array(res[0][1])).max() < 5.0   # WGS84 vs WGS72
+    dev0 = sats[0]._dev
+    del sats, res, s
+    gc.collect()
+    assert sys.getrefcount(dev0) <= 3            # the records are gone: only this test holds the shared handle

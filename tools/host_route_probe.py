@@ -44,8 +44,8 @@ for name, l1, l2 in (("ISS (near-earth)", "1 25544U 98067A   24127.82853009  .00
     for npts in (1, 4, 16, 32, 64, 128, 256, 512, 1024, 4096):
         tt = np.linspace(0.0, 1440.0, npts)
         _native.set_host_points(1 << 20)
-        h = wall(lambda: dev.propagate_one(0, tt), 2000 if npts <= 64 else 200)
+        h = wall(lambda: dev.propagate_one(sat._idx, tt), 2000 if npts <= 64 else 200)
         _native.set_host_points(0)
-        k = wall(lambda: dev.propagate_one(0, tt), 300)
+        k = wall(lambda: dev.propagate_one(sat._idx, tt), 300)
         print("propagate_one x %5d points: host route %8.2f us (%.3f us/point)   kernel route %8.2f us" % (npts, h, h / npts, k))
     _native.set_host_points(n0)
