@@ -182,6 +182,22 @@ class Satrec:
         self.error = int(e[0])
         return self.error, tuple(float(x) for x in r[0]), tuple(float(x) for x in v[0])
 
+    def sgp4_array_into(self, jd, fr, positions, velocities):
+        """The native single-satellite batch call (satrec.zig L296-345): like :meth:`sgp4_array`, written into the caller's
+        writable float64 buffers of ``len(jd) * 3`` elements each."""
+        jd = np.atleast_1d(np.asarray(jd, dtype=np.float64))
+        fr = np.atleast_1d(np.asarray(fr, dtype=np.float64))
+        tsince = ((jd + fr) - (self.jdsatepoch + self.jdsatepochF)) * 1440.0
+        outs = []
+        for name, a in (("positions", positions), ("velocities", velocities)):
+            a = np.asarray(a)
+            if a.dtype != np.float64 or not a.flags.c_contiguous or not a.flags.writeable or a.size < 3 * len(tsince):
+                raise ValueError("%s must be a writable C-contiguous float64 array of len(jd) * 3 elements" % name)
+            outs.append(a.reshape(-1)[:3 * len(tsince)])
+        _, r, v = self._ensure().propagate_one(self._idx, tsince)
+        outs[0][:] = r.reshape(-1)
+        outs[1][:] = v.reshape(-1)
+
     def _bind_scalar(self):
         dev = self._ensure()
         mod = _native.fast_scalar()
@@ -231,6 +247,32 @@ class SatrecArray:
     @property
     def num_satellites(self):
         return self._num_sats
+
+    @property
+    def epochs(self):
+        """Epoch Julian date of every satellite (the native type's `epochs` getter, bindings/python/src/satrec.zig L807)."""
+        return [float(x) for x in self._epochs]
+
+    def propagate_into(self, times, positions, velocities=None, epoch_offsets=None):
+        """The native batch call the reference's facade is built on (satrec.zig L895-990): TEME, TIME-major --
+        ``positions`` / ``velocities`` are caller-owned writable float64 buffers of at least ``num_satellites * n_times * 3``
+        elements, filled as ``(n_times, num_satellites, 3)``; ``times`` in minutes, ``epoch_offsets`` (minutes, per satellite;
+        default: zeros = every satellite relative to its own epoch).  ValueError when a buffer is too small."""
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        need = self._num_sats * len(t) * 3
+        arrs = []
+        for name, a in (("positions", positions), ("velocities", velocities)):
+            if a is None:
+                arrs.append(None)
+                continue
+            a = np.asarray(a)
+            if a.dtype != np.float64 or not a.flags.c_contiguous or not a.flags.writeable:
+                raise ValueError("%s must be a writable C-contiguous float64 array" % name)
+            if a.size < need:
+                raise ValueError("%s array too small" % name)
+            arrs.append(a.reshape(-1)[:need])
+        off = None if epoch_offsets is None else np.ascontiguousarray(epoch_offsets, dtype=np.float64)
+        self._dev.propagate_host(t, off, pos=arrs[0], vel=arrs[1], layout=_native.TIME_MAJOR)
 
     def _grid(self, jd, fr):
         jd = np.atleast_1d(np.asarray(jd, dtype=np.float64))

@@ -430,3 +430,34 @@ def test_satrecs_made_together_share_one_handle(native, orc, synth):
     del sats, res, s
     gc.collect()
     assert sys.getrefcount(dev0) <= 3            # the records are gone: only this test holds the shared handle
+
+
+def test_native_type_methods_of_the_reference(native, orc, synth):
+    """the methods of the reference's NATIVE types that its facade is built on and a user can reach through attribute
+    delegation (bindings/python/src/satrec.zig): Satrec.sgp4_array_into, SatrecArray.propagate_into / .epochs"""
+    from astroz_amd.api import Satrec, SatrecArray, WGS72
+    pairs = synth.synth_catalog(n_near=70, n_deep=6, seed=41)
+    cat = orc.Catalog.from_pairs(pairs, orc.WGS72)
+    sats = [Satrec.twoline2rv(a, b, WGS72) for a, b in pairs]
+    sa = SatrecArray(sats)
+    assert np.allclose(sa.epochs, cat.epoch_jd, rtol=0, atol=1e-9) and isinstance(sa.epochs, list)
+    times = np.arange(0.0, 200.0, 2.5)
+    pos, vel = np.full((len(times), sa.num_satellites, 3), np.nan), np.full((len(times), sa.num_satellites, 3), np.nan)
+    sa.propagate_into(times, pos, vel)                                    # zeros = each satellite from its own epoch
+    _, p0, v0 = cat.propagate(times, None, layout=orc.TIME_MAJOR)
+    assert np.abs(pos - p0).max() < TOL_R and np.abs(vel - v0).max() < TOL_V
+    off = np.linspace(-30.0, 30.0, sa.num_satellites)
+    flat = np.zeros(len(times) * sa.num_satellites * 3 + 5)              # (a flat buffer with room to spare, positions only)
+    sa.propagate_into(times, flat, epoch_offsets=off)
+    _, p1, _ = cat.propagate(times, off, layout=orc.TIME_MAJOR, velocities=False)
+    assert np.abs(flat[:p1.size].reshape(p1.shape) - p1).max() < TOL_R and not flat[p1.size:].any()
+    with pytest.raises(ValueError):
+        sa.propagate_into(times, np.zeros(10))
+    s = sats[3]
+    jd, fr = np.full(50, s.jdsatepoch), s.jdsatepochF + np.arange(50) / 96.0
+    r, v = np.empty((50, 3)), np.empty((50, 3))
+    s.sgp4_array_into(jd, fr, r, v)
+    e2, r2, v2 = s.sgp4_array(jd, fr)
+    assert np.array_equal(r, r2) and np.array_equal(v, v2) and not e2.any()
+    with pytest.raises(ValueError):
+        s.sgp4_array_into(jd, fr, np.empty(10), v)
