@@ -99,6 +99,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # DRY RUN of the N > 1 code path on a box with ONE GPU (tools/gpu_world2_dryrun.sh): every rank on device 0, process group over
+    # gloo (RCCL refuses two ranks on one device) -- exercises the barriers, reductions, object gathers, per-rank certificates and
+    # the sharded screen with a real world size; its timings mean nothing and the line says so
+    dry = os.environ.get("ASTROZ_BENCH_DRYRUN_ONE_DEVICE") == "1"
+    if dry:
+        local_rank = 0
     if world != a.gpus and world > 1:
         a.gpus = world
 
@@ -110,7 +116,10 @@ def main():
     if world > 1 or a.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if rank == 0:
         entry.build()          # no-op when the in-tree .so files are current
     if world > 1:
@@ -124,7 +133,7 @@ def main():
     vel_on = not a.pos_only
     odt = torch.float32 if a.f32_out else torch.float64
     sharded = (world > 1 or a.force_sharded) and a.scaling == "strong"      # BASELINE config 4
-    gather = sharded and not a.no_gather
+    gather = sharded and not a.no_gather and not dry      # (gloo has no all-gather of device tensors: the dry run skips the gather)
     mode = {"teme": 0, "ecef": 1, "geodetic": 2}[a.mode]
     ref_jd = 0.0   # set with the workload (synth.START_JD) once the package is imported
     if sharded and (a.layout != "sat" or a.f32_out or mode):
@@ -358,7 +367,7 @@ def main():
         "value": value, "unit": "propagations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True,
         "scaling": "n/a" if world == 1 else a.scaling, "vs_baseline": None,
-        "dtype": "f64" if "fp64 arithmetic" == arith else "f32 (+f64 phase/radius chains)", "data": "synthetic",
+        "dtype": "f64" if "fp64 arithmetic" == arith else "f32 (+f64 phase/radius chains)", "data": "synthetic" if not dry else "synthetic; DRY RUN: all ranks on ONE device over gloo -- code-path check, timings meaningless",
         "config": {
             "workload": wl + ("" if a.grid == "uniform" else " [time grid: %s]" % a.grid), "launch_path": dev.last_path(), "n_sats_total": n_total, "n_sats_per_gpu": n_local, "n_times": n_times, "gather": bool(gather),
             "precondition_ms": a.precondition_ms, "precondition_steps": n_pre,

@@ -463,3 +463,29 @@ def test_native_type_methods_of_the_reference(native, orc, synth):
     assert np.array_equal(r, r2) and np.array_equal(v, v2) and not e2.any()
     with pytest.raises(ValueError):
         s.sgp4_array_into(jd, fr, np.empty(10), v)
+
+
+def test_bench_n_gt_1_code_path_with_a_real_world_size(native):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, two ranks), on a one-GPU box: both ranks on device 0
+    over gloo (ASTROZ_BENCH_DRYRUN_ONE_DEVICE=1; RCCL refuses two ranks on one device).  Every rank must reach every collective
+    -- timing reductions, kernel-only / replicate points, the sharded screen's agreement and object gather, the per-rank
+    certificates -- and rank 0's line must carry one certificate per rank, the sharded screen with 0 index mismatches and a
+    CPU baseline.  (Timings of a dry run mean nothing; the line's `data` field says so.)"""
+    import json
+    import subprocess
+    env = dict(os.environ, ASTROZ_BENCH_DRYRUN_ONE_DEVICE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29583", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--precondition-ms", "0", "--sats", "2000", "--times", "200", "--cpu-seconds", "0.5"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and "DRY RUN" in j["data"]
+    pr = j["parity"]["per_rank"]
+    assert [c[0] for c in pr] == [0, 1] and all(c[1] < TOL_R and c[2] < TOL_V and c[4] is True for c in pr), pr
+    ss = j["config"]["sharded_screen"]
+    assert ss["index_mismatches"] == 0 and ss["max_dd_km"] < 1e-6 and ss["ms"] > 0
+    assert j["config"]["t_kernel_ms"] > 0 and j["config"]["t_replicate_ms"] > 0
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1
