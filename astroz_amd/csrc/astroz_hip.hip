@@ -195,6 +195,7 @@ struct azh_constellation {
     unsigned cached_n_times = 0;
     int cached_mode = 0;
     hipStream_t s_main = nullptr, s_deep = nullptr, s_ecc = nullptr;
+    bool own_stream = true; // false: s_main is the device's shared stream of small handles (never destroyed with the handle)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
     unsigned off_cat = 0; // d_list + off_cat: near-earth members in plain catalog order (k_tiles_fast: runs of consecutive rows)
     unsigned off_deep_cat = 0; // d_list + off_deep_cat: deep-space members in plain catalog order (lane = time kernels)
@@ -257,6 +258,23 @@ inline size_t host_points() { return azhost::cpu_ok() ? g_host_points.load(std::
 constexpr int32_t AZ_RC_EAGER = 0x7a5eca9;
 int set_device(const azh_constellation *c) { return hip_ok(hipSetDevice(c->device), "hipSetDevice") ? AZ_OK : AZ_ERR_HIP; }
 
+// One launch stream per DEVICE for all handles of a few satellites (what sgp4_init / Satrec make, possibly by the thousand): a
+// stream of its own per handle was 0.4-3.5 ms to create and 0.5-2.5 ms to destroy -- hipStreamCreate / hipStreamDestroy get
+// slower with every live stream (3.5 / 2.5 ms each at 500) -- for handles that have nothing to overlap.  Created on first use,
+// kept for the life of the process.  Launches of different handles interleave on it; a synchronize waits for all of them.
+hipStream_t small_stream(int device)
+{
+    static std::mutex mu;
+    static std::map<int, hipStream_t> streams;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = streams.find(device);
+    if (it != streams.end()) return it->second;
+    hipStream_t s = nullptr;
+    if (!hip_ok(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate")) return nullptr;
+    streams[device] = s;
+    return s;
+}
+
 void drop_graphs(azh_constellation *c);
 void destroy(azh_constellation *c)
 {
@@ -303,7 +321,7 @@ void destroy(azh_constellation *c)
     if (c->ev_t0) (void)hipEventDestroy(c->ev_t0);
     if (c->ev_t1) (void)hipEventDestroy(c->ev_t1);
     if (c->s_deep && c->s_deep != c->s_main) (void)hipStreamDestroy(c->s_deep);
-    if (c->s_main) (void)hipStreamDestroy(c->s_main);
+    if (c->s_main && c->own_stream) (void)hipStreamDestroy(c->s_main);
     delete c;
 }
 
@@ -334,7 +352,11 @@ int32_t build(const std::vector<double> (&cols)[AZ_NUM_RAW], size_t n, int grav,
         // a few satellites -- what sgp4_init / Satrec create, possibly by the thousand -- has nothing to overlap: its side
         // streams ARE the launch stream (the fork / join events then order a stream with itself)
         const bool side_streams = n > 16;
-        if (!hip_ok(hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking), "hipStreamCreate") ||
+        if (!side_streams) {
+            c->s_main = small_stream(device);
+            c->own_stream = false;
+        }
+        if ((side_streams ? !hip_ok(hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking), "hipStreamCreate") : c->s_main == nullptr) ||
             (side_streams && (!hip_ok(hipStreamCreateWithFlags(&c->s_deep, hipStreamNonBlocking), "hipStreamCreate") ||
                               !hip_ok(hipStreamCreateWithFlags(&c->s_ecc, hipStreamNonBlocking), "hipStreamCreate"))) ||
             !hip_ok(hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming), "hipEventCreate") ||
@@ -1261,7 +1283,8 @@ int32_t launch_all(azh_constellation *c, double *d_pos, double *d_vel, int layou
 int32_t launch_cached(azh_constellation *c, double *d_pos, double *d_vel, int layout, size_t stride, uint8_t *d_err, hipStream_t st,
                       int f32 = 0, size_t row_lo = 0, size_t row_hi = ~(size_t)0)
 {
-    if (!c->graphs_on || c->timing || c->cached_n_times == 0) return launch_all(c, d_pos, d_vel, layout, stride, d_err, st, f32, row_lo, row_hi);
+    // (a small handle launches on its device's shared stream: no capture there)
+    if (!c->graphs_on || c->timing || c->cached_n_times == 0 || !c->own_stream) return launch_all(c, d_pos, d_vel, layout, stride, d_err, st, f32, row_lo, row_hi);
     const unsigned sig = plan_sig(c);
     azh_constellation::LaunchGraph *hit = nullptr, *pending = nullptr;
     for (auto &g : c->graphs)
