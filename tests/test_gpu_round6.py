@@ -489,3 +489,47 @@ def test_bench_n_gt_1_code_path_with_a_real_world_size(native):
     assert ss["index_mismatches"] == 0 and ss["max_dd_km"] < 1e-6 and ss["ms"] > 0
     assert j["config"]["t_kernel_ms"] > 0 and j["config"]["t_replicate_ms"] > 0
     assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1
+
+
+def test_small_handles_share_a_stream_safely(native, orc, synth):
+    """Handles of a few satellites launch on ONE stream per device (round 6).  Eight host threads, each with its own one-satellite
+    handles, hammer the kernel route (1,000-point series: above the host-route limit) and the constellation route concurrently --
+    ctypes releases the GIL, so the launches really interleave on the shared stream: every result equals the single-threaded one
+    bit for bit and the oracle at the gate; handles are made and freed while others are in flight."""
+    import threading
+    pairs = synth.synth_catalog(n_near=14, n_deep=2, seed=77)
+    cat = orc.Catalog.from_pairs(pairs, orc.WGS72)
+    ts = np.linspace(-700.0, 2100.0, 1000)
+    _, p0, v0 = cat.propagate(ts, None, layout=orc.SAT_MAJOR)
+    ref = {}
+    for i, pr in enumerate(pairs):
+        h = native.DeviceConstellation.from_tle_lines([pr], native.WGS72, 0)
+        e, r, v = h.propagate_one(0, ts)
+        assert h.last_path() != native.PATH_HOST_STEP
+        ref[i] = (r.copy(), v.copy())
+        assert np.abs(r - p0[i]).max() < TOL_R and np.abs(v - v0[i]).max() < TOL_V
+        h.close()
+    errors = []
+
+    def worker(tid):
+        try:
+            rng = np.random.default_rng(tid)
+            for it in range(25):
+                i = int(rng.integers(len(pairs)))
+                h = native.DeviceConstellation.from_tle_lines([pairs[i]], native.WGS72, 0)
+                e, r, v = h.propagate_one(0, ts)
+                if not (np.array_equal(r, ref[i][0]) and np.array_equal(v, ref[i][1]) and not e.any()):
+                    errors.append((tid, it, i, "one-satellite series"))
+                pos = np.empty((1, 300, 3))
+                h.propagate_host(ts[:300], None, pos=pos, layout=native.SAT_MAJOR)
+                if np.abs(pos[0] - p0[i][:300]).max() > TOL_R:
+                    errors.append((tid, it, i, "constellation call"))
+                h.close()
+        except Exception as exc:      # pragma: no cover
+            errors.append((tid, repr(exc)))
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
