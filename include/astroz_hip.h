@@ -363,7 +363,7 @@ int32_t azh_selftest_math(const double *x, size_t n, double *out6n, int32_t devi
 int32_t azh_selftest_coords(int32_t op, const double in[4], double out[5]);
 /* the host route's step (azh_set_host_points; astroz_amd/csrc/host_step.h) on a caller-supplied element table
  * el[field * n_pad + sat] (the 85 rows of astroz_amd/csrc/fields.h, in that order) with status word `flags`: n points, out6n = n x
- * (x, y, z, vx, vy, vz), err (n, optional).  Needs no device: lets the CPU test tier hold the shipped object to the oracle.
+ * (x, y, z, vx, vy, vz), err (n, optional).  Needs no device: lets the CPU test tier hold the shipped object to its reference checker.
  * Test infrastructure; not part of the reference surface. */
 int32_t azh_selftest_host_step(const double *el, size_t n_pad, size_t sat, uint32_t flags, int32_t grav, const double *tsince_min,
                                size_t n, double *out6n, uint8_t *err);
